@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/encode_*.npz by running the REFERENCE's own model classes (unmodified source,
+imported from /root/reference through oracle/_ref_shim.py) on seeded inputs.
+
+Run in the build container only:   python -B oracle/gen_golden.py
+Outputs are data (inputs, weights, expected outputs) -- no reference source or bytecode is written.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import numpy as np
+import torch
+
+import _ref_shim as shim
+from oracle import encoder_oracle as eo
+
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+FIXTURES = {
+    # name: (vision dims, nbit, nclass, adapter b, center_dim, batch, hidden_act)
+    "encode_tiny": (dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                         image_size=64, patch_size=16, projection_dim=32), 16, 10, 384, 32, 3, "quick_gelu"),
+    "encode_hd64": (dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                         image_size=64, patch_size=16, projection_dim=64), 64, 20, 64, 48, 4, "quick_gelu"),
+}
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    for name, (vd, nbit, nclass, b, cdim, batch, act) in FIXTURES.items():
+        model = shim.build_reference_model(vd, nbit=nbit, nclass=nclass, adapter_bottleneck_dim=b, seed=7,
+                                           center_dim=cdim, hidden_act=act)
+        cfg = dict(D=vd["hidden_size"], L=vd["num_hidden_layers"], heads=vd["num_attention_heads"],
+                   M=vd["intermediate_size"], patch=vd["patch_size"], image=vd["image_size"],
+                   P=vd["projection_dim"], b=b)
+        # randomise everything the reference zero/one-initialises (adapters' up_proj, LN, BN stats) so the
+        # whole path is exercised; keys follow the reference state_dict layout.
+        syn = eo.synthetic_state_dict(cfg, nbit=nbit, nclass=nclass, seed=11, center_dim=cdim)
+        missing, unexpected = model.load_state_dict(syn, strict=False)
+        assert not unexpected, unexpected
+        model.eval()
+        x = eo.synthetic_images(batch, vd["image_size"], seed=5)
+        with torch.no_grad():
+            feats, out = model(x)
+        sd = model.state_dict()
+        all_keys = sorted(sd.keys())
+        keep = {k: v.detach().cpu().numpy() for k, v in sd.items()
+                if not k.startswith("adapter_params.") and not k.startswith("trainable_params.")
+                and not k.startswith("backbone.text_projection") and k != "backbone.logit_scale"
+                and k != "hash_bn.num_batches_tracked"}
+        payload = {"sd/" + k: v for k, v in keep.items()}
+        payload["meta/all_state_dict_keys"] = np.array(all_keys)
+        payload["meta/heads"] = np.int64(vd["num_attention_heads"])
+        payload["meta/upt_heads"] = np.int64(8)
+        payload["meta/act"] = np.array(act)
+        payload["in/images"] = x.numpy()
+        payload["out/codes"] = out["codes"].numpy()
+        payload["out/hash_features"] = out["hash_features"].numpy()
+        payload["out/logits_cont"] = out["logits_cont"].numpy()
+        payload["out/logits_bin"] = out["logits_bin"].numpy()
+        payload["out/logits_concept"] = out["logits_concept"].numpy()
+        payload["out/image_features"] = feats.numpy()
+        hs = out["image_hidden_states"]
+        payload["out/h0"] = hs[0].numpy()
+        payload["out/h1"] = hs[1].numpy()
+        payload["out/h_last"] = hs[-1].numpy()
+        payload["out/attn0"] = out["attn_cache"][0].numpy()
+        path = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(path, **payload)
+        print(name, "->", path, f"{os.path.getsize(path) / 1e6:.2f} MB",
+              "codes", out["codes"].shape, "|codes| mean", float(out["codes"].abs().mean()))
+
+    # directly importable reference module (no shim needed): CosSim
+    shim.install()
+    from models.layers.cossim import CosSim  # unmodified reference source
+    torch.manual_seed(3)
+    cs = CosSim(24, 7)
+    xin = torch.randn(5, 24)
+    with torch.no_grad():
+        y = cs(xin)
+    np.savez_compressed(os.path.join(GOLDEN, "cossim.npz"), centroids=cs.centroids.detach().numpy(),
+                        x=xin.numpy(), logits=y.numpy())
+    print("cossim ->", y.shape)
+
+
+if __name__ == "__main__":
+    main()
