@@ -1,0 +1,95 @@
+"""ctypes binding of libconcepthash_hip.so (the C-ABI declared in include/concepthash_hip.h).
+
+The product path has NO fallback: if the library is missing, or an entry point is absent, importing callers get a
+loud ``RuntimeError`` -- never a silent PyTorch/CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32,
+                    c_uint64, c_ulonglong, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libconcepthash_hip.so")
+ABI_VERSION = 1
+
+
+class ModelConfig(Structure):
+    _fields_ = [(n, c_int32) for n in ("image_size", "patch", "dim", "layers", "heads", "ffn", "adapter_dim", "ncontext",
+                                       "nbit", "nclass", "proj_dim", "center_dim", "upt_heads", "act", "max_batch")] + \
+               [("ln_eps", c_float), ("bn_eps", c_float)]
+
+
+class Tensor(Structure):
+    _fields_ = [("name", c_char_p), ("data", POINTER(c_float)), ("numel", c_int64)]
+
+
+# name -> (restype, argtypes); the single source of truth for the symbol-export test
+SIGNATURES = {
+    "ch_abi_version": (c_int, []),
+    "ch_last_error": (c_char_p, []),
+    "ch_model_create": (c_int, [POINTER(ModelConfig), POINTER(Tensor), c_int32, POINTER(c_void_p)]),
+    "ch_model_destroy": (None, [c_void_p]),
+    "ch_model_device_bytes": (c_size_t, [c_void_p]),
+    "ch_model_flops_per_image": (c_double, [c_void_p]),
+    "ch_encode": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_void_p]),
+    "ch_encode_hidden": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "ch_pack_sign": (c_int, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p]),
+    "ch_hamming_dist": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "ch_hamming_topk_workspace": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+    "ch_hamming_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
+    "ch_topk_merge": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ch_hamming_hist": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                                c_void_p, c_void_p]),
+    "ch_hamming_ap": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                              c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_hamming_hist_prefix": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library, or raise.  There is deliberately no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the ConceptHash MI355X path needs the HIP extension. "
+            "Build it with `python -m concepthash_amd.build` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 not found
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ch_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"ABI mismatch: library {lib.ch_abi_version()} vs binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().ch_last_error()
+        raise RuntimeError(f"{what} failed (status {status}): {msg.decode() if msg else 'unknown error'}")
+
+
+def stream_ptr(stream=None) -> c_void_p:
+    """hipStream_t of a torch stream (default: torch's current stream)."""
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return c_void_p(s.cuda_stream)
+
+
+def ptr(t) -> c_void_p:
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)

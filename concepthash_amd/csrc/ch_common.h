@@ -1,0 +1,60 @@
+// Shared device/host helpers for libconcepthash_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;   // MFMA A/B fragment (4 VGPRs)
+using bf16x4 = __attribute__((ext_vector_type(4))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;    // 16x16 accumulator
+using f32x16 = __attribute__((ext_vector_type(16))) float;  // 32x32 accumulator
+
+// round-to-nearest-even fp32 -> bf16 (plain cast compiles to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN)
+__device__ __forceinline__ bf16_t f2bf(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t x) { return __builtin_bit_cast(float, (uint32_t)x << 16); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- host-side error plumbing ----------------------------------------------------------------------------
+void ch_set_error(const std::string &msg);
+#define CH_CHECK_HIP(expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) {                                                                              \
+            ch_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
+            return 1;                                                                                        \
+        }                                                                                                    \
+    } while (0)
+#define CH_REQUIRE(cond, msg)                                                                                \
+    do {                                                                                                     \
+        if (!(cond)) {                                                                                       \
+            ch_set_error(std::string("invalid argument: ") + (msg));                                         \
+            return 2;                                                                                        \
+        }                                                                                                    \
+    } while (0)
+#define CH_LAUNCH_CHECK()                                                                                    \
+    do {                                                                                                     \
+        hipError_t _e = hipGetLastError();                                                                   \
+        if (_e != hipSuccess) {                                                                              \
+            ch_set_error(std::string("kernel launch: ") + hipGetErrorString(_e));                            \
+            return 3;                                                                                        \
+        }                                                                                                    \
+    } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up64(int64_t a, int64_t b) { return ceil_div64(a, b) * b; }

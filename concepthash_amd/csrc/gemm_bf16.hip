@@ -1,0 +1,193 @@
+// bf16 MFMA GEMM with fused epilogues for the ConceptHash encoder (gfx950 / CDNA4).
+//
+//   C[m][n] = sum_k X[m][k] * W[n][k]        X: activations [M,K] bf16 row-major, W: nn.Linear weight [N,K] bf16
+//
+// This is the arithmetic of every Linear on the reference's hot path (HF CLIPAttention q/k/v/out_proj, CLIPMLP fc1/fc2,
+// models/layers/adapter.py:46-60 down/up_proj, and the patch-embed Conv2d restated as im2col GEMM,
+// models/arch/coop.py:452-466).  The reference runs them as fp32 torch ops; here operands are bf16, accumulation fp32.
+//
+// Structure (v1): 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 v_mfma_f32_16x16x32_bf16
+// tiles.  Both operands are staged global->LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered,
+// one barrier per K-step.  LDS rows are 128 B (64 bf16); the 16-B chunk index is XOR-swizzled with (row & 7), applied
+// on the per-lane *source* address (the LDS-DMA destination is lane-linear) and again on the ds_read_b128 address,
+// which makes every fragment read conflict free.
+// The MFMA A operand is the WEIGHT tile and the B operand the ACTIVATION tile, so the accumulator holds D[n][m]:
+// a lane owns 4 consecutive n for one m, i.e. 4 contiguous output elements -> 8-B bf16 / 16-B fp32 stores.
+#include "ch_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+constexpr int NTHREADS = 256;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// XCD-aware, bijective block remap: blocks b and b+8 share an XCD (observed round-robin dispatch; speed only).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid & 1, wn = wid >> 1;
+
+    const int tiles_n = p.N / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging addresses: the stage image is [X rows 0..127 ; W rows 0..127] x 128 B, 8 rows per wave-instruction.
+    // wave w issues instructions i = 8w .. 8w+7; lane l -> row 8i + (l>>3), LDS chunk (l&7) holding source chunk
+    // (l&7) ^ (row&7).
+    const int lrow = lane >> 3;
+    const int src_chunk = (lane & 7) ^ lrow;  // (8i + lrow) & 7 == lrow
+    const char *gsrc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (wid * 8 + j) * 8 + lrow;  // 0..255
+        const bf16_t *base = row < BM ? p.X + (size_t)(m0 + row) * p.K : p.W + (size_t)(n0 + row - BM) * p.K;
+        gsrc[j] = (const char *)(base + src_chunk * 8);
+    }
+    auto stage = [&](int buf, int kt) {
+        char *dst = smem + buf * STAGE_BYTES + wid * 8 * 1024;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(gsrc[j] + (size_t)kt * BK * 2), (lds_void_t *)(dst + j * 1024),
+                                             16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes) inside a stage: row = sub*16 + (lane&15), chunk = (kk*4 + (lane>>4)) ^ (row&7)
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nk = p.K / BK;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char *xs = smem + cur * STAGE_BYTES;
+        const char *ws = xs + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int wr = wn * 64 + t * 16 + frow;
+                wf[t] = *(const bf16x8 *)(ws + wr * 128 + (((kk * 4 + fq) ^ (wr & 7)) << 4));
+                const int xr = wm * 64 + t * 16 + frow;
+                xf[t] = *(const bf16x8 *)(xs + xr * 128 + (((kk * 4 + fq) ^ (xr & 7)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane owns n = nb + 0..3 (contiguous) for row m
+    float scale = 1.0f;
+    if constexpr (EPI == EPI_SCALE_RESID) scale = *p.scale_ptr;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + frow;
+        if (m >= p.M) continue;
+        size_t orow = (size_t)m;
+        const float *posrow = nullptr;
+        if constexpr (EPI == EPI_PATCH) {
+            const int img = m / p.patches_per_img, pp = m - img * p.patches_per_img;
+            orow = (size_t)img * p.tokens_per_img + 1 + pp;
+            posrow = p.pos + (size_t)(1 + pp) * p.N;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+            f32x4 v = acc[nt][mt];
+            if constexpr (EPI != EPI_PATCH) v += *(const f32x4 *)(p.bias + n);
+            if constexpr (EPI == EPI_BIAS_QUICKGELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+            }
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+            }
+            if constexpr (EPI == EPI_PATCH) {
+                const f32x4 pe = *(const f32x4 *)(posrow + n);
+                *(f32x4 *)(p.resid + orow * p.ldr + n) = v + pe;
+            }
+            if constexpr (EPI == EPI_BIAS_RESID) {
+                f32x4 *hp = (f32x4 *)(p.resid + orow * p.ldr + n);
+                *hp = *hp + v;
+            }
+            if constexpr (EPI == EPI_SCALE_RESID) {
+                f32x4 *hp = (f32x4 *)(p.resid + orow * p.ldr + n);
+                *hp = *hp + v * scale;
+            }
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QUICKGELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(uint2 *)(p.out_bf16 + orow * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch(const GemmParams &p, hipStream_t s) {
+    const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         2 * STAGE_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(NTHREADS), 2 * STAGE_BYTES, s, p);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
+    CH_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem");
+    CH_REQUIRE(epi == EPI_PATCH || p.bias != nullptr, "gemm: bias is required");
+    CH_REQUIRE(p.N % BN == 0, "gemm: N must be a multiple of 128");
+    CH_REQUIRE(p.K % BK == 0, "gemm: K must be a multiple of 64");
+    CH_REQUIRE(p.X_rows_alloc >= round_up64(p.M, BM), "gemm: X must be allocated for M rounded up to 128 rows");
+    switch (epi) {
+        case EPI_BIAS: return launch<EPI_BIAS>(p, s);
+        case EPI_BIAS_QUICKGELU: return launch<EPI_BIAS_QUICKGELU>(p, s);
+        case EPI_BIAS_GELU: return launch<EPI_BIAS_GELU>(p, s);
+        case EPI_BIAS_RESID: return launch<EPI_BIAS_RESID>(p, s);
+        case EPI_SCALE_RESID: return launch<EPI_SCALE_RESID>(p, s);
+        case EPI_PATCH: return launch<EPI_PATCH>(p, s);
+    }
+    ch_set_error("gemm: unknown epilogue");
+    return 2;
+}

@@ -1,0 +1,462 @@
+// Packed Hamming retrieval kernels (gfx950): XOR + popcount distance, exact top-k, and the two passes of mAP.
+//
+// Replaces the un-vendored utils.hashing.{calculate_mAP, calculate_pr_curve, get_hamm_dist} (call sites
+// experiments/test_hashing.py:106-119,153-162; trainers/orthohash.py:362; in-repo twin get_hd trainers/orthohash.py:263-264,
+// which builds a float (Qn,G) matrix with a matmul and argsorts it).  Definition: SURVEY.md section 8c / oracle/hamming_oracle.c.
+//
+// Work layout for all three scan kernels: one LANE per QUERY (its code words and its selection state live in that
+// lane's registers / LDS column), the GALLERY segment is walked sequentially and is wave-uniform, so gallery words and
+// labels arrive through the scalar data path (s_load_dwordx{4,8,16}) and every XOR uses an SGPR operand.  Nothing of
+// size Qn x G is ever written.  grid = (query tiles, gallery segments) so small galleries still fill the chip.
+//
+//  * top-k:   per-lane sorted list of the KREG smallest keys, key = dist << 23 | row-in-segment (unique, so "k smallest
+//             keys" == ascending (distance, gallery index)).  A wave-uniform branch skips the insertion network unless
+//             some lane beats its current threshold; the network itself is branch free (min/max chain).
+//  * hist:    per-lane per-distance counters in LDS, column = lane -> conflict-free ds_add; count and relevant count
+//             share one 32-bit word (16 + 16 bits, segments <= 65535 rows).
+//  * AP:      the same LDS counters, read-modify-write with return: the returned value is the row's position inside its
+//             (query, distance) bucket in gallery order, which with the prefix "base" gives its exact global rank and
+//             relevant-rank; AP numerators are accumulated in 2^-32 fixed point (integer, order independent).
+#include "../../include/concepthash_hip.h"
+#include "ch_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int KEY_SHIFT = 23;
+constexpr uint32_t KEY_MASK = (1u << KEY_SHIFT) - 1;
+
+template <int W>
+__device__ __forceinline__ int hamming(const uint32_t (&q)[2 * W], const uint64_t *__restrict__ g) {
+    int d = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint64_t gw = g[w];
+        d += __builtin_popcount(q[2 * w] ^ (uint32_t)gw);
+        d += __builtin_popcount(q[2 * w + 1] ^ (uint32_t)(gw >> 32));
+    }
+    return d;
+}
+
+template <int W>
+__device__ __forceinline__ void load_query(uint32_t (&q)[2 * W], const uint64_t *qp, int64_t qi, int64_t Qn) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const uint64_t v = qi < Qn ? qp[qi * W + w] : 0ull;
+        q[2 * w] = (uint32_t)v;
+        q[2 * w + 1] = (uint32_t)(v >> 32);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// full distance matrix (small problems)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void dist_kernel(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int W, int32_t *out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= Qn * G) return;
+    const int64_t i = gid / G, j = gid - i * G;
+    int d = 0;
+    for (int w = 0; w < W; ++w) d += __builtin_popcountll(q[i * W + w] ^ g[j * W + w]);
+    out[gid] = d;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// top-k, per (query tile, gallery segment) partial lists
+// ---------------------------------------------------------------------------------------------------------------
+template <int W, int KREG>
+__global__ __launch_bounds__(256) void topk_partial_kernel(const uint64_t *__restrict__ q, int64_t Qn,
+                                                           const uint64_t *__restrict__ g, int64_t G, int seg_rows, int k,
+                                                           uint32_t *__restrict__ part) {
+    const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int seg = blockIdx.y;
+    const int64_t g0 = (int64_t)seg * seg_rows;
+    const int n = (int)min((int64_t)seg_rows, G - g0);
+    uint32_t qw[2 * W];
+    load_query<W>(qw, q, qi, Qn);
+    uint32_t list[KREG];
+#pragma unroll
+    for (int i = 0; i < KREG; ++i) list[i] = 0xFFFFFFFFu;
+    const uint64_t *gp = g + g0 * W;
+    for (int j = 0; j < n; ++j) {
+        const int d = hamming<W>(qw, gp + (size_t)j * W);
+        uint32_t key = ((uint32_t)d << KEY_SHIFT) | (uint32_t)j;
+        if (__builtin_amdgcn_ballot_w64(key < list[KREG - 1]) != 0ull) {
+#pragma unroll
+            for (int i = 0; i < KREG; ++i) {
+                const uint32_t lo = min(list[i], key);
+                key = max(list[i], key);
+                list[i] = lo;
+            }
+        }
+    }
+    if (qi < Qn) {
+        uint32_t *o = part + ((size_t)seg * Qn + qi) * k;
+#pragma unroll
+        for (int i = 0; i < KREG; ++i)
+            if (i < k) o[i] = list[i];
+    }
+}
+
+// one wave per query: repeatedly extract the smallest composite (dist, global row) above the previous one
+__global__ __launch_bounds__(256) void topk_merge_keys_kernel(const uint32_t *__restrict__ part, int nseg, int64_t Qn, int k,
+                                                              int seg_rows, int64_t g_index_base, int64_t *out_idx,
+                                                              int32_t *out_dist) {
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (qi >= Qn) return;
+    const int ncand = nseg * k;
+    unsigned long long prev = 0ull;  // composite + 1 of the last output (0 = none yet)
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = ~0ull;
+        for (int c = lane; c < ncand; c += 64) {
+            const int s = c / k, i = c - s * k;
+            const uint32_t key = part[((size_t)s * Qn + qi) * k + i];
+            if (key == 0xFFFFFFFFu) continue;
+            const unsigned long long comp =
+                ((unsigned long long)(key >> KEY_SHIFT) << 40) | ((unsigned long long)s * seg_rows + (key & KEY_MASK));
+            if (comp + 1 > prev && comp < best) best = comp;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other < best ? other : best;
+        }
+        if (lane == 0) {
+            if (best == ~0ull) {
+                out_idx[qi * k + r] = -1;
+                out_dist[qi * k + r] = -1;
+            } else {
+                out_idx[qi * k + r] = g_index_base + (int64_t)(best & ((1ull << 40) - 1));
+                out_dist[qi * k + r] = (int32_t)(best >> 40);
+            }
+        }
+        if (best == ~0ull) {
+            // nothing left: fill the rest
+            for (int rr = r + 1; rr < k; ++rr)
+                if (lane == 0) {
+                    out_idx[qi * k + rr] = -1;
+                    out_dist[qi * k + rr] = -1;
+                }
+            return;
+        }
+        prev = best + 1;
+    }
+}
+
+// merge already-final lists (idx,dist) from several shards: same extraction on composite (dist, idx)
+__global__ __launch_bounds__(256) void topk_merge_lists_kernel(const int64_t *__restrict__ idx_lists,
+                                                               const int32_t *__restrict__ dist_lists, int nlists, int64_t Qn,
+                                                               int k, int64_t *out_idx, int32_t *out_dist) {
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (qi >= Qn) return;
+    const int ncand = nlists * k;
+    unsigned long long prev = 0ull;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = ~0ull;
+        for (int c = lane; c < ncand; c += 64) {
+            const int s = c / k, i = c - s * k;
+            const int32_t d = dist_lists[((size_t)s * Qn + qi) * k + i];
+            if (d < 0) continue;
+            const unsigned long long comp =
+                ((unsigned long long)d << 48) | (unsigned long long)idx_lists[((size_t)s * Qn + qi) * k + i];
+            if (comp + 1 > prev && comp < best) best = comp;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other < best ? other : best;
+        }
+        if (lane == 0) {
+            out_idx[qi * k + r] = best == ~0ull ? -1 : (int64_t)(best & ((1ull << 48) - 1));
+            out_dist[qi * k + r] = best == ~0ull ? -1 : (int32_t)(best >> 48);
+        }
+        if (best != ~0ull) prev = best + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mAP passes.  MODE 0 = histogram, MODE 1 = AP accumulation
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool relevant_multi(const uint64_t *qm, const uint64_t *gm, int LW) {
+    bool r = false;
+    for (int w = 0; w < LW; ++w) r |= (qm[w] & gm[w]) != 0ull;
+    return r;
+}
+
+// floor(a * 2^32 / b) for 1 <= a <= b < 2^32, exact: double estimate + integer correction
+__device__ __forceinline__ unsigned long long fixdiv32(uint32_t a, uint32_t b) {
+    const unsigned long long num = (unsigned long long)a << 32;
+    unsigned long long qq = (unsigned long long)((double)a * 4294967296.0 / (double)b);
+    long long rem = (long long)(num - qq * (unsigned long long)b);
+    if (rem < 0) {
+        qq -= 1;
+        rem += b;
+    }
+    if (rem >= (long long)b) qq += 1;
+    return qq;
+}
+
+template <int W, int BLK, int MODE>
+__global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restrict__ q, int64_t Qn,
+                                                       const uint64_t *__restrict__ g, int64_t G, const void *q_labels,
+                                                       const void *g_labels, int LW, int seg_rows,
+                                                       uint32_t *__restrict__ out_hist, const uint32_t *__restrict__ base,
+                                                       int64_t rank_limit, const int32_t *__restrict__ first_rel,
+                                                       unsigned long long *out_S, uint32_t *out_nrel) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // [nb][BLK]
+    constexpr int NB = 64 * W + 1;
+    const int tid = threadIdx.x;
+    const int64_t qi = (int64_t)blockIdx.x * BLK + tid;
+    const int seg = blockIdx.y;
+    const int64_t g0 = (int64_t)seg * seg_rows;
+    const int n = (int)min((int64_t)seg_rows, G - g0);
+    for (int i = tid; i < NB * BLK; i += BLK) cnt[i] = 0;
+    uint32_t qw[2 * W];
+    load_query<W>(qw, q, qi, Qn);
+    const bool valid = qi < Qn;
+    const int32_t qlab = (LW == 0 && valid) ? ((const int32_t *)q_labels)[qi] : -1;
+    const uint64_t *qm = (LW > 0 && valid) ? (const uint64_t *)q_labels + qi * LW : nullptr;
+    const int32_t *gl32 = (const int32_t *)g_labels + g0;
+    const uint64_t *glm = (const uint64_t *)g_labels + g0 * (LW > 0 ? LW : 0);
+    __syncthreads();  // counters zeroed (each lane only touches its own column afterwards)
+
+    unsigned long long S = 0ull;
+    uint32_t nrel = 0;
+    int skip = 0, frel = 0;
+    if (MODE == 1 && first_rel != nullptr) {
+        skip = 1;
+        frel = valid ? first_rel[qi] : 0;
+    }
+    const uint64_t *gp = g + g0 * W;
+    const size_t brow = ((size_t)seg * Qn + (valid ? qi : 0)) * NB * 2;
+    for (int j = 0; j < n; ++j) {
+        const int d = hamming<W>(qw, gp + (size_t)j * W);
+        bool rel;
+        if (LW == 0)
+            rel = valid && (gl32[j] == qlab);
+        else
+            rel = valid && relevant_multi(qm, glm + (size_t)j * LW, LW);
+        const uint32_t inc = 1u | ((uint32_t)rel << 16);
+        if (MODE == 0) {
+            atomicAdd(&cnt[d * BLK + tid], inc);
+        } else {
+            const uint32_t old = atomicAdd(&cnt[d * BLK + tid], inc);
+            if (rel) {
+                uint32_t rank = base[brow + 2 * d] + (old & 0xFFFFu) + 1u;      // 1-based global rank
+                uint32_t relrank = base[brow + 2 * d + 1] + (old >> 16) + 1u;  // 1-based rank among relevant rows
+                bool counts = true;
+                if (skip) {
+                    if (rank == 1u) counts = false;
+                    rank -= 1u;
+                    relrank -= (uint32_t)frel;
+                }
+                if (rank_limit > 0 && (int64_t)rank > rank_limit) counts = false;
+                if (counts) {
+                    S += fixdiv32(relrank, rank);
+                    nrel += 1;
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        if (valid) {
+            uint32_t *o = out_hist + brow;
+            for (int d = 0; d < NB; ++d) {
+                const uint32_t v = cnt[d * BLK + tid];
+                *(uint2 *)(o + 2 * d) = make_uint2(v & 0xFFFFu, v >> 16);
+            }
+        }
+    } else {
+        if (valid && nrel) {
+            atomicAdd(out_S + qi, S);
+            atomicAdd(out_nrel + qi, nrel);
+        }
+    }
+}
+
+// hist [nseg,Qn,nb,2] -> base: exclusive prefix in ranking order (bucket ascending, then segment ascending)
+__global__ void hist_prefix_kernel(const uint32_t *__restrict__ hist, int nseg, int64_t Qn, int nb, uint32_t *__restrict__ base,
+                                   uint32_t *__restrict__ totals) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= Qn * 2) return;
+    const int64_t qi = gid >> 1;
+    const int comp = (int)(gid & 1);
+    uint32_t run = 0;
+    for (int d = 0; d < nb; ++d)
+        for (int s = 0; s < nseg; ++s) {
+            const size_t off = (((size_t)s * Qn + qi) * nb + d) * 2 + comp;
+            base[off] = run;
+            run += hist[off];
+        }
+    if (totals) totals[qi * 2 + comp] = run;
+}
+
+template <int W, int BLK>
+int launch_scan(int mode, const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql, const void *gl,
+                int LW, int seg_rows, uint32_t *out_hist, const uint32_t *base, int64_t rank_limit, const int32_t *first_rel,
+                unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
+    const int nseg = (int)ceil_div64(G, seg_rows);
+    const size_t lds = sizeof(uint32_t) * (64 * W + 1) * BLK;
+    dim3 grid((unsigned)ceil_div64(Qn, BLK), (unsigned)nseg);
+    if (mode == 0) {
+        static bool set0 = false;
+        if (!set0) {
+            CH_CHECK_HIP(hipFuncSetAttribute((const void *)map_scan_kernel<W, BLK, 0>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set0 = true;
+        }
+        hipLaunchKernelGGL((map_scan_kernel<W, BLK, 0>), grid, dim3(BLK), lds, s, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist,
+                           base, rank_limit, first_rel, out_S, out_nrel);
+    } else {
+        static bool set1 = false;
+        if (!set1) {
+            CH_CHECK_HIP(hipFuncSetAttribute((const void *)map_scan_kernel<W, BLK, 1>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            set1 = true;
+        }
+        hipLaunchKernelGGL((map_scan_kernel<W, BLK, 1>), grid, dim3(BLK), lds, s, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist,
+                           base, rank_limit, first_rel, out_S, out_nrel);
+    }
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+
+int scan_dispatch(int mode, const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int W, const void *ql,
+                  const void *gl, int LW, int seg_rows, uint32_t *out_hist, const uint32_t *base, int64_t rank_limit,
+                  const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
+    CH_REQUIRE(W >= 1 && W <= 4, "hamming: 1 <= W <= 4 (nbit <= 256)");
+    CH_REQUIRE(seg_rows >= 1 && seg_rows <= 65535, "hamming: seg_rows must be in [1, 65535]");
+    CH_REQUIRE(LW >= 0, "hamming: LW must be >= 0");
+    CH_REQUIRE(Qn >= 0 && G >= 0, "hamming: negative sizes");
+    if (Qn == 0 || G == 0) return 0;
+    CH_REQUIRE(q && g && ql && gl, "hamming: null pointer");
+    CH_REQUIRE(ceil_div64(G, seg_rows) <= 65535, "hamming: too many gallery segments (raise seg_rows)");
+    switch (W) {
+        case 1: return launch_scan<1, 256>(mode, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, rank_limit, first_rel, out_S, out_nrel, s);
+        case 2: return launch_scan<2, 256>(mode, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, rank_limit, first_rel, out_S, out_nrel, s);
+        case 3: return launch_scan<3, 128>(mode, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, rank_limit, first_rel, out_S, out_nrel, s);
+        default: return launch_scan<4, 128>(mode, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, rank_limit, first_rel, out_S, out_nrel, s);
+    }
+}
+
+int topk_seg_rows(int64_t Qn, int64_t G) {
+    // enough (tile, segment) workgroups to fill 256 CUs a few times over, segments not shorter than 256 rows
+    const int64_t tiles = ceil_div64(Qn, 256);
+    int64_t nseg = ceil_div64(2048, tiles);
+    int64_t rows = ceil_div64(G, nseg);
+    if (rows < 256) rows = 256;
+    if (rows > (int64_t)KEY_MASK) rows = KEY_MASK;
+    return (int)rows;
+}
+
+template <int W, int KREG>
+int launch_topk_partial(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int seg_rows, int k, uint32_t *part,
+                        hipStream_t s) {
+    const int nseg = (int)ceil_div64(G, seg_rows);
+    dim3 grid((unsigned)ceil_div64(Qn, 256), (unsigned)nseg);
+    hipLaunchKernelGGL((topk_partial_kernel<W, KREG>), grid, dim3(256), 0, s, q, Qn, g, G, seg_rows, k, part);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int W>
+int topk_dispatch_k(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int seg_rows, int k, uint32_t *part,
+                    hipStream_t s) {
+    if (k <= 16) return launch_topk_partial<W, 16>(q, Qn, g, G, seg_rows, k, part, s);
+    if (k <= 32) return launch_topk_partial<W, 32>(q, Qn, g, G, seg_rows, k, part, s);
+    if (k <= 64) return launch_topk_partial<W, 64>(q, Qn, g, G, seg_rows, k, part, s);
+    return launch_topk_partial<W, 128>(q, Qn, g, G, seg_rows, k, part, s);
+}
+
+}  // namespace
+
+extern "C" int ch_hamming_dist(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, int32_t *out,
+                               void *stream) {
+    CH_REQUIRE(W >= 1 && Qn >= 0 && G >= 0, "hamming_dist: bad sizes");
+    if (Qn == 0 || G == 0) return 0;
+    CH_REQUIRE(q && g && out, "hamming_dist: null pointer");
+    hipLaunchKernelGGL(dist_kernel, dim3((unsigned)ceil_div64(Qn * G, 256)), dim3(256), 0, (hipStream_t)stream, q, Qn, g, G, W,
+                       out);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t ch_hamming_topk_workspace(int64_t Qn, int64_t G, int32_t W, int32_t k) {
+    (void)W;
+    if (Qn <= 0 || G <= 0 || k <= 0) return 16;
+    const int seg_rows = topk_seg_rows(Qn, G);
+    const int64_t nseg = ceil_div64(G, seg_rows);
+    return (size_t)(nseg * Qn * k) * sizeof(uint32_t) + 16;
+}
+
+extern "C" int ch_hamming_topk(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, int32_t k,
+                               int64_t g_index_base, int64_t *out_idx, int32_t *out_dist, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    CH_REQUIRE(W >= 1 && W <= 4, "hamming_topk: 1 <= W <= 4 (nbit <= 256)");
+    CH_REQUIRE(k >= 1 && k <= 128, "hamming_topk: 1 <= k <= 128");
+    CH_REQUIRE(Qn >= 0 && G >= 0, "hamming_topk: negative sizes");
+    if (Qn == 0) return 0;
+    CH_REQUIRE(q && out_idx && out_dist, "hamming_topk: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (G == 0) {
+        CH_CHECK_HIP(hipMemsetAsync(out_idx, 0xFF, sizeof(int64_t) * Qn * k, s));
+        CH_CHECK_HIP(hipMemsetAsync(out_dist, 0xFF, sizeof(int32_t) * Qn * k, s));
+        return 0;
+    }
+    CH_REQUIRE(g != nullptr, "hamming_topk: null gallery");
+    CH_REQUIRE(workspace && workspace_bytes >= ch_hamming_topk_workspace(Qn, G, W, k), "hamming_topk: workspace too small");
+    const int seg_rows = topk_seg_rows(Qn, G);
+    const int nseg = (int)ceil_div64(G, seg_rows);
+    CH_REQUIRE(nseg <= 65535, "hamming_topk: gallery too large for one call (shard it)");
+    uint32_t *part = (uint32_t *)workspace;
+    int e;
+    switch (W) {
+        case 1: e = topk_dispatch_k<1>(q, Qn, g, G, seg_rows, k, part, s); break;
+        case 2: e = topk_dispatch_k<2>(q, Qn, g, G, seg_rows, k, part, s); break;
+        case 3: e = topk_dispatch_k<3>(q, Qn, g, G, seg_rows, k, part, s); break;
+        default: e = topk_dispatch_k<4>(q, Qn, g, G, seg_rows, k, part, s); break;
+    }
+    if (e) return e;
+    hipLaunchKernelGGL(topk_merge_keys_kernel, dim3((unsigned)ceil_div64(Qn, 4)), dim3(256), 0, s, part, nseg, Qn, k, seg_rows,
+                       g_index_base, out_idx, out_dist);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ch_topk_merge(const int64_t *idx_lists, const int32_t *dist_lists, int32_t nlists, int64_t Qn, int32_t k,
+                             int64_t *out_idx, int32_t *out_dist, void *stream) {
+    CH_REQUIRE(nlists >= 1 && k >= 1 && Qn >= 0, "topk_merge: bad sizes");
+    if (Qn == 0) return 0;
+    CH_REQUIRE(idx_lists && dist_lists && out_idx && out_dist, "topk_merge: null pointer");
+    hipLaunchKernelGGL(topk_merge_lists_kernel, dim3((unsigned)ceil_div64(Qn, 4)), dim3(256), 0, (hipStream_t)stream, idx_lists,
+                       dist_lists, nlists, Qn, k, out_idx, out_dist);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ch_hamming_hist(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                               const void *g_labels, int32_t LW, int32_t seg_rows, uint32_t *out_hist, void *stream) {
+    CH_REQUIRE(Qn == 0 || G == 0 || out_hist != nullptr, "hamming_hist: null output");
+    return scan_dispatch(0, q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, out_hist, nullptr, 0, nullptr, nullptr, nullptr,
+                         (hipStream_t)stream);
+}
+
+extern "C" int ch_hamming_ap(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                             const void *g_labels, int32_t LW, int32_t seg_rows, const uint32_t *base, int64_t rank_limit,
+                             const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, void *stream) {
+    CH_REQUIRE(Qn == 0 || G == 0 || (base && out_S && out_nrel), "hamming_ap: null pointer");
+    return scan_dispatch(1, q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, nullptr, base, rank_limit, first_rel, out_S,
+                         out_nrel, (hipStream_t)stream);
+}
+
+extern "C" int ch_hamming_hist_prefix(const uint32_t *hist, int32_t nseg, int64_t Qn, int32_t nb, uint32_t *out_base,
+                                      uint32_t *out_totals, void *stream) {
+    CH_REQUIRE(nseg >= 1 && nb >= 1 && Qn >= 0, "hist_prefix: bad sizes");
+    if (Qn == 0) return 0;
+    CH_REQUIRE(hist && out_base, "hist_prefix: null pointer");
+    hipLaunchKernelGGL(hist_prefix_kernel, dim3((unsigned)ceil_div64(Qn * 2, 256)), dim3(256), 0, (hipStream_t)stream, hist, nseg,
+                       Qn, nb, out_base, out_totals);
+    CH_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,93 @@
+// Internal launcher declarations shared by the .hip translation units of libconcepthash_hip.
+#pragma once
+#include "ch_common.h"
+
+// ---- gemm_bf16.hip -------------------------------------------------------------------------------------------
+enum GemmEpilogue {
+    EPI_BIAS = 0,           // out_bf16 = acc + bias
+    EPI_BIAS_QUICKGELU = 1, // out_bf16 = quick_gelu(acc + bias)
+    EPI_BIAS_GELU = 2,      // out_bf16 = gelu_erf(acc + bias)
+    EPI_BIAS_RESID = 3,     // v = acc + bias; resid += v; out_bf16 = v
+    EPI_SCALE_RESID = 4,    // resid += *scale_ptr * (acc + bias)
+    EPI_PATCH = 5,          // resid[token row of patch m] = acc + pos[1 + patch]
+};
+
+struct GemmParams {
+    const bf16_t *X;       // [X_rows_alloc, K]
+    const bf16_t *W;       // [N, K]
+    int M, N, K;
+    int64_t X_rows_alloc;  // rows actually allocated behind X (>= M rounded up to the block tile)
+    const float *bias;     // [N] or nullptr
+    bf16_t *out_bf16;      // [M, ldo]
+    int ldo;
+    float *resid;          // fp32 residual stream [rows, ldr]
+    int ldr;
+    const float *scale_ptr;  // device scalar (adapter scale)
+    const float *pos;        // EPI_PATCH: position embedding [1 + Np, N]
+    int tokens_per_img;      // EPI_PATCH: N tokens per image in the residual stream
+    int patches_per_img;     // EPI_PATCH: Np
+};
+int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);
+
+// ---- rowops.hip ----------------------------------------------------------------------------------------------
+// im2col for the patch-embed conv (k = s = patch, no bias): out[b*Np + p][c*pp + ky*patch + kx], zero padded to Kp.
+int ch_im2col(const void *images, int image_dtype, int B, int image, int patch, int Kp, bf16_t *out, hipStream_t s);
+// rows of H: token 0 <- cls + pos[0]; tokens > Np <- ctx[token - Np - 1]; then pre-LN (in place, fp32) and, fused,
+// the first encoder layer's LN1 -> xn (bf16).
+int ch_assemble_preln(float *H, int B, int ntok, int np, int D, const float *cls_pos0, const float *ctx,
+                      const float *pre_w, const float *pre_b, const float *ln_w, const float *ln_b, float eps,
+                      bf16_t *xn, hipStream_t s);
+// LayerNorm over D of fp32 rows -> bf16
+int ch_layernorm_f32(const float *x, int64_t rows, int D, const float *w, const float *b, float eps, bf16_t *out,
+                     hipStream_t s);
+// LayerNorm over D of bf16 rows -> bf16
+int ch_layernorm_bf16(const bf16_t *x, int64_t rows, int D, const float *w, const float *b, float eps, bf16_t *out,
+                      hipStream_t s);
+
+// ---- attention.hip -------------------------------------------------------------------------------------------
+// qkv [B*ntok, 3D] bf16 (q | k | v, head h at columns h*64), out [B*ntok, D] bf16.  head_dim == 64.
+int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s);
+
+// ---- head.hip ------------------------------------------------------------------------------------------------
+struct HeadParams {
+    const float *H;  // residual stream [B*ntok, D]
+    int B, ntok, D, Q, nbit, C, P;
+    const float *hash_pe;     // [Q, D]
+    const float *hash_fc;     // [nbit/Q, D]
+    const float *bn_scale;    // [nbit]  gamma / sqrt(var + eps)
+    const float *bn_shift;    // [nbit]  beta - mean * scale
+    const float *center_l2;   // [C, nbit] l2-normalised projected centres
+    const float *center_bin;  // [C, nbit] sign(center_l2) / sqrt(nbit)
+    const float *concept_pe;  // [Q, D] or nullptr
+    const float *concept_cent_l2;  // [C, D] l2-normalised centroids or nullptr
+    const float *post_w, *post_b;  // post_layernorm
+    const float *vis_proj;         // [P, D]
+    float ln_eps;
+    float *out_codes;          // [B, nbit]
+    uint64_t *out_packed;      // [B, W] or nullptr
+    float *out_logits_cont;    // [B, C] or nullptr
+    float *out_logits_bin;     // [B, C] or nullptr
+    float *out_logits_concept; // [Q, B, C] or nullptr
+    float *out_hash_features;  // [B, Q, D] or nullptr
+    float *out_image_features; // [B, P] or nullptr
+};
+int ch_head(const HeadParams &p, hipStream_t s);
+int ch_pack_sign_launch(const float *codes, int64_t rows, int nbit, float thr, uint64_t *out, hipStream_t s);
+
+// ---- small_f32.hip (model-load-time constant folding, fp32) -------------------------------------------------------
+// y[r][o] = act(sum_i x[r][i] * W[o][i] + b[o]);  act: 0 none, 1 relu
+int ch_small_linear(const float *x, int rows, int in_f, const float *W, const float *b, int out_f, int act, float *y,
+                    hipStream_t s);
+int ch_small_layernorm(const float *x, int rows, int D, const float *w, const float *b, float eps, float *y,
+                       hipStream_t s);
+// y = a + b (elementwise)
+int ch_small_add(const float *a, const float *b, int64_t n, float *y, hipStream_t s);
+// single-sequence multi-head attention core on packed qkv [T, 3P] -> out [T, P]
+int ch_small_mha(const float *qkv, int T, int P, int heads, float *out, hipStream_t s);
+// rows l2-normalise; optionally also sign(x_l2)/sqrt(cols) into out_bin
+int ch_small_l2norm(const float *x, int rows, int cols, float *out_l2, float *out_bin, hipStream_t s);
+// fp32 -> bf16 with optional zero padding of the inner dimension: in [rows, cols] -> out [rows, cols_pad]
+int ch_convert_bf16(const float *x, int64_t rows, int cols, int cols_pad, bf16_t *out, hipStream_t s);
+// bn fold: scale = w / sqrt(var + eps), shift = b - mean * scale
+int ch_bn_fold(const float *w, const float *b, const float *mean, const float *var, int n, float eps, float *scale,
+               float *shift, hipStream_t s);

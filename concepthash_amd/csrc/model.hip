@@ -1,0 +1,476 @@
+// ch_model: weights + workspace + the per-batch launch sequence of the ConceptHash encoder (C-ABI in
+// include/concepthash_hip.h).  Restates LGHWithFixedPrompt.forward (models/arch/coop.py:524-598) as a fixed chain of
+// HIP launches on one stream; see DESIGN.md for the kernel list and data layout.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/concepthash_hip.h"
+#include "ch_common.h"
+#include "kernels.h"
+
+static thread_local std::string g_last_error;
+void ch_set_error(const std::string &msg) { g_last_error = msg; }
+extern "C" const char *ch_last_error(void) { return g_last_error.c_str(); }
+extern "C" int ch_abi_version(void) { return CH_ABI_VERSION; }
+
+namespace {
+struct AdapterW {
+    const float *ln_w = nullptr, *ln_b = nullptr, *down_b = nullptr, *up_b = nullptr, *scale = nullptr;
+    const bf16_t *down_w = nullptr, *up_w = nullptr;
+};
+struct LayerW {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *out_b, *fc1_b, *fc2_b;
+    const bf16_t *qkv_w, *out_w, *fc1_w, *fc2_w;
+    AdapterW ad[2];
+};
+}  // namespace
+
+struct ch_model {
+    ch_model_config cfg;
+    int np = 0, ntok = 0, Kp = 0, bpad = 0;
+    std::vector<void *> allocs;
+    size_t bytes = 0;
+    // weights
+    const bf16_t *patch_w = nullptr;
+    const float *pos = nullptr, *cls_pos0 = nullptr, *ctx = nullptr, *pre_w = nullptr, *pre_b = nullptr;
+    const float *zero_bias = nullptr;
+    std::vector<LayerW> layers;
+    const float *hash_pe = nullptr, *hash_fc = nullptr, *bn_scale = nullptr, *bn_shift = nullptr;
+    const float *center_l2 = nullptr, *center_bin = nullptr, *concept_pe = nullptr, *concept_cent_l2 = nullptr;
+    const float *post_w = nullptr, *post_b = nullptr, *vis_proj = nullptr;
+    // workspace
+    int64_t rows_alloc = 0, prow_alloc = 0;
+    float *H = nullptr;
+    bf16_t *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *A = nullptr, *AD = nullptr, *F1 = nullptr, *PATCH = nullptr;
+};
+
+namespace {
+
+struct Builder {
+    ch_model *m;
+    std::map<std::string, const ch_tensor *> tab;
+    hipStream_t s = nullptr;
+    bool ok = true;
+
+    void *alloc(size_t bytes) {
+        void *p = nullptr;
+        if (bytes == 0) bytes = 16;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            ch_set_error("hipMalloc failed for " + std::to_string(bytes) + " bytes");
+            ok = false;
+            return nullptr;
+        }
+        m->allocs.push_back(p);
+        m->bytes += bytes;
+        return p;
+    }
+    const ch_tensor *find(const std::string &name, int64_t numel) {
+        auto it = tab.find(name);
+        if (it == tab.end()) {
+            ch_set_error("missing tensor '" + name + "'");
+            ok = false;
+            return nullptr;
+        }
+        if (it->second->numel != numel) {
+            ch_set_error("tensor '" + name + "' has " + std::to_string(it->second->numel) + " elements, expected " +
+                         std::to_string(numel));
+            ok = false;
+            return nullptr;
+        }
+        return it->second;
+    }
+    bool has(const std::string &name) { return tab.count(name) != 0; }
+    // fp32 host -> fp32 device
+    float *f32(const std::string &name, int64_t numel) {
+        const ch_tensor *t = find(name, numel);
+        if (!t) return nullptr;
+        float *d = (float *)alloc(sizeof(float) * numel);
+        if (!d) return nullptr;
+        if (hipMemcpy(d, t->data, sizeof(float) * numel, hipMemcpyHostToDevice) != hipSuccess) {
+            ch_set_error("hipMemcpy failed for '" + name + "'");
+            ok = false;
+        }
+        return d;
+    }
+    float *f32_zeros(int64_t numel) {
+        float *d = (float *)alloc(sizeof(float) * numel);
+        if (d && hipMemset(d, 0, sizeof(float) * numel) != hipSuccess) ok = false;
+        return d;
+    }
+    // fp32 host [rows, cols] -> bf16 device [rows, cols_pad] written at row offset into dst (or fresh alloc)
+    bf16_t *bf16(const std::string &name, int64_t rows, int cols, int cols_pad, bf16_t *dst = nullptr) {
+        const ch_tensor *t = find(name, rows * cols);
+        if (!t) return nullptr;
+        float *tmp = nullptr;
+        if (hipMalloc((void **)&tmp, sizeof(float) * rows * cols) != hipSuccess) {
+            ch_set_error("hipMalloc failed (staging)");
+            ok = false;
+            return nullptr;
+        }
+        if (!dst) dst = (bf16_t *)alloc(sizeof(bf16_t) * rows * cols_pad);
+        if (dst) {
+            if (hipMemcpy(tmp, t->data, sizeof(float) * rows * cols, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+            if (ch_convert_bf16(tmp, rows, cols, cols_pad, dst, s) != 0) ok = false;
+            if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+        }
+        (void)hipFree(tmp);
+        return dst;
+    }
+};
+
+int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
+    const ch_model_config &c = m->cfg;
+    Builder B;
+    B.m = m;
+    for (int i = 0; i < ntensors; ++i) {
+        CH_REQUIRE(tensors[i].name && tensors[i].data, "tensor entry with null name/data");
+        B.tab[tensors[i].name] = &tensors[i];
+    }
+    const int D = c.dim, L = c.layers, M = c.ffn, b = c.adapter_dim, Q = c.ncontext, P = c.proj_dim, C = c.nclass;
+    const int np = m->np, K = 3 * c.patch * c.patch, Kp = m->Kp;
+    const std::string VM = "backbone.vision_model.";
+    hipStream_t s = nullptr;
+
+    // ---- embeddings
+    m->patch_w = B.bf16(VM + "embeddings.patch_embedding.weight", D, K, Kp);
+    m->pos = B.f32(VM + "embeddings.position_embedding.weight", (int64_t)(np + 1) * D);
+    const float *cls = B.f32(VM + "embeddings.class_embedding", D);
+    m->pre_w = B.f32(VM + "pre_layrnorm.weight", D);
+    m->pre_b = B.f32(VM + "pre_layrnorm.bias", D);
+    m->zero_bias = B.f32_zeros(std::max(std::max(3 * D, M), 1024));
+    float *cls_pos0 = (float *)B.alloc(sizeof(float) * D);
+    if (!B.ok) return 4;
+    if (ch_small_add(cls, m->pos, D, cls_pos0, s)) return 4;
+    m->cls_pos0 = cls_pos0;
+
+    // ---- encoder layers
+    m->layers.resize(L);
+    for (int i = 0; i < L && B.ok; ++i) {
+        const std::string pre = VM + "encoder.layers." + std::to_string(i) + ".";
+        LayerW &w = m->layers[i];
+        w.ln1_w = B.f32(pre + "layer_norm1.weight", D);
+        w.ln1_b = B.f32(pre + "layer_norm1.bias", D);
+        w.ln2_w = B.f32(pre + "layer_norm2.weight", D);
+        w.ln2_b = B.f32(pre + "layer_norm2.bias", D);
+        bf16_t *qkvw = (bf16_t *)B.alloc(sizeof(bf16_t) * 3 * D * D);
+        float *qkvb = (float *)B.alloc(sizeof(float) * 3 * D);
+        if (!B.ok) break;
+        const char *names[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3 && B.ok; ++j) {
+            B.bf16(pre + "self_attn." + names[j] + ".weight", D, D, D, qkvw + (size_t)j * D * D);
+            const ch_tensor *bt = B.find(pre + "self_attn." + names[j] + ".bias", D);
+            if (bt && hipMemcpy(qkvb + (size_t)j * D, bt->data, sizeof(float) * D, hipMemcpyHostToDevice) != hipSuccess)
+                B.ok = false;
+        }
+        w.qkv_w = qkvw;
+        w.qkv_b = qkvb;
+        w.out_w = B.bf16(pre + "self_attn.out_proj.weight", D, D, D);
+        w.out_b = B.f32(pre + "self_attn.out_proj.bias", D);
+        w.fc1_w = B.bf16(pre + "mlp.fc1.weight", M, D, D);
+        w.fc1_b = B.f32(pre + "mlp.fc1.bias", M);
+        w.fc2_w = B.bf16(pre + "mlp.fc2.weight", D, M, M);
+        w.fc2_b = B.f32(pre + "mlp.fc2.bias", D);
+        for (int a = 0; a < 2 && B.ok && b > 0; ++a) {
+            const std::string ap = pre + "adapt_mlp_" + std::to_string(a + 1) + ".";
+            AdapterW &aw = w.ad[a];
+            aw.ln_w = B.f32(ap + "adapter_layer_norm.weight", D);
+            aw.ln_b = B.f32(ap + "adapter_layer_norm.bias", D);
+            aw.scale = B.f32(ap + "scale", 1);
+            // bottleneck padded to the GEMM N/K granularity (128): padded rows/cols are zero, GELU(0) = 0
+            bf16_t *dw = (bf16_t *)B.alloc(sizeof(bf16_t) * (size_t)m->bpad * D);
+            float *db = B.f32_zeros(m->bpad);
+            bf16_t *uw = (bf16_t *)B.alloc(sizeof(bf16_t) * (size_t)D * m->bpad);
+            if (!B.ok) break;
+            if (hipMemset(dw, 0, sizeof(bf16_t) * (size_t)m->bpad * D) != hipSuccess) B.ok = false;
+            B.bf16(ap + "down_proj.weight", b, D, D, dw);
+            const ch_tensor *bt = B.find(ap + "down_proj.bias", b);
+            if (bt && hipMemcpy(db, bt->data, sizeof(float) * b, hipMemcpyHostToDevice) != hipSuccess) B.ok = false;
+            B.bf16(ap + "up_proj.weight", D, b, m->bpad, uw);
+            aw.down_w = dw;
+            aw.down_b = db;
+            aw.up_w = uw;
+            aw.up_b = B.f32(ap + "up_proj.bias", D);
+        }
+    }
+    if (!B.ok) return 4;
+
+    // ---- concept tokens: forward_hash_query (coop.py:413-427), folded here once
+    {
+        const float *hq = B.f32("hash_queries", (int64_t)Q * P);
+        const float *inw = B.f32("hash_attention.sa.in_proj_weight", (int64_t)3 * P * P);
+        const float *inb = B.f32("hash_attention.sa.in_proj_bias", 3 * P);
+        const float *ow = B.f32("hash_attention.sa.out_proj.weight", (int64_t)P * P);
+        const float *ob = B.f32("hash_attention.sa.out_proj.bias", P);
+        const float *f0w = B.f32("hash_attention.ffn.0.weight", (int64_t)P * P);
+        const float *f0b = B.f32("hash_attention.ffn.0.bias", P);
+        const float *f3w = B.f32("hash_attention.ffn.3.weight", (int64_t)P * P);
+        const float *f3b = B.f32("hash_attention.ffn.3.bias", P);
+        const float *n1w = B.f32("hash_attention.norm1.weight", P);
+        const float *n1b = B.f32("hash_attention.norm1.bias", P);
+        const float *n2w = B.f32("hash_attention.norm2.weight", P);
+        const float *n2b = B.f32("hash_attention.norm2.bias", P);
+        const float *f2w = B.f32("hash_attention.ffn2.weight", (int64_t)D * P);
+        const float *f2b = B.f32("hash_attention.ffn2.bias", D);
+        float *qkv = (float *)B.alloc(sizeof(float) * Q * 3 * P);
+        float *t0 = (float *)B.alloc(sizeof(float) * Q * P);
+        float *t1 = (float *)B.alloc(sizeof(float) * Q * P);
+        float *t2 = (float *)B.alloc(sizeof(float) * Q * P);
+        float *ctx = (float *)B.alloc(sizeof(float) * Q * D);
+        if (!B.ok) return 4;
+        int e = 0;
+        e |= ch_small_linear(hq, Q, P, inw, inb, 3 * P, 0, qkv, s);
+        e |= ch_small_mha(qkv, Q, P, c.upt_heads, t0, s);
+        e |= ch_small_linear(t0, Q, P, ow, ob, P, 0, t1, s);         // sa(x)
+        e |= ch_small_layernorm(hq, Q, P, n1w, n1b, 1e-5f, t0, s);   // norm1(x)
+        e |= ch_small_add(t0, t1, (int64_t)Q * P, t2, s);            // x1 = norm1(x) + sa(x)
+        e |= ch_small_linear(t2, Q, P, f0w, f0b, P, 1, t0, s);       // relu(ffn.0(x1))
+        e |= ch_small_linear(t0, Q, P, f3w, f3b, P, 0, t1, s);       // ffn(x1)
+        e |= ch_small_layernorm(t2, Q, P, n2w, n2b, 1e-5f, t0, s);   // norm2(x1)
+        e |= ch_small_add(t0, t1, (int64_t)Q * P, t2, s);            // x2
+        e |= ch_small_linear(t2, Q, P, f2w, f2b, D, 0, ctx, s);
+        if (e) return 4;
+        m->ctx = ctx;
+    }
+
+    // ---- hash head
+    m->hash_pe = B.has("hash_pe") ? B.f32("hash_pe", (int64_t)Q * D) : B.f32_zeros((int64_t)Q * D);
+    m->hash_fc = B.f32("hash_fc.weight", (int64_t)(c.nbit / Q) * D);
+    {
+        float *sc = (float *)B.alloc(sizeof(float) * c.nbit), *sh = (float *)B.alloc(sizeof(float) * c.nbit);
+        if (!B.ok) return 4;
+        if (B.has("hash_bn.running_mean")) {
+            const float *w = B.f32("hash_bn.weight", c.nbit), *bb = B.f32("hash_bn.bias", c.nbit);
+            const float *mu = B.f32("hash_bn.running_mean", c.nbit), *var = B.f32("hash_bn.running_var", c.nbit);
+            if (!B.ok) return 4;
+            if (ch_bn_fold(w, bb, mu, var, c.nbit, c.bn_eps, sc, sh, s)) return 4;
+        } else {
+            std::vector<float> ones(c.nbit, 1.0f);
+            if (hipMemcpy(sc, ones.data(), sizeof(float) * c.nbit, hipMemcpyHostToDevice) != hipSuccess) return 4;
+            if (hipMemset(sh, 0, sizeof(float) * c.nbit) != hipSuccess) return 4;
+        }
+        m->bn_scale = sc;
+        m->bn_shift = sh;
+    }
+    // ---- centres: get_center (coop.py:624-625) + l2 / sign variants (coop.py:573-580)
+    {
+        const int cd = c.center_dim;
+        const float *cen = B.f32("center", (int64_t)C * cd);
+        float *proj = (float *)B.alloc(sizeof(float) * C * c.nbit);
+        if (B.has("text_projection.0.weight")) {
+            const float *w0 = B.f32("text_projection.0.weight", (int64_t)cd * cd), *b0 = B.f32("text_projection.0.bias", cd);
+            const float *w2 = B.f32("text_projection.2.weight", (int64_t)c.nbit * cd),
+                        *b2 = B.f32("text_projection.2.bias", c.nbit);
+            float *t = (float *)B.alloc(sizeof(float) * C * cd);
+            if (!B.ok) return 4;
+            if (ch_small_linear(cen, C, cd, w0, b0, cd, 1, t, s)) return 4;
+            if (ch_small_linear(t, C, cd, w2, b2, c.nbit, 0, proj, s)) return 4;
+        } else {
+            const float *w = B.f32("text_projection.weight", (int64_t)c.nbit * cd), *bb = B.f32("text_projection.bias", c.nbit);
+            if (!B.ok) return 4;
+            if (ch_small_linear(cen, C, cd, w, bb, c.nbit, 0, proj, s)) return 4;
+        }
+        float *l2 = (float *)B.alloc(sizeof(float) * C * c.nbit), *bin = (float *)B.alloc(sizeof(float) * C * c.nbit);
+        if (!B.ok) return 4;
+        if (ch_small_l2norm(proj, C, c.nbit, l2, bin, s)) return 4;
+        m->center_l2 = l2;
+        m->center_bin = bin;
+    }
+    if (B.has("concept_ce.centroids")) {
+        m->concept_pe = B.f32("concept_pe", (int64_t)Q * D);
+        const float *cc = B.f32("concept_ce.centroids", (int64_t)C * D);
+        float *l2 = (float *)B.alloc(sizeof(float) * C * D);
+        if (!B.ok) return 4;
+        if (ch_small_l2norm(cc, C, D, l2, nullptr, s)) return 4;
+        m->concept_cent_l2 = l2;
+    }
+    if (B.has(VM + "post_layernorm.weight") && B.has("backbone.visual_projection.weight")) {
+        m->post_w = B.f32(VM + "post_layernorm.weight", D);
+        m->post_b = B.f32(VM + "post_layernorm.bias", D);
+        m->vis_proj = B.f32("backbone.visual_projection.weight", (int64_t)P * D);
+    }
+    if (!B.ok) return 4;
+
+    // ---- workspace (rows padded to the GEMM block tile; padding rows are zero and never read back)
+    const int64_t rows = round_up64((int64_t)c.max_batch * m->ntok, 128);
+    const int64_t prows = round_up64((int64_t)c.max_batch * np, 128);
+    m->rows_alloc = rows;
+    m->prow_alloc = prows;
+    m->H = (float *)B.alloc(sizeof(float) * rows * D);
+    m->Xn = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * D);
+    m->QKV = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * 3 * D);
+    m->AO = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * D);
+    m->A = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * D);
+    m->AD = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * std::max(m->bpad, 128));
+    m->F1 = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * M);
+    m->PATCH = (bf16_t *)B.alloc(sizeof(bf16_t) * prows * Kp);
+    if (!B.ok) return 4;
+    CH_CHECK_HIP(hipMemset(m->H, 0, sizeof(float) * rows * D));
+    CH_CHECK_HIP(hipMemset(m->Xn, 0, sizeof(bf16_t) * rows * D));
+    CH_CHECK_HIP(hipMemset(m->QKV, 0, sizeof(bf16_t) * rows * 3 * D));
+    CH_CHECK_HIP(hipMemset(m->AO, 0, sizeof(bf16_t) * rows * D));
+    CH_CHECK_HIP(hipMemset(m->A, 0, sizeof(bf16_t) * rows * D));
+    CH_CHECK_HIP(hipMemset(m->AD, 0, sizeof(bf16_t) * rows * std::max(m->bpad, 128)));
+    CH_CHECK_HIP(hipMemset(m->F1, 0, sizeof(bf16_t) * rows * M));
+    CH_CHECK_HIP(hipMemset(m->PATCH, 0, sizeof(bf16_t) * prows * Kp));
+    CH_CHECK_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+// encoder up to `nlayers` layers; leaves the residual stream in m->H
+int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nlayers, hipStream_t s) {
+    const ch_model_config &c = m->cfg;
+    const int D = c.dim, M = c.ffn, ntok = m->ntok, np = m->np;
+    const int rows = B * ntok;
+    const int act_epi = c.act == 0 ? EPI_BIAS_QUICKGELU : EPI_BIAS_GELU;
+
+    if (int e = ch_im2col(images, image_dtype, B, c.image_size, c.patch, m->Kp, m->PATCH, s)) return e;
+    {
+        GemmParams p{};
+        p.X = m->PATCH; p.W = m->patch_w; p.M = B * np; p.N = D; p.K = m->Kp; p.X_rows_alloc = m->prow_alloc;
+        p.bias = nullptr; p.resid = m->H; p.ldr = D; p.pos = m->pos; p.tokens_per_img = ntok; p.patches_per_img = np;
+        if (int e = ch_gemm_bf16(p, EPI_PATCH, s)) return e;
+    }
+    const LayerW &w0 = m->layers[0];
+    if (int e = ch_assemble_preln(m->H, B, ntok, np, D, m->cls_pos0, m->ctx, m->pre_w, m->pre_b, w0.ln1_w, w0.ln1_b,
+                                  c.ln_eps, m->Xn, s))
+        return e;
+
+    auto gemm = [&](const bf16_t *X, const bf16_t *W, int N, int K, const float *bias, int epi, bf16_t *out, int ldo,
+                    const float *scale) {
+        GemmParams p{};
+        p.X = X; p.W = W; p.M = rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
+        p.out_bf16 = out; p.ldo = ldo; p.resid = m->H; p.ldr = D; p.scale_ptr = scale;
+        return ch_gemm_bf16(p, epi, s);
+    };
+    auto adapter = [&](const AdapterW &aw) -> int {
+        if (!aw.down_w) return 0;
+        // Adapter (models/layers/adapter.py:46-60) on the bf16 copy of the sub-block output held in m->A
+        if (int e = ch_layernorm_bf16(m->A, rows, D, aw.ln_w, aw.ln_b, 1e-5f, m->Xn, s)) return e;
+        if (int e = gemm(m->Xn, aw.down_w, m->bpad, D, aw.down_b, EPI_BIAS_GELU, m->AD, m->bpad, nullptr)) return e;
+        return gemm(m->AD, aw.up_w, D, m->bpad, aw.up_b, EPI_SCALE_RESID, nullptr, 0, aw.scale);
+    };
+
+    for (int i = 0; i < nlayers; ++i) {
+        const LayerW &w = m->layers[i];
+        if (i > 0)
+            if (int e = ch_layernorm_f32(m->H, rows, D, w.ln1_w, w.ln1_b, c.ln_eps, m->Xn, s)) return e;
+        if (int e = gemm(m->Xn, w.qkv_w, 3 * D, D, w.qkv_b, EPI_BIAS, m->QKV, 3 * D, nullptr)) return e;
+        if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s)) return e;
+        // h = r + a  (+ adapter_1(a) below);  a kept as bf16 in m->A for the adapter branch
+        if (int e = gemm(m->AO, w.out_w, D, D, w.out_b, EPI_BIAS_RESID, m->A, D, nullptr)) return e;
+        if (int e = adapter(w.ad[0])) return e;
+        if (int e = ch_layernorm_f32(m->H, rows, D, w.ln2_w, w.ln2_b, c.ln_eps, m->Xn, s)) return e;
+        if (int e = gemm(m->Xn, w.fc1_w, M, D, w.fc1_b, act_epi, m->F1, M, nullptr)) return e;
+        if (int e = gemm(m->F1, w.fc2_w, D, M, w.fc2_b, EPI_BIAS_RESID, m->A, D, nullptr)) return e;
+        if (int e = adapter(w.ad[1])) return e;
+    }
+    return 0;
+}
+
+int validate(const ch_model_config *c) {
+    CH_REQUIRE(c != nullptr, "null config");
+    CH_REQUIRE(c->dim > 0 && c->dim % 128 == 0 && c->dim <= 1280, "dim must be a multiple of 128 and <= 1280");
+    CH_REQUIRE(c->heads > 0 && c->dim == c->heads * 64, "head_dim must be 64 (dim == heads * 64)");
+    CH_REQUIRE(c->ffn > 0 && c->ffn % 128 == 0, "ffn must be a multiple of 128");
+    CH_REQUIRE(c->layers >= 1, "layers must be >= 1");
+    CH_REQUIRE(c->patch > 0 && c->image_size > 0 && c->image_size % c->patch == 0, "image_size must be divisible by patch");
+    CH_REQUIRE(c->ncontext >= 1 && c->ncontext <= 64, "ncontext must be in [1, 64]");
+    CH_REQUIRE(c->nbit > 0 && c->nbit % c->ncontext == 0, "nbit must be divisible by ncontext");
+    CH_REQUIRE(c->nclass > 0 && c->proj_dim > 0 && c->center_dim > 0, "nclass / proj_dim / center_dim must be positive");
+    CH_REQUIRE(c->upt_heads > 0 && c->proj_dim % c->upt_heads == 0, "proj_dim must be divisible by upt_heads");
+    CH_REQUIRE(c->adapter_dim >= 0, "adapter_dim must be >= 0");
+    CH_REQUIRE(c->max_batch >= 1, "max_batch must be >= 1");
+    CH_REQUIRE(c->act == 0 || c->act == 1, "act must be 0 (quick_gelu) or 1 (gelu)");
+    const int grid = c->image_size / c->patch;
+    CH_REQUIRE(1 + grid * grid + c->ncontext <= 288, "more than 288 tokens per image is not supported");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tensors, int32_t ntensors, ch_model **out) {
+    CH_REQUIRE(out != nullptr, "null out pointer");
+    *out = nullptr;
+    if (int e = validate(cfg)) return e;
+    CH_REQUIRE(tensors != nullptr && ntensors > 0, "no tensors");
+    ch_model *m = new ch_model();
+    m->cfg = *cfg;
+    if (m->cfg.ln_eps <= 0.f) m->cfg.ln_eps = 1e-5f;
+    if (m->cfg.bn_eps <= 0.f) m->cfg.bn_eps = 1e-5f;
+    const int grid = cfg->image_size / cfg->patch;
+    m->np = grid * grid;
+    m->ntok = 1 + m->np + cfg->ncontext;
+    m->Kp = (int)round_up64(3 * cfg->patch * cfg->patch, 64);
+    m->bpad = (int)round_up64(cfg->adapter_dim, 128);
+    int e = build_model(m, tensors, ntensors);
+    if (e == 0 && hipDeviceSynchronize() != hipSuccess) {
+        ch_set_error("device error while folding weights");
+        e = 4;
+    }
+    if (e) {
+        ch_model_destroy(m);
+        return e;
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" void ch_model_destroy(ch_model *m) {
+    if (!m) return;
+    for (void *p : m->allocs) (void)hipFree(p);
+    delete m;
+}
+
+extern "C" size_t ch_model_device_bytes(const ch_model *m) { return m ? m->bytes : 0; }
+
+extern "C" double ch_model_flops_per_image(const ch_model *m) {
+    if (!m) return 0.0;
+    const ch_model_config &c = m->cfg;
+    const double N = m->ntok, D = c.dim, M = c.ffn, b = c.adapter_dim, L = c.layers;
+    const double patch = 2.0 * m->np * D * 3.0 * c.patch * c.patch;
+    const double layer = 8.0 * N * D * D + 4.0 * N * D * M + 4.0 * N * N * D + 8.0 * N * D * b;
+    return patch + L * layer + 2.0 * D * c.nbit;
+}
+
+extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, float *out_codes,
+                         uint64_t *out_packed, float *out_logits_cont, float *out_logits_bin, float *out_logits_concept,
+                         float *out_hash_features, float *out_image_features, void *stream) {
+    CH_REQUIRE(m != nullptr && images != nullptr && out_codes != nullptr, "null model / images / out_codes");
+    CH_REQUIRE(image_dtype == 0 || image_dtype == 1, "image_dtype must be 0 (fp32) or 1 (bf16)");
+    CH_REQUIRE(B >= 1 && B <= m->cfg.max_batch, "batch outside [1, max_batch]");
+    CH_REQUIRE(!out_logits_concept || m->concept_cent_l2, "model has no concept classifier (concept_ce.centroids)");
+    CH_REQUIRE(!out_image_features || m->vis_proj, "model has no post_layernorm / visual_projection");
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = run_encoder(m, images, image_dtype, B, m->cfg.layers, s)) return e;
+    const ch_model_config &c = m->cfg;
+    HeadParams p{};
+    p.H = m->H; p.B = B; p.ntok = m->ntok; p.D = c.dim; p.Q = c.ncontext; p.nbit = c.nbit; p.C = c.nclass; p.P = c.proj_dim;
+    p.hash_pe = m->hash_pe; p.hash_fc = m->hash_fc; p.bn_scale = m->bn_scale; p.bn_shift = m->bn_shift;
+    p.center_l2 = m->center_l2; p.center_bin = m->center_bin; p.concept_pe = m->concept_pe;
+    p.concept_cent_l2 = m->concept_cent_l2; p.post_w = m->post_w; p.post_b = m->post_b; p.vis_proj = m->vis_proj;
+    p.ln_eps = c.ln_eps;
+    p.out_codes = out_codes; p.out_packed = out_packed; p.out_logits_cont = out_logits_cont;
+    p.out_logits_bin = out_logits_bin; p.out_logits_concept = out_logits_concept;
+    p.out_hash_features = out_hash_features; p.out_image_features = out_image_features;
+    return ch_head(p, s);
+}
+
+extern "C" int ch_encode_hidden(ch_model *m, const void *images, int32_t image_dtype, int32_t B, int32_t layer,
+                                float *out_hidden, void *stream) {
+    CH_REQUIRE(m != nullptr && images != nullptr && out_hidden != nullptr, "null model / images / out_hidden");
+    CH_REQUIRE(B >= 1 && B <= m->cfg.max_batch, "batch outside [1, max_batch]");
+    CH_REQUIRE(layer >= 0 && layer <= m->cfg.layers, "layer outside [0, layers]");
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = run_encoder(m, images, image_dtype, B, layer, s)) return e;
+    CH_CHECK_HIP(hipMemcpyAsync(out_hidden, m->H, sizeof(float) * (size_t)B * m->ntok * m->cfg.dim,
+                                hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+extern "C" int ch_pack_sign(const float *codes, int64_t rows, int32_t nbit, float threshold, uint64_t *out_packed,
+                            void *stream) {
+    CH_REQUIRE(rows >= 0 && nbit > 0, "pack_sign: rows must be >= 0 and nbit > 0");
+    CH_REQUIRE(rows == 0 || (codes && out_packed), "pack_sign: null pointer");
+    return ch_pack_sign_launch(codes, rows, nbit, threshold, out_packed, (hipStream_t)stream);
+}

@@ -1,0 +1,168 @@
+"""Host-side owner of a ``ch_model`` (HIP encoder).  PyTorch is used for device memory and streams only.
+
+Mirrors the reference's model object for the encode path: built from a reference-layout ``state_dict``
+(aliases ``adapter_params.*`` / ``trainable_params.*`` are dropped), evaluated with
+``encode(images) -> dict`` whose keys follow ``LGHWithoutText.forward`` (models/arch/coop.py:582-598).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Iterable, Optional
+
+import torch
+
+from . import _lib
+
+VM = "backbone.vision_model."
+_SKIP_PREFIXES = ("adapter_params.", "trainable_params.", "backbone.text_model.", "backbone.text_projection",
+                  "token_embeds")
+_SKIP_KEYS = ("backbone.logit_scale", "hash_bn.num_batches_tracked", VM + "embeddings.position_ids")
+
+
+def infer_config(sd: Dict[str, torch.Tensor], heads: Optional[int] = None) -> dict:
+    """Model dimensions from a reference-layout state_dict."""
+    pw = sd[VM + "embeddings.patch_embedding.weight"]
+    D, _, p, _ = pw.shape
+    npos = sd[VM + "embeddings.position_embedding.weight"].shape[0]
+    grid = int(round(math.sqrt(npos - 1)))
+    if grid * grid != npos - 1:
+        raise ValueError(f"position embedding has {npos} rows; expected 1 + grid^2")
+    L = 0
+    while (VM + f"encoder.layers.{L}.layer_norm1.weight") in sd:
+        L += 1
+    if L == 0:
+        raise ValueError("state_dict has no encoder layers under " + VM + "encoder.layers.*")
+    ad_key = VM + "encoder.layers.0.adapt_mlp_1.down_proj.weight"
+    Q = sd["hash_pe"].shape[1] if "hash_pe" in sd else sd["hash_queries"].shape[1]
+    cfg = dict(image_size=grid * p, patch=p, dim=D, layers=L, heads=heads if heads else D // 64,
+               ffn=sd[VM + "encoder.layers.0.mlp.fc1.weight"].shape[0],
+               adapter_dim=sd[ad_key].shape[0] if ad_key in sd else 0, ncontext=Q,
+               nbit=sd["hash_fc.weight"].shape[0] * Q, nclass=sd["center"].shape[0],
+               proj_dim=sd["hash_queries"].shape[2], center_dim=sd["center"].shape[1])
+    return cfg
+
+
+class ConceptHashEncoder:
+    """ViT + concept tokens + hashing head on one MI355X, through the C-ABI."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], heads: Optional[int] = None, upt_heads: int = 8,
+                 act: str = "quick_gelu", max_batch: int = 256, device: Optional[torch.device] = None,
+                 ln_eps: float = 1e-5, bn_eps: float = 1e-5):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("ConceptHashEncoder needs a GPU (MI355X); there is no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        cfg = infer_config(state_dict, heads)
+        cfg.update(upt_heads=upt_heads, act={"quick_gelu": 0, "gelu": 1}[act], max_batch=max_batch)
+        self.cfg = cfg
+        c = _lib.ModelConfig(ln_eps=ln_eps, bn_eps=bn_eps, **cfg)
+        keep = []
+        entries = []
+        for k, v in state_dict.items():
+            if k.startswith(_SKIP_PREFIXES) or k in _SKIP_KEYS or not torch.is_tensor(v):
+                continue
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            keep.append(t)
+            entries.append((k.encode(), t))
+        arr = (_lib.Tensor * len(entries))()
+        for i, (name, t) in enumerate(entries):
+            arr[i].name = name
+            arr[i].data = ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))
+            arr[i].numel = t.numel()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ch_model_create(ctypes.byref(c), arr, len(entries), ctypes.byref(handle)),
+                       "ch_model_create")
+        self._h = handle
+        self.nbit = cfg["nbit"]
+        self.words = (self.nbit + 63) // 64
+        self.ntok = 1 + (cfg["image_size"] // cfg["patch"]) ** 2 + cfg["ncontext"]
+        self.has_concept = "concept_ce.centroids" in state_dict
+        self.has_pooled = (VM + "post_layernorm.weight") in state_dict and "backbone.visual_projection.weight" in state_dict
+
+    # -- lifetime ------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ch_model_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.lib.ch_model_device_bytes(self._h))
+
+    @property
+    def flops_per_image(self) -> float:
+        return float(self.lib.ch_model_flops_per_image(self._h))
+
+    # -- encode ---------------------------------------------------------------------------------------------------
+    def _check_images(self, images: torch.Tensor):
+        s = self.cfg["image_size"]
+        if images.dim() != 4 or images.shape[1] != 3 or images.shape[2] != s or images.shape[3] != s:
+            raise ValueError(f"images must be [B,3,{s},{s}], got {tuple(images.shape)}")
+        if images.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("images must be float32 or bfloat16")
+        if images.device != self.device:
+            raise ValueError(f"images are on {images.device}, the model is on {self.device}")
+
+    def encode(self, images: torch.Tensor, want: Iterable[str] = ("codes", "packed"), stream=None) -> Dict[str, torch.Tensor]:
+        """want: subset of {codes, packed, logits_cont, logits_bin, logits_concept, hash_features, image_features};
+        'codes' is always produced.  Batches larger than max_batch are processed in chunks on the same stream."""
+        self._check_images(images)
+        images = images.contiguous()
+        want = set(want) | {"codes"}
+        unknown = want - {"codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features", "image_features"}
+        if unknown:
+            raise KeyError(f"unknown outputs {sorted(unknown)}")
+        B = images.shape[0]
+        c = self.cfg
+        dev = self.device
+        out = {"codes": torch.empty(B, c["nbit"], dtype=torch.float32, device=dev)}
+        if "packed" in want:
+            out["packed"] = torch.empty(B, self.words, dtype=torch.int64, device=dev)
+        if "logits_cont" in want:
+            out["logits_cont"] = torch.empty(B, c["nclass"], dtype=torch.float32, device=dev)
+        if "logits_bin" in want:
+            out["logits_bin"] = torch.empty(B, c["nclass"], dtype=torch.float32, device=dev)
+        if "hash_features" in want:
+            out["hash_features"] = torch.empty(B, c["ncontext"], c["dim"], dtype=torch.float32, device=dev)
+        if "image_features" in want:
+            out["image_features"] = torch.empty(B, c["proj_dim"], dtype=torch.float32, device=dev)
+        concept_chunks = []
+        dt = 0 if images.dtype == torch.float32 else 1
+        sp = _lib.stream_ptr(stream)
+        mb = c["max_batch"]
+        with torch.cuda.device(dev):
+            for b0 in range(0, B, mb):
+                b1 = min(B, b0 + mb)
+                lc = None
+                if "logits_concept" in want:
+                    lc = torch.empty(c["ncontext"], b1 - b0, c["nclass"], dtype=torch.float32, device=dev)
+                    concept_chunks.append(lc)
+
+                def sl(name):
+                    return _lib.ptr(out[name][b0:b1]) if name in out else ctypes.c_void_p(0)
+
+                _lib.check(self.lib.ch_encode(self._h, _lib.ptr(images[b0:b1]), dt, b1 - b0, sl("codes"), sl("packed"),
+                                              sl("logits_cont"), sl("logits_bin"), _lib.ptr(lc), sl("hash_features"),
+                                              sl("image_features"), sp), "ch_encode")
+        if concept_chunks:
+            out["logits_concept"] = concept_chunks[0] if len(concept_chunks) == 1 else torch.cat(concept_chunks, dim=1)
+        return out
+
+    def hidden_states(self, images: torch.Tensor, layer: int, stream=None) -> torch.Tensor:
+        """Parity tap: fp32 residual stream [B, N, D] after `layer` encoder layers (0 = after pre-LN)."""
+        self._check_images(images)
+        images = images.contiguous()
+        B = images.shape[0]
+        out = torch.empty(B, self.ntok, self.cfg["dim"], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ch_encode_hidden(self._h, _lib.ptr(images), 0 if images.dtype == torch.float32 else 1, B,
+                                                 layer, _lib.ptr(out), _lib.stream_ptr(stream)), "ch_encode_hidden")
+        return out

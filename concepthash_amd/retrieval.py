@@ -1,0 +1,231 @@
+"""Packed-code Hamming retrieval on the GPU through the C-ABI: pack, distance, top-k, mAP / P@k / R@k, and the
+gallery-sharded multi-GPU variants (one process per GPU, RCCL via ``torch.distributed``).
+
+Replaces the reference's un-vendored ``utils.hashing`` arithmetic (call sites experiments/test_hashing.py:106-119,
+153-162).  PyTorch supplies device buffers, streams and collectives; all per-pair arithmetic runs in
+``csrc/hamming.hip``.  Packed codes are ``int64`` tensors holding the uint64 bit patterns ([rows, W]).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+TWO32 = 4294967296.0
+
+
+def _dev_guard(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("retrieval kernels need GPU tensors (MI355X); there is no CPU fallback")
+    return torch.cuda.device(t.device)
+
+
+def pack_sign(codes: torch.Tensor, threshold: float = 0.0, stream=None) -> torch.Tensor:
+    """[rows, nbit] fp32 -> [rows, ceil(nbit/64)] int64; bit i = (codes[:, i] - threshold) > 0 (little endian)."""
+    lib = _lib.load()
+    if codes.dim() != 2:
+        raise ValueError("codes must be 2-D")
+    codes = codes.to(torch.float32).contiguous()
+    rows, nbit = codes.shape
+    out = torch.empty(rows, (nbit + 63) // 64, dtype=torch.int64, device=codes.device)
+    with _dev_guard(codes):
+        _lib.check(lib.ch_pack_sign(_lib.ptr(codes), rows, nbit, float(threshold), _lib.ptr(out), _lib.stream_ptr(stream)),
+                   "ch_pack_sign")
+    return out
+
+
+def _check_packed(q: torch.Tensor, g: torch.Tensor):
+    if q.dtype != torch.int64 or g.dtype != torch.int64 or q.dim() != 2 or g.dim() != 2:
+        raise TypeError("packed codes must be 2-D int64 tensors")
+    if q.shape[1] != g.shape[1]:
+        raise ValueError(f"query has {q.shape[1]} words per code, gallery {g.shape[1]}")
+    if q.device != g.device:
+        raise ValueError("query and gallery codes must be on the same device")
+    return q.contiguous(), g.contiguous()
+
+
+def hamming_dist(q: torch.Tensor, g: torch.Tensor, stream=None) -> torch.Tensor:
+    """Full [Qn, G] int32 distance matrix (small problems; ``get_hamm_dist`` semantics without normalisation)."""
+    lib = _lib.load()
+    q, g = _check_packed(q, g)
+    out = torch.empty(q.shape[0], g.shape[0], dtype=torch.int32, device=q.device)
+    with _dev_guard(q):
+        _lib.check(lib.ch_hamming_dist(_lib.ptr(q), q.shape[0], _lib.ptr(g), g.shape[0], q.shape[1], _lib.ptr(out),
+                                       _lib.stream_ptr(stream)), "ch_hamming_dist")
+    return out
+
+
+def hamming_topk(q: torch.Tensor, g: torch.Tensor, k: int, g_index_base: int = 0, stream=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Top-k by ascending (distance, gallery index): (idx int64 [Qn,k], dist int32 [Qn,k]); -1 where k > G."""
+    lib = _lib.load()
+    q, g = _check_packed(q, g)
+    Qn, W = q.shape
+    G = g.shape[0]
+    idx = torch.empty(Qn, k, dtype=torch.int64, device=q.device)
+    dist = torch.empty(Qn, k, dtype=torch.int32, device=q.device)
+    wsb = int(lib.ch_hamming_topk_workspace(Qn, G, W, k))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+    with _dev_guard(q):
+        _lib.check(lib.ch_hamming_topk(_lib.ptr(q), Qn, _lib.ptr(g), G, W, k, int(g_index_base), _lib.ptr(idx),
+                                       _lib.ptr(dist), _lib.ptr(ws), wsb, _lib.stream_ptr(stream)), "ch_hamming_topk")
+    return idx, dist
+
+
+def topk_merge(idx_lists: torch.Tensor, dist_lists: torch.Tensor, stream=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[nlists, Qn, k] per-shard lists -> global [Qn, k]."""
+    lib = _lib.load()
+    idx_lists = idx_lists.contiguous()
+    dist_lists = dist_lists.contiguous()
+    n, Qn, k = idx_lists.shape
+    idx = torch.empty(Qn, k, dtype=torch.int64, device=idx_lists.device)
+    dist = torch.empty(Qn, k, dtype=torch.int32, device=idx_lists.device)
+    with _dev_guard(idx_lists):
+        _lib.check(lib.ch_topk_merge(_lib.ptr(idx_lists), _lib.ptr(dist_lists), n, Qn, k, _lib.ptr(idx), _lib.ptr(dist),
+                                     _lib.stream_ptr(stream)), "ch_topk_merge")
+    return idx, dist
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# labels
+# ---------------------------------------------------------------------------------------------------------------
+def prepare_labels(q_labels: torch.Tensor, g_labels: torch.Tensor):
+    """Returns (q_lab, g_lab, LW).  1-D integer labels, or one-hot rows with exactly one class each -> int32 ids
+    (LW = 0); otherwise multi-hot -> int64 bitmasks [rows, LW]."""
+    if q_labels.dim() == 1 and g_labels.dim() == 1:
+        return q_labels.to(torch.int32).contiguous(), g_labels.to(torch.int32).contiguous(), 0
+    if q_labels.dim() != 2 or g_labels.dim() != 2 or q_labels.shape[1] != g_labels.shape[1]:
+        raise ValueError("labels must both be 1-D class ids or 2-D [rows, C] indicator matrices")
+    qb, gb = q_labels != 0, g_labels != 0
+    single = bool((qb.sum(1) == 1).all().item()) and bool((gb.sum(1) == 1).all().item())
+    if single:
+        return qb.int().argmax(1).to(torch.int32).contiguous(), gb.int().argmax(1).to(torch.int32).contiguous(), 0
+    C = qb.shape[1]
+    LW = (C + 63) // 64
+
+    def pack(b):
+        pad = LW * 64 - C
+        if pad:
+            b = torch.cat([b, torch.zeros(b.shape[0], pad, dtype=torch.bool, device=b.device)], dim=1)
+        w = torch.ones(64, dtype=torch.int64, device=b.device) << torch.arange(64, dtype=torch.int64, device=b.device)
+        return (b.view(b.shape[0], LW, 64).to(torch.int64) * w).sum(-1).contiguous()  # wraps mod 2^64: bit 63 ok
+
+    return pack(qb), pack(gb), LW
+
+
+def map_seg_rows(Qn: int, G: int, W: int) -> int:
+    blk = 256 if W <= 2 else 128
+    tiles = max(1, -(-Qn // blk))
+    nseg = max(1, -(-1024 // tiles))
+    rows = -(-G // nseg)
+    return int(min(65535, max(256, rows)))
+
+
+def hamming_hist(q, g, q_lab, g_lab, LW: int, seg_rows: int, stream=None) -> torch.Tensor:
+    """mAP pass 1: [nseg, Qn, 64W+1, 2] int32 (uint32 bit patterns)."""
+    lib = _lib.load()
+    q, g = _check_packed(q, g)
+    Qn, W = q.shape
+    G = g.shape[0]
+    nseg = max(1, -(-G // seg_rows))
+    hist = torch.zeros(nseg, Qn, 64 * W + 1, 2, dtype=torch.int32, device=q.device)
+    with _dev_guard(q):
+        _lib.check(lib.ch_hamming_hist(_lib.ptr(q), Qn, _lib.ptr(g), G, W, _lib.ptr(q_lab), _lib.ptr(g_lab), LW, seg_rows,
+                                       _lib.ptr(hist), _lib.stream_ptr(stream)), "ch_hamming_hist")
+    return hist
+
+
+def hist_prefix(hist: torch.Tensor, stream=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    lib = _lib.load()
+    hist = hist.contiguous()
+    nseg, Qn, nb, _ = hist.shape
+    base = torch.empty_like(hist)
+    totals = torch.empty(Qn, 2, dtype=torch.int32, device=hist.device)
+    with _dev_guard(hist):
+        _lib.check(lib.ch_hamming_hist_prefix(_lib.ptr(hist), nseg, Qn, nb, _lib.ptr(base), _lib.ptr(totals),
+                                              _lib.stream_ptr(stream)), "ch_hamming_hist_prefix")
+    return base, totals
+
+
+def hamming_ap(q, g, q_lab, g_lab, LW: int, seg_rows: int, base: torch.Tensor, rank_limit: int = -1,
+               first_rel: Optional[torch.Tensor] = None, out_S: Optional[torch.Tensor] = None,
+               out_nrel: Optional[torch.Tensor] = None, stream=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """mAP pass 2 -> (S int64 [Qn] fixed-point numerators, nrel int32 [Qn])."""
+    lib = _lib.load()
+    q, g = _check_packed(q, g)
+    Qn, W = q.shape
+    G = g.shape[0]
+    S = out_S if out_S is not None else torch.zeros(Qn, dtype=torch.int64, device=q.device)
+    nrel = out_nrel if out_nrel is not None else torch.zeros(Qn, dtype=torch.int32, device=q.device)
+    if first_rel is not None:
+        first_rel = first_rel.to(torch.int32).contiguous()
+    with _dev_guard(q):
+        _lib.check(lib.ch_hamming_ap(_lib.ptr(q), Qn, _lib.ptr(g), G, W, _lib.ptr(q_lab), _lib.ptr(g_lab), LW, seg_rows,
+                                     _lib.ptr(base.contiguous()), int(rank_limit), _lib.ptr(first_rel), _lib.ptr(S),
+                                     _lib.ptr(nrel), _lib.stream_ptr(stream)), "ch_hamming_ap")
+    return S, nrel
+
+
+def _relevance_of(idx: torch.Tensor, q_lab: torch.Tensor, g_lab_all: torch.Tensor, LW: int) -> torch.Tensor:
+    """[Qn,k] bool relevance of retrieved rows (label gather; idx -1 -> False)."""
+    safe = idx.clamp_min(0)
+    if LW == 0:
+        rel = g_lab_all[safe] == q_lab[:, None]
+    else:
+        rel = (g_lab_all[safe] & q_lab[:, None, :]).ne(0).any(-1)
+    return rel & (idx >= 0)
+
+
+def ap_from_fixed(S: torch.Tensor, nrel: torch.Tensor) -> torch.Tensor:
+    """AP[q] = S / (nrel * 2^32) in float64 (0 where nrel == 0); S holds uint64 bit patterns."""
+    Sf = S.to(torch.float64)
+    Sf = torch.where(S < 0, Sf + 18446744073709551616.0, Sf)
+    n = nrel.to(torch.float64)
+    return torch.where(nrel > 0, Sf / (n.clamp_min(1.0) * TWO32), torch.zeros_like(Sf))
+
+
+def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels: torch.Tensor, R: int = -1,
+             ks: Sequence[int] = (1, 5, 10), remove_first: bool = False, seg_rows: Optional[int] = None) -> dict:
+    """Single-GPU mAP@R + P@k + R@k on packed codes.  Returns python floats/lists plus the raw integer statistics
+    (S, nrel, hits, total) that the parity tests compare bit-for-bit with the oracle."""
+    q, g = _check_packed(q, g)
+    Qn, W = q.shape
+    G = g.shape[0]
+    q_lab, g_lab, LW = prepare_labels(q_labels.to(q.device), g_labels.to(q.device))
+    seg = seg_rows or map_seg_rows(Qn, G, W)
+    ks = [int(k) for k in ks]
+    kmax = (max(ks) if ks else 0) + (1 if remove_first else 0)
+    dev = q.device
+    if Qn == 0 or G == 0:
+        z64 = torch.zeros(Qn, dtype=torch.int64, device=dev)
+        z32 = torch.zeros(Qn, dtype=torch.int32, device=dev)
+        return dict(mAP=0.0, precisions=[0.0] * len(ks), recalls=[0.0] * len(ks), S=z64, nrel=z32,
+                    hits=torch.zeros(Qn, len(ks), dtype=torch.int32, device=dev), total=z32, ap=z64.double())
+    first_rel = None
+    rel_top = None
+    if kmax > 0:
+        kk = min(kmax, 128)
+        idx, _ = hamming_topk(q, g, kk)
+        rel_top = _relevance_of(idx, q_lab, g_lab, LW)
+        if remove_first:
+            first_rel = rel_top[:, 0].to(torch.int32)
+            rel_top = rel_top[:, 1:]
+    hist = hamming_hist(q, g, q_lab, g_lab, LW, seg)
+    base, totals = hist_prefix(hist)
+    S, nrel = hamming_ap(q, g, q_lab, g_lab, LW, seg, base, rank_limit=R, first_rel=first_rel)
+    total = totals[:, 1].clone()
+    if remove_first:
+        total = total - first_rel
+    ap = ap_from_fixed(S, nrel)
+    hits = torch.zeros(Qn, len(ks), dtype=torch.int32, device=dev)
+    precisions, recalls = [], []
+    for t, k in enumerate(ks):
+        h = rel_top[:, :k].sum(1).to(torch.int32) if rel_top is not None and rel_top.shape[1] > 0 else torch.zeros_like(total)
+        hits[:, t] = h
+        precisions.append(float((h.double() / k).mean().item()))
+        recalls.append(float(torch.where(total > 0, h.double() / total.clamp_min(1).double(),
+                                         torch.zeros_like(h, dtype=torch.float64)).mean().item()))
+    return dict(mAP=float(ap.mean().item()), precisions=precisions, recalls=recalls, S=S, nrel=nrel, hits=hits,
+                total=total, ap=ap)

@@ -1,0 +1,154 @@
+/*
+ * concepthash_hip.h -- C-ABI of libconcepthash_hip.so (MI355X / gfx950).
+ *
+ * The reference (kamwoh/concepthash) is pure Python/PyTorch and exposes NO FFI/operator interface (SURVEY.md F1,
+ * section 8b); its boundary is Python import paths.  This header is therefore the boundary *defined by this
+ * project*: each entry point names the reference function(s) it replaces (paths relative to the reference root) and
+ * is what a maintainer's ctypes stub binds.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; ch_last_error() gives the message (thread local);
+ *     no C++ exception crosses the boundary.
+ *   - all data pointers are DEVICE pointers owned by the caller unless a parameter says "host".
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work and never
+ *     synchronise, allocate or free device memory (graph-capture safe) -- except ch_model_create/destroy.
+ *   - integers are bit-exact by contract; floating point tolerances are stated in DESIGN.md / tests.
+ */
+#ifndef CONCEPTHASH_HIP_H
+#define CONCEPTHASH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CH_ABI_VERSION 1
+
+typedef struct ch_model ch_model; /* opaque: weights (bf16/fp32, device) + activation workspace */
+
+typedef struct ch_model_config {
+    int32_t image_size;  /* H == W of the input, e.g. 224 (pretrain resolution; no pos-embed interpolation) */
+    int32_t patch;       /* 14 / 16 / 32 */
+    int32_t dim;         /* D: ViT width (multiple of 64) */
+    int32_t layers;      /* L */
+    int32_t heads;       /* attention heads; dim / heads must be 64 */
+    int32_t ffn;         /* MLP hidden width */
+    int32_t adapter_dim; /* adapter bottleneck b (0 = no adapters) */
+    int32_t ncontext;    /* Q: number of concept tokens */
+    int32_t nbit;        /* total hash bits = Q * bits-per-concept */
+    int32_t nclass;      /* C */
+    int32_t proj_dim;    /* P: CLIP projection dim (concept-token generator width) */
+    int32_t center_dim;  /* width of the `center` buffer (512 for CLIP text features) */
+    int32_t upt_heads;   /* heads of the concept-token generator MHA (config upt_config.num_heads, 8) */
+    int32_t act;         /* 0 = quick_gelu (OpenAI CLIP), 1 = exact gelu */
+    int32_t max_batch;   /* largest B accepted by ch_encode (workspace is sized for it) */
+    float ln_eps;        /* LayerNorm eps (1e-5) */
+    float bn_eps;        /* BatchNorm1d eps (1e-5) */
+} ch_model_config;
+
+/* One named fp32 tensor in HOST memory.  `name` is the reference state_dict key, e.g.
+ * "backbone.vision_model.encoder.layers.0.self_attn.q_proj.weight", "hash_fc.weight", "hash_bn.running_var". */
+typedef struct ch_tensor {
+    const char *name;
+    const float *data; /* host, fp32, contiguous, PyTorch layout */
+    int64_t numel;
+} ch_tensor;
+
+int ch_abi_version(void);
+const char *ch_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Encode
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* Replaces: model construction + BaseTrainer.load_model_state (trainers/base.py:195-197) + .to(device)
+ * (trainers/base.py:57-71) for models.arch.coop.LGHWithFixedPrompt.  Copies/convert weights to the device (GEMM
+ * operands -> bf16, everything else fp32), and folds the input-independent parts of the forward once, on the GPU:
+ * forward_hash_query (models/arch/coop.py:413-427) -> concept tokens; get_center (coop.py:624-625) -> projected,
+ * l2-normalised centres; BatchNorm1d eval (coop.py:559) -> per-bit affine.  Unknown/missing names are an error;
+ * aliases (`adapter_params.*`, `trainable_params.*`) are ignored. */
+int ch_model_create(const ch_model_config *cfg, const ch_tensor *tensors, int32_t ntensors, ch_model **out);
+void ch_model_destroy(ch_model *m);
+/* bytes of device memory held by the model (weights + workspace) */
+size_t ch_model_device_bytes(const ch_model *m);
+
+/* Replaces: LGHWithFixedPrompt.forward (models/arch/coop.py:524-598) as driven by
+ * COOPTrainer.compute_features_one_batch (trainers/coop.py:59-71), eval mode.
+ *   images        [B,3,H,W] NCHW, fp32 (image_dtype 0) or bf16 (image_dtype 1)
+ *   out_codes     [B,nbit] fp32 pre-sign codes ("codes", coop.py:559)                      (required)
+ *   out_packed    [B,W] uint64, W = ceil(nbit/64); bit i = codes[i] > 0 (little endian)   (optional, NULL)
+ *   out_logits_cont / out_logits_bin [B,C] fp32 (coop.py:573-580)                          (optional)
+ *   out_logits_concept [Q,B,C] fp32 (coop.py:269-276)                                      (optional)
+ *   out_hash_features  [B,Q,D] fp32 raw last-layer concept-token states (coop.py:503-509) (optional)
+ *   out_image_features [B,P] fp32 pooled CLS -> post-LN -> visual_projection (coop.py:498-501) (optional)
+ * B must be in [1, max_batch]. */
+int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, float *out_codes,
+              uint64_t *out_packed, float *out_logits_cont, float *out_logits_bin, float *out_logits_concept,
+              float *out_hash_features, float *out_image_features, void *stream);
+
+/* Parity tap (tests only): run the encoder for `layer` layers (0 = embeddings + concept tokens + pre-LN) and copy the
+ * fp32 residual stream [B*N, D], N = 1 + patches + Q, to out_hidden.  Mirrors `image_hidden_states[layer]`
+ * (models/arch/coop.py:474-486). */
+int ch_encode_hidden(ch_model *m, const void *images, int32_t image_dtype, int32_t B, int32_t layer,
+                     float *out_hidden, void *stream);
+
+/* Algorithmic FLOPs of one image through ch_encode (SURVEY.md section 8d formula). */
+double ch_model_flops_per_image(const ch_model *m);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Retrieve  (replaces the un-vendored utils.hashing.{calculate_mAP, calculate_pr_curve, get_hamm_dist}; call sites
+ *            experiments/test_hashing.py:106-119,153-162, trainers/orthohash.py:362; definition: SURVEY.md 8c)
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* codes [rows,nbit] fp32 -> packed [rows,W] uint64; bit i = (codes[i] - threshold) > 0.  Replaces the sign() /
+ * threshold step of calculate_mAP (ternary_threshold = 0 at every reference call site). */
+int ch_pack_sign(const float *codes, int64_t rows, int32_t nbit, float threshold, uint64_t *out_packed, void *stream);
+
+/* Full distance matrix (small problems / get_hamm_dist semantics, trainers/orthohash.py:362; in-repo twin
+ * get_hd, trainers/orthohash.py:263-264): out[Qn,G] int32 = popcount(q xor g). */
+int ch_hamming_dist(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, int32_t *out,
+                    void *stream);
+
+/* Top-k by ascending (distance, gallery index).  g_index_base is added to the local gallery row number (gallery
+ * shards).  out_idx [Qn,k] int64 (global index, -1 when k > G), out_dist [Qn,k] int32 (-1 when k > G).
+ * 1 <= k <= 128, 1 <= W <= 4.  workspace: ch_hamming_topk_workspace() bytes. */
+size_t ch_hamming_topk_workspace(int64_t Qn, int64_t G, int32_t W, int32_t k);
+int ch_hamming_topk(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, int32_t k,
+                    int64_t g_index_base, int64_t *out_idx, int32_t *out_dist, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
+/* Merge nlists per-shard top-k lists ([nlists,Qn,k] each sorted ascending by (dist, idx); -1 entries = absent)
+ * into the global top-k [Qn,k]. */
+int ch_topk_merge(const int64_t *idx_lists, const int32_t *dist_lists, int32_t nlists, int64_t Qn, int32_t k,
+                  int64_t *out_idx, int32_t *out_dist, void *stream);
+
+/* Labels: single-label mode (LW == 0): int32 class id per row.  Multi-label mode (LW > 0): uint64[rows,LW] bitmasks;
+ * relevant <=> masks intersect. */
+
+/* mAP pass 1: per (gallery segment, query, distance bucket) counts.  The gallery is cut into nseg contiguous segments
+ * of seg_rows rows (last one shorter); out_hist [nseg, Qn, nb, 2] uint32 with nb = 64*W+1, [..,0] = #rows at that
+ * distance, [..,1] = #relevant rows.  seg_rows <= 65535. */
+int ch_hamming_hist(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                    const void *g_labels, int32_t LW, int32_t seg_rows, uint32_t *out_hist, void *stream);
+
+/* mAP pass 2: AP numerators in 2^-32 fixed point.  base [nseg,Qn,nb,2] uint32: for each (segment, query, bucket) the
+ * number of rows / relevant rows ranked before the segment's first row of that bucket (global prefix over lower
+ * buckets and over earlier segments -- and earlier gallery shards -- of the same bucket; built by
+ * ch_hamming_hist_prefix or by the multi-GPU host code).  rank_limit = R (rows ranked after R do not count; <= 0: no
+ * limit).  first_rel: NULL, or int32[Qn] = relevance (0/1) of each query's rank-1 row, which is then dropped before
+ * ranking (remove_first_retrieved, experiments/test_hashing.py:105-112).  Accumulates (atomic add) into out_S[Qn]
+ * uint64 and out_nrel[Qn] uint32 -- zero them first.  AP[q] = S[q] / (nrel[q] * 2^32). */
+int ch_hamming_ap(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                  const void *g_labels, int32_t LW, int32_t seg_rows, const uint32_t *base, int64_t rank_limit,
+                  const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, void *stream);
+
+/* Single-GPU helper: hist [nseg,Qn,nb,2] -> base (same shape) + totals[Qn,2] (rows, relevant rows overall). */
+int ch_hamming_hist_prefix(const uint32_t *hist, int32_t nseg, int64_t Qn, int32_t nb, uint32_t *out_base,
+                           uint32_t *out_totals, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONCEPTHASH_HIP_H */

@@ -1,0 +1,136 @@
+"""GPU parity: the HIP encoder (through the C-ABI) against (a) golden vectors produced by the reference's own model
+code and (b) the CPU oracle on seeded synthetic weights.
+
+Tolerances (bf16 GEMM operands, fp32 accumulation, fp32 residual stream; stated per comparison):
+  * vs the bf16-rounding-emulating oracle: what is left is accumulation order and exp/erf implementation;
+  * vs the fp32 oracle / reference golden: bf16 operand rounding through L layers.
+Errors are measured relative to the RMS of the compared tensor, and the measured value is printed.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a.double() - b.double()).abs().max() / b.double().pow(2).mean().sqrt().clamp_min(1e-12))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _encoder(sd, heads, **kw):
+    from concepthash_amd.encoder import ConceptHashEncoder
+    return ConceptHashEncoder(sd, heads=heads, **kw)
+
+
+def test_golden_reference_vectors(dev):
+    """tests/golden/encode_hd64.npz was produced by the reference's LGHWithFixedPrompt (oracle/gen_golden.py)."""
+    from oracle import encoder_oracle as eo
+    sd, z = load_fixture("encode_hd64")
+    heads = int(z["meta/heads"])
+    enc = _encoder(sd, heads, max_batch=4)
+    x = torch.from_numpy(z["in/images"]).to(dev)
+    out = enc.encode(x, want=("codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features",
+                              "image_features"))
+    torch.cuda.synchronize()
+    emu = eo.encode(sd, torch.from_numpy(z["in/images"]), heads=heads, emulate_bf16=True)
+    for key, tol_ref, tol_emu in (("codes", 2e-2, 5e-3), ("hash_features", 2e-2, 5e-3), ("logits_cont", 2e-2, 5e-3),
+                                  ("logits_bin", 3e-2, 1e-2), ("logits_concept", 2e-2, 5e-3),
+                                  ("image_features", 2e-2, 1e-2)):
+        got = out[key].cpu()
+        ref = torch.from_numpy(z["out/" + key])
+        e_ref = _rel_err(got, ref)
+        e_emu = _rel_err(got, emu[key]) if key in emu else float("nan")
+        print(f"{key}: rel err vs reference golden {e_ref:.2e}, vs bf16-emulating oracle {e_emu:.2e}")
+        assert got.shape == ref.shape
+        assert e_ref < tol_ref, key
+        if key in emu:
+            assert e_emu < tol_emu, key
+    # hidden-state taps: layer 0 (embeddings + concept tokens + pre-LN) is fp32 except the bf16 patch GEMM
+    h0 = enc.hidden_states(x, 0).cpu()
+    assert _rel_err(h0, torch.from_numpy(z["out/h0"])) < 1e-2
+    h1 = enc.hidden_states(x, 1).cpu()
+    assert _rel_err(h1, torch.from_numpy(z["out/h1"])) < 2e-2
+    hl = enc.hidden_states(x, 2).cpu()
+    assert _rel_err(hl, torch.from_numpy(z["out/h_last"])) < 2e-2
+    # packed bits == sign of the HIP codes, bit for bit (integer contract)
+    from oracle import hamming_oracle as ho
+    assert np.array_equal(out["packed"].cpu().numpy().view(np.uint64), ho.pack(out["codes"].cpu().numpy()))
+    # bits that differ from the fp32 reference are only those with |code| within the numeric error
+    refc = torch.from_numpy(z["out/codes"])
+    flips = (out["codes"].cpu() > 0) != (refc > 0)
+    assert bool((refc[flips].abs() < 2e-2 * refc.pow(2).mean().sqrt()).all())
+
+
+@pytest.mark.parametrize("cfg_name,L,batch,nbit,nclass", [("vit_s16", 2, 3, 16, 200), ("vit_b16", 12, 2, 64, 200),
+                                                         ("vit_b32", 3, 5, 64, 196), ("vit_l14", 2, 2, 128, 555)])
+def test_synthetic_configs_against_oracle(dev, cfg_name, L, batch, nbit, nclass):
+    """BASELINE.json configs (dims), seeded random weights, depth cut where the CPU oracle would be slow."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS[cfg_name])
+    cfg["L"] = L
+    sd = eo.synthetic_state_dict(cfg, nbit=nbit, nclass=nclass)
+    x = eo.synthetic_images(batch, cfg["image"])
+    enc = _encoder(sd, cfg["heads"], max_batch=4)
+    out = enc.encode(x.to(dev), want=("codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features"))
+    torch.cuda.synchronize()
+    ref = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False)
+    emu = eo.encode(sd, x, heads=cfg["heads"], emulate_bf16=True, with_pooled=False)
+    for key in ("codes", "hash_features", "logits_cont", "logits_concept"):
+        e_ref, e_emu = _rel_err(out[key].cpu(), ref[key]), _rel_err(out[key].cpu(), emu[key])
+        print(f"{cfg_name} {key}: rel err vs fp32 oracle {e_ref:.2e}, vs bf16-emulating oracle {e_emu:.2e}")
+        assert e_ref < 4e-2, key
+        assert e_emu < 1e-2, key
+    flips = (out["codes"].cpu() > 0) != (ref["codes"] > 0)
+    print(f"{cfg_name}: {int(flips.sum())} / {flips.numel()} bits differ from the fp32 oracle")
+    assert bool((ref["codes"][flips].abs() < 4e-2 * ref["codes"].pow(2).mean().sqrt()).all())
+    assert enc.flops_per_image > 0
+
+
+def test_batching_dtype_and_determinism(dev):
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_s16"])
+    cfg["L"] = 2
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    x = eo.synthetic_images(11, cfg["image"]).to(dev)
+    enc = _encoder(sd, cfg["heads"], max_batch=4)            # 11 images -> chunks 4,4,3
+    a = enc.encode(x)
+    b = enc.encode(x)
+    torch.cuda.synchronize()
+    assert torch.equal(a["codes"], b["codes"]) and torch.equal(a["packed"], b["packed"])     # run-to-run identical
+    one = torch.cat([enc.encode(x[i:i + 1])["codes"] for i in range(11)])
+    assert torch.equal(one, a["codes"])                      # an image's code does not depend on its batch-mates
+    xb = x.to(torch.bfloat16)
+    c = enc.encode(xb)
+    d = enc.encode(xb.float())                               # bf16 images == the same values given as fp32
+    assert torch.equal(c["codes"], d["codes"])
+    enc.close()
+
+
+def test_errors_are_loud(dev):
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_s16"])
+    cfg["L"] = 1
+    sd = eo.synthetic_state_dict(cfg, nbit=16, nclass=10)
+    enc = _encoder(sd, cfg["heads"], max_batch=2)
+    with pytest.raises(ValueError):
+        enc.encode(torch.zeros(1, 3, 64, 64, device=dev))
+    with pytest.raises(TypeError):
+        enc.encode(torch.zeros(1, 3, 224, 224, device=dev, dtype=torch.float16))
+    with pytest.raises(KeyError):
+        enc.encode(torch.zeros(1, 3, 224, 224, device=dev), want=("nope",))
+    bad = dict(sd)
+    del bad["hash_fc.weight"]
+    with pytest.raises((RuntimeError, KeyError)):
+        _encoder(bad, cfg["heads"])
+    bad = dict(sd)
+    bad["hash_bn.weight"] = torch.zeros(3)
+    with pytest.raises(RuntimeError, match="hash_bn.weight"):
+        _encoder(bad, cfg["heads"])
