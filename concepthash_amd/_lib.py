@@ -33,6 +33,8 @@ SIGNATURES = {
     "ch_model_destroy": (None, [c_void_p]),
     "ch_model_device_bytes": (c_size_t, [c_void_p]),
     "ch_model_flops_per_image": (c_double, [c_void_p]),
+    "ch_model_profile_begin": (c_int, [c_void_p, c_int32]),
+    "ch_model_profile_end": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "ch_encode": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p]),
     "ch_encode_hidden": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
@@ -48,6 +50,9 @@ SIGNATURES = {
                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_hamming_hist_prefix": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
 }
+
+CATEGORIES = ("im2col", "gemm_patch", "rowops", "gemm_qkv", "attention", "gemm_out", "gemm_down", "gemm_up", "gemm_fc1",
+              "gemm_fc2", "head", "end")
 
 _lib = None
 

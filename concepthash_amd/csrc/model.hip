@@ -39,6 +39,13 @@ struct ch_model {
     const float *hash_pe = nullptr, *hash_fc = nullptr, *bn_scale = nullptr, *bn_shift = nullptr;
     const float *center_l2 = nullptr, *center_bin = nullptr, *concept_pe = nullptr, *concept_cent_l2 = nullptr;
     const float *post_w = nullptr, *post_b = nullptr, *vis_proj = nullptr;
+    // launch profiler (bench.py): one hipEvent before every launch + one after the last; elapsed(e[j], e[j+1]) is
+    // attributed to launch j's category
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_cat;
+    std::vector<double> prof_flops;
+    size_t prof_n = 0;
     // workspace
     int64_t rows_alloc = 0, prow_alloc = 0;
     float *H = nullptr;
@@ -317,6 +324,15 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
     return 0;
 }
 
+// profiler mark: called immediately before a launch of category `cat` doing `flops` algorithmic FLOPs
+inline void mark(ch_model *m, int cat, double flops, hipStream_t s) {
+    if (!m->prof_on || m->prof_n + 1 >= m->prof_ev.size()) return;
+    (void)hipEventRecord(m->prof_ev[m->prof_n], s);
+    m->prof_cat[m->prof_n] = cat;
+    m->prof_flops[m->prof_n] = flops;
+    m->prof_n++;
+}
+
 // encoder up to `nlayers` layers; leaves the residual stream in m->H
 int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nlayers, hipStream_t s) {
     const ch_model_config &c = m->cfg;
@@ -324,7 +340,9 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
     const int rows = B * ntok;
     const int act_epi = c.act == 0 ? EPI_BIAS_QUICKGELU : EPI_BIAS_GELU;
 
+    mark(m, CH_CAT_IM2COL, 0.0, s);
     if (int e = ch_im2col(images, image_dtype, B, c.image_size, c.patch, m->Kp, m->PATCH, s)) return e;
+    mark(m, CH_CAT_GEMM_PATCH, 2.0 * B * np * (double)D * 3.0 * c.patch * c.patch, s);
     {
         GemmParams p{};
         p.X = m->PATCH; p.W = m->patch_w; p.M = B * np; p.N = D; p.K = m->Kp; p.X_rows_alloc = m->prow_alloc;
@@ -332,12 +350,15 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
         if (int e = ch_gemm_bf16(p, EPI_PATCH, s)) return e;
     }
     const LayerW &w0 = m->layers[0];
+    mark(m, CH_CAT_ROWOPS, 0.0, s);
     if (int e = ch_assemble_preln(m->H, B, ntok, np, D, m->cls_pos0, m->ctx, m->pre_w, m->pre_b, w0.ln1_w, w0.ln1_b,
                                   c.ln_eps, m->Xn, s))
         return e;
 
-    auto gemm = [&](const bf16_t *X, const bf16_t *W, int N, int K, const float *bias, int epi, bf16_t *out, int ldo,
-                    const float *scale) {
+    // cat / n_true / k_true: profiler category and the un-padded (algorithmic) GEMM extents
+    auto gemm = [&](int cat, int n_true, int k_true, const bf16_t *X, const bf16_t *W, int N, int K, const float *bias,
+                    int epi, bf16_t *out, int ldo, const float *scale) {
+        mark(m, cat, 2.0 * rows * (double)n_true * k_true, s);
         GemmParams p{};
         p.X = X; p.W = W; p.M = rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
         p.out_bf16 = out; p.ldo = ldo; p.resid = m->H; p.ldr = D; p.scale_ptr = scale;
@@ -346,23 +367,31 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
     auto adapter = [&](const AdapterW &aw) -> int {
         if (!aw.down_w) return 0;
         // Adapter (models/layers/adapter.py:46-60) on the bf16 copy of the sub-block output held in m->A
+        mark(m, CH_CAT_ROWOPS, 0.0, s);
         if (int e = ch_layernorm_bf16(m->A, rows, D, aw.ln_w, aw.ln_b, 1e-5f, m->Xn, s)) return e;
-        if (int e = gemm(m->Xn, aw.down_w, m->bpad, D, aw.down_b, EPI_BIAS_GELU, m->AD, m->bpad, nullptr)) return e;
-        return gemm(m->AD, aw.up_w, D, m->bpad, aw.up_b, EPI_SCALE_RESID, nullptr, 0, aw.scale);
+        if (int e = gemm(CH_CAT_GEMM_DOWN, c.adapter_dim, D, m->Xn, aw.down_w, m->bpad, D, aw.down_b, EPI_BIAS_GELU, m->AD,
+                         m->bpad, nullptr))
+            return e;
+        return gemm(CH_CAT_GEMM_UP, D, c.adapter_dim, m->AD, aw.up_w, D, m->bpad, aw.up_b, EPI_SCALE_RESID, nullptr, 0,
+                    aw.scale);
     };
 
     for (int i = 0; i < nlayers; ++i) {
         const LayerW &w = m->layers[i];
-        if (i > 0)
+        if (i > 0) {
+            mark(m, CH_CAT_ROWOPS, 0.0, s);
             if (int e = ch_layernorm_f32(m->H, rows, D, w.ln1_w, w.ln1_b, c.ln_eps, m->Xn, s)) return e;
-        if (int e = gemm(m->Xn, w.qkv_w, 3 * D, D, w.qkv_b, EPI_BIAS, m->QKV, 3 * D, nullptr)) return e;
+        }
+        if (int e = gemm(CH_CAT_GEMM_QKV, 3 * D, D, m->Xn, w.qkv_w, 3 * D, D, w.qkv_b, EPI_BIAS, m->QKV, 3 * D, nullptr)) return e;
+        mark(m, CH_CAT_ATTENTION, 4.0 * B * (double)ntok * ntok * D, s);
         if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s)) return e;
         // h = r + a  (+ adapter_1(a) below);  a kept as bf16 in m->A for the adapter branch
-        if (int e = gemm(m->AO, w.out_w, D, D, w.out_b, EPI_BIAS_RESID, m->A, D, nullptr)) return e;
+        if (int e = gemm(CH_CAT_GEMM_OUT, D, D, m->AO, w.out_w, D, D, w.out_b, EPI_BIAS_RESID, m->A, D, nullptr)) return e;
         if (int e = adapter(w.ad[0])) return e;
+        mark(m, CH_CAT_ROWOPS, 0.0, s);
         if (int e = ch_layernorm_f32(m->H, rows, D, w.ln2_w, w.ln2_b, c.ln_eps, m->Xn, s)) return e;
-        if (int e = gemm(m->Xn, w.fc1_w, M, D, w.fc1_b, act_epi, m->F1, M, nullptr)) return e;
-        if (int e = gemm(m->F1, w.fc2_w, D, M, w.fc2_b, EPI_BIAS_RESID, m->A, D, nullptr)) return e;
+        if (int e = gemm(CH_CAT_GEMM_FC1, M, D, m->Xn, w.fc1_w, M, D, w.fc1_b, act_epi, m->F1, M, nullptr)) return e;
+        if (int e = gemm(CH_CAT_GEMM_FC2, D, M, m->F1, w.fc2_w, D, M, w.fc2_b, EPI_BIAS_RESID, m->A, D, nullptr)) return e;
         if (int e = adapter(w.ad[1])) return e;
     }
     return 0;
@@ -418,6 +447,7 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
 
 extern "C" void ch_model_destroy(ch_model *m) {
     if (!m) return;
+    for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     for (void *p : m->allocs) (void)hipFree(p);
     delete m;
 }
@@ -453,7 +483,10 @@ extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, i
     p.out_codes = out_codes; p.out_packed = out_packed; p.out_logits_cont = out_logits_cont;
     p.out_logits_bin = out_logits_bin; p.out_logits_concept = out_logits_concept;
     p.out_hash_features = out_hash_features; p.out_image_features = out_image_features;
-    return ch_head(p, s);
+    mark(m, CH_CAT_HEAD, 2.0 * B * (double)c.dim * c.nbit, s);
+    if (int e = ch_head(p, s)) return e;
+    mark(m, CH_CAT_END, 0.0, s);
+    return 0;
 }
 
 extern "C" int ch_encode_hidden(ch_model *m, const void *images, int32_t image_dtype, int32_t B, int32_t layer,
@@ -473,4 +506,41 @@ extern "C" int ch_pack_sign(const float *codes, int64_t rows, int32_t nbit, floa
     CH_REQUIRE(rows >= 0 && nbit > 0, "pack_sign: rows must be >= 0 and nbit > 0");
     CH_REQUIRE(rows == 0 || (codes && out_packed), "pack_sign: null pointer");
     return ch_pack_sign_launch(codes, rows, nbit, threshold, out_packed, (hipStream_t)stream);
+}
+
+extern "C" int ch_model_profile_begin(ch_model *m, int32_t max_launches) {
+    CH_REQUIRE(m != nullptr && max_launches > 0, "profile_begin: null model or non-positive capacity");
+    while (m->prof_ev.size() < (size_t)max_launches + 1) {
+        hipEvent_t e;
+        CH_CHECK_HIP(hipEventCreate(&e));
+        m->prof_ev.push_back(e);
+    }
+    m->prof_cat.assign(m->prof_ev.size(), CH_CAT_END);
+    m->prof_flops.assign(m->prof_ev.size(), 0.0);
+    m->prof_n = 0;
+    m->prof_on = true;
+    return 0;
+}
+
+extern "C" int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *launches_per_cat, double *flops_per_cat) {
+    CH_REQUIRE(m != nullptr && ms_per_cat && launches_per_cat && flops_per_cat, "profile_end: null pointer");
+    m->prof_on = false;
+    for (int i = 0; i < CH_NCAT; ++i) {
+        ms_per_cat[i] = 0.0;
+        launches_per_cat[i] = 0;
+        flops_per_cat[i] = 0.0;
+    }
+    if (m->prof_n < 2) return 0;
+    CH_CHECK_HIP(hipEventSynchronize(m->prof_ev[m->prof_n - 1]));
+    for (size_t j = 0; j + 1 < m->prof_n; ++j) {
+        const int cat = m->prof_cat[j];
+        if (cat == CH_CAT_END) continue;  // gap between two ch_encode calls
+        float ms = 0.f;
+        CH_CHECK_HIP(hipEventElapsedTime(&ms, m->prof_ev[j], m->prof_ev[j + 1]));
+        ms_per_cat[cat] += ms;
+        launches_per_cat[cat] += 1;
+        flops_per_cat[cat] += m->prof_flops[j];
+    }
+    m->prof_n = 0;
+    return 0;
 }

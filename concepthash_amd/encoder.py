@@ -101,6 +101,24 @@ class ConceptHashEncoder:
     def flops_per_image(self) -> float:
         return float(self.lib.ch_model_flops_per_image(self._h))
 
+    # -- launch profiler (bench.py roofline) ------------------------------------------------------------------------
+    def profile_begin(self, max_launches: int) -> None:
+        _lib.check(self.lib.ch_model_profile_begin(self._h, int(max_launches)), "ch_model_profile_begin")
+
+    def profile_end(self) -> Dict[str, dict]:
+        n = len(_lib.CATEGORIES)
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_int64 * n)()
+        fl = (ctypes.c_double * n)()
+        _lib.check(self.lib.ch_model_profile_end(self._h, ms, cnt, fl), "ch_model_profile_end")
+        return {name: dict(ms=ms[i], launches=int(cnt[i]), flops=fl[i]) for i, name in enumerate(_lib.CATEGORIES)
+                if name != "end"}
+
+    @property
+    def launches_per_encode(self) -> int:
+        L, ad = self.cfg["layers"], 1 if self.cfg["adapter_dim"] > 0 else 0
+        return 3 + L * (7 + 6 * ad) + 2
+
     # -- encode ---------------------------------------------------------------------------------------------------
     def _check_images(self, images: torch.Tensor):
         s = self.cfg["image_size"]

@@ -94,6 +94,17 @@ int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, f
 int ch_encode_hidden(ch_model *m, const void *images, int32_t image_dtype, int32_t B, int32_t layer,
                      float *out_hidden, void *stream);
 
+/* Launch profiler for bench.py's roofline: between begin and end every kernel launch of ch_encode is bracketed by
+ * HIP events on the caller's stream (capacity max_launches events; launches beyond it are not recorded).
+ * ch_model_profile_end waits for the last recorded event and returns, per category, the summed launch durations
+ * (ms), the number of launches and their algorithmic FLOPs. */
+enum {
+    CH_CAT_IM2COL = 0, CH_CAT_GEMM_PATCH, CH_CAT_ROWOPS, CH_CAT_GEMM_QKV, CH_CAT_ATTENTION, CH_CAT_GEMM_OUT,
+    CH_CAT_GEMM_DOWN, CH_CAT_GEMM_UP, CH_CAT_GEMM_FC1, CH_CAT_GEMM_FC2, CH_CAT_HEAD, CH_CAT_END, CH_NCAT
+};
+int ch_model_profile_begin(ch_model *m, int32_t max_launches);
+int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *launches_per_cat, double *flops_per_cat);
+
 /* Algorithmic FLOPs of one image through ch_encode (SURVEY.md section 8d formula). */
 double ch_model_flops_per_image(const ch_model *m);
 
