@@ -1,0 +1,86 @@
+"""`models.loss.coop.LGHLoss` for the evaluation meters only.
+
+The reference's trainer calls the criterion during inference to fill the loss/accuracy meters
+(trainers/coop.py:80-88 -> models/loss/coop.py:120-189).  This restates the terms the shipped config enables
+(`bin_logits`, `cont_logits`, `concept_logits`: margin-cosine cross-entropy with `scale`/`margin`; plus the `quan`
+diagnostic) on the small (B, C) logits the HIP head produces.  It is bookkeeping on a few KB per batch -- not part of the
+encode or retrieve arithmetic -- and it is not a training objective here (no autograd use).  `hash_logits` (mixture of
+softmaxes) is included for completeness; `attn_div_loss` needs attention maps, which the fused path never materialises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class LGHLoss(nn.Module):
+    def __init__(self, scale=1, margin=0, loss_scales=None, avg_before_softmax=False, lmbd=0.5, ncontext=8,
+                 exponential_scale=0, div_method=0, concept_cossim=True, **kwargs):
+        super().__init__()
+        self.scale, self.margin, self.lmbd = scale, margin, lmbd
+        self.loss_scales = dict(loss_scales) if loss_scales is not None else {
+            "logits": 1, "hash_logits": 1, "bin_logits": 1, "cont_logits": 1, "concept_logits": 0, "attn_div_loss": 0}
+        if self.loss_scales.get("attn_div_loss", 0):
+            raise NotImplementedError("attn_div_loss needs attention maps, which the fused MI355X path does not emit")
+        if exponential_scale:
+            raise NotImplementedError("exponential_scale != 0 is not built")
+        self.avg_before_softmax, self.ncontext, self.concept_cossim = avg_before_softmax, ncontext, concept_cossim
+        self.losses = {}
+
+    def _margin_logits(self, logits, labels):
+        """cosine-margin logits: scale * (logits - margin * onehot)  (reference :46-66)"""
+        if labels.dim() == 2:       # soft / multi-hot labels
+            onehot = labels.to(logits.dtype)
+            target = onehot / onehot.sum(-1, keepdim=True)
+        else:
+            onehot = F.one_hot(labels, logits.shape[-1]).to(logits.dtype)
+            target = labels
+        if logits.dim() == 3:
+            onehot = onehot.unsqueeze(0)
+        return self.scale * (logits - self.margin * onehot), target
+
+    def _ce(self, logits, labels, cossim=True):
+        if cossim:
+            logits, labels = self._margin_logits(logits, labels)
+        elif labels.dim() == 2:
+            labels = labels / labels.sum(-1, keepdim=True)
+        if logits.dim() == 3:       # (Q, B, C): every concept classifies the same labels (reference :74-85)
+            Q = logits.shape[0]
+            flat = logits.reshape(Q * logits.shape[1], -1)
+            rep = labels.unsqueeze(0).expand(Q, *labels.shape).reshape(-1, *labels.shape[1:])
+            return F.cross_entropy(flat, rep)
+        return F.cross_entropy(logits, labels)
+
+    def _hash_loss(self, l1, l2, labels):
+        if self.avg_before_softmax:
+            return self._ce(self.lmbd * l1 + (1 - self.lmbd) * l2, labels)
+        l1, _ = self._margin_logits(l1, labels)
+        l2, target = self._margin_logits(l2, labels)
+        if target.dim() == 1:
+            target = F.one_hot(target, l1.shape[-1]).to(l1.dtype)
+        prob = self.lmbd * torch.softmax(l1, -1) + (1 - self.lmbd) * torch.softmax(l2, -1)
+        return -(target * torch.log(prob.clamp(min=1e-7))).sum(-1).mean()
+
+    @torch.no_grad()
+    def forward(self, outputs, labels):
+        codes = outputs["codes"]
+        self.losses["quan"] = 1 - F.cosine_similarity(codes, codes.sign(), dim=-1).mean()
+        total = torch.zeros((), device=codes.device)
+        ls = self.loss_scales
+        if ls.get("logits", 0) and "logits" in outputs:
+            self.losses["aux"] = self._ce(outputs["logits"], labels)
+            total = total + ls["logits"] * self.losses["aux"]
+        if ls.get("concept_logits", 0):
+            self.losses["concept"] = self._ce(outputs["logits_concept"], labels, cossim=self.concept_cossim)
+            total = total + ls["concept_logits"] * self.losses["concept"]
+        if ls.get("hash_logits", 0):
+            self.losses["hash"] = self._hash_loss(outputs["logits_cont"], outputs["logits_bin"], labels)
+            total = total + ls["hash_logits"] * self.losses["hash"]
+        if ls.get("cont_logits", 0):
+            self.losses["cont"] = self._ce(outputs["logits_cont"], labels)
+            total = total + ls["cont_logits"] * self.losses["cont"]
+        if ls.get("bin_logits", 0):
+            self.losses["bin"] = self._ce(outputs["logits_bin"], labels)
+            total = total + ls["bin_logits"] * self.losses["bin"]
+        return total

@@ -1,0 +1,74 @@
+"""CPU, world_size 2 (gloo): the multi-GPU retrieval choreography of concepthash_amd/distributed.py -- ragged gallery
+shards, all_gather of queries / lists / histograms, global prefix bases, integer all_reduce -- must reproduce the
+single-process oracle bit for bit.  Per-shard arithmetic is the numpy/C stand-in of tests/cpu_ops.py; on GPUs the same
+class runs with the HIP kernels (tests/test_hamming_gpu.py covers those, incl. the shard+merge data path on one GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, bounds, remove_first, R, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_ops
+        from concepthash_amd.distributed import ShardedRetrieval
+        from oracle import hamming_oracle as ho
+        q, ql = ho.synthetic_codes(61, 64, seed=5, nclass=6)
+        g, gl = ho.synthetic_codes(bounds[-1], 64, seed=6, nclass=6)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64) if a.dtype == np.uint64 else a)
+        sr = ShardedRetrieval(tt(g[lo:hi]), tt(gl[lo:hi]), ops=cpu_ops)
+        assert sr.base == lo and sr.total == bounds[-1]
+        # queries "encoded" on different ranks, unequal counts
+        qb = [0, 20, 61] if world == 2 else [0, 61]
+        q_all = sr.gather_queries(tt(q[qb[rank]:qb[rank + 1]]))
+        assert torch.equal(q_all, tt(q))
+        idx, dst = sr.topk(q_all, 12)
+        ev = sr.evaluate(q_all, tt(ql), R=R, ks=(1, 5, 10), remove_first=remove_first, seg_rows=97)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=idx.numpy(), dst=dst.numpy(), S=ev["S"].numpy(),
+                 nrel=ev["nrel"].numpy(), hits=ev["hits"].numpy(), total=ev["total"].numpy(), mAP=ev["mAP"],
+                 P=np.array(ev["precisions"]), Rc=np.array(ev["recalls"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bounds,remove_first,R", [([0, 300, 700], False, -1), ([0, 1, 450], True, 40), ([0, 0, 333], False, -1)])
+def test_two_rank_sharded_retrieval_matches_oracle(tmp_path, bounds, remove_first, R):
+    from oracle import hamming_oracle as ho
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, bounds, remove_first, R, str(tmp_path)), nprocs=2, join=True)
+    q, ql = ho.synthetic_codes(61, 64, seed=5, nclass=6)
+    g, gl = ho.synthetic_codes(bounds[-1], 64, seed=6, nclass=6)
+    ridx, rdst = ho.topk(q, g, 12)
+    ref = ho.mean_ap(q, g, ql, gl, R=R, ks=(1, 5, 10), remove_first=remove_first)
+    for r in range(2):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["idx"], ridx.astype(np.int64)) and np.array_equal(z["dst"], rdst)
+        assert np.array_equal(z["S"].view(np.uint64), ref["S"])
+        assert np.array_equal(z["nrel"].astype(np.uint32), ref["nrel"])
+        assert np.array_equal(z["hits"].astype(np.uint32), ref["hits"])
+        assert np.array_equal(z["total"].astype(np.uint32), ref["total"])
+        assert abs(float(z["mAP"]) - ref["mAP"]) < 1e-12
+        assert np.allclose(z["P"], ref["precisions"]) and np.allclose(z["Rc"], ref["recalls"])
+
+
+def test_shard_bounds():
+    from concepthash_amd.distributed import shard_bounds
+    assert shard_bounds(10, 3) == [0, 4, 7, 10]
+    assert shard_bounds(2, 4) == [0, 1, 2, 2, 2]
+    assert shard_bounds(0, 2) == [0, 0, 0]

@@ -1,0 +1,103 @@
+"""`trainers.base.BaseTrainer` -- the trainer protocol the evaluator drives (reference trainers/base.py:17-71,128-131,
+195-197,275-307), inference side only.
+
+Kept: method names, argument meaning, return shapes -- `inference_one_epoch(datakey, return_codes=True) ->
+(meters, {'codes': FloatTensor[N, nbit] on CPU, 'labels': Tensor[N, C]})`.
+Changed on purpose: per-batch outputs stay on the GPU and are copied to the host once per epoch (the reference does a
+synchronising `.cpu()` per batch, trainers/base.py:291-296).  Training entry points raise: out of scope.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+import yaml
+
+from concepthash_amd.config import DictConfig, instantiate, to_container
+from utils.misc import AverageMeter
+
+
+class BaseTrainer:
+    def __init__(self, config: DictConfig):
+        self.config = config
+        self.dataset = None
+        self.dataloader = None
+        self.model = None
+        self.optimizer = None
+        self.scheduler = None
+        self.criterion = None
+        self.current_epoch = 0
+        self.inference_datakey = ""
+        self.device = torch.device(config["device"])
+
+    # ---- loading -------------------------------------------------------------------------------------------------
+    def load_criterion(self):
+        self.criterion = instantiate(self.config.criterion)
+
+    def load_model(self):
+        self.model = instantiate(self.config.model)
+
+    def load_for_inference(self, logdir):
+        pass
+
+    def load_model_state(self, fn):
+        sd = torch.load(fn, map_location="cpu")
+        self.model.load_state_dict(sd)
+
+    def save_model_state(self, fn):
+        os.makedirs(os.path.dirname(fn) or ".", exist_ok=True)
+        torch.save(self.model.state_dict(), fn)
+
+    def save_config(self, logdir):
+        os.makedirs(logdir, exist_ok=True)
+        with open(os.path.join(logdir, "config.yaml"), "w") as f:
+            yaml.safe_dump(to_container(self.config), f)
+
+    def to_device(self, device=None):
+        device = self.device if device is None else device
+        if self.model is not None:
+            self.model = self.model.to(device)
+        if self.criterion is not None:
+            self.criterion = self.criterion.to(device)
+
+    def is_ready_for_inference(self):
+        return all(x is not None for x in (self.dataset, self.dataloader, self.model, self.criterion))
+
+    # ---- inference -----------------------------------------------------------------------------------------------
+    def inference_one_batch(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def inference_one_epoch(self, datakey="test", return_codes=False, **kwargs):
+        assert self.is_ready_for_inference()
+        self.model.eval()
+        self.criterion.eval()
+        meters = defaultdict(AverageMeter)
+        ret = defaultdict(list)
+        self.inference_datakey = datakey
+        loader = self.dataloader[datakey]
+        n = len(loader) if hasattr(loader, "__len__") else 0
+        for i, data in enumerate(loader):
+            output = self.inference_one_batch(data, meters, bidx=i, **kwargs)
+            if return_codes:
+                for key, val in output.items():
+                    ret[key].append(val)          # GPU tensors stay on the GPU until the epoch ends
+            if n and (i + 1) % max(1, n // 10) == 0:
+                logging.info("%s: batch %d/%d %s", datakey, i + 1, n, {k: round(v.avg, 4) for k, v in meters.items()})
+        if not return_codes:
+            return meters
+        res = {}
+        for key, vals in ret.items():
+            if isinstance(vals[0], torch.Tensor):
+                res[key] = torch.cat(vals).cpu()  # one device->host copy per output per epoch
+            else:
+                res[key] = np.concatenate(vals)
+        return meters, res
+
+    # ---- training: out of scope ----------------------------------------------------------------------------------
+    def train_one_epoch(self, *a, **k):
+        raise NotImplementedError("training is outside the MI355X encode-and-retrieve path (DESIGN.md section 8)")
+
+    load_optimizer_and_scheduler = train_one_batch = train_one_epoch

@@ -1,0 +1,59 @@
+"""`trainers.coop.COOPTrainer` -- the ConceptHash trainer's inference side (reference trainers/coop.py:13-106)."""
+from __future__ import annotations
+
+import logging
+import os
+
+import torch
+
+import engine
+from concepthash_amd.config import DictConfig, instantiate
+from trainers.base import BaseTrainer
+
+
+class COOPTrainer(BaseTrainer):
+    def __init__(self, config: DictConfig):
+        super().__init__(config)
+        os.environ["TOKENIZERS_PARALLELISM"] = "false"
+
+    def load_dataset(self, load_db=True):
+        ds = self.config.dataset
+        self.dataset = {"train": instantiate(ds.train_dataset) if ds.get("train_dataset") is not None else [],
+                        "test": instantiate(ds.test_dataset),
+                        "db": instantiate(ds.db_dataset) if load_db else []}
+        logging.info("Number of Query data: %d; Database data: %d", len(self.dataset["test"]), len(self.dataset["db"]))
+
+    def load_dataloader(self):
+        assert self.dataset is not None
+        bs = self.config.batch_size
+        self.dataloader = {k: engine.dataloader(self.dataset[k], bs, shuffle=False, drop_last=False) for k in ("test", "db")}
+        self.dataloader["train"] = []
+
+    def parse_model_output(self, output):
+        codes, logits = output
+        return logits if isinstance(logits, dict) else {"codes": codes, "logits": logits}
+
+    def compute_features_one_batch(self, data):
+        image, labels, index = data
+        image = image.to(self.device, non_blocking=True)
+        labels = labels.to(self.device, non_blocking=True)
+        output = self.model(image, labels) if self.config.model.get("pass_labels") else self.model(image)
+        return (image, labels, index), self.parse_model_output(output)
+
+    def inference_one_batch(self, *args, **kwargs):
+        data, meters = args
+        with torch.no_grad():
+            (image, labels, index), output = self.compute_features_one_batch(data)
+            n = image.size(0)
+            target = labels if self.config.dataset.get("multiclass") else labels.argmax(1)
+            loss = self.criterion(output, target)
+            meters["loss"].update(loss.item(), n)
+            for key, val in self.criterion.losses.items():
+                meters[key].update(val.item(), n)
+            for key, val in output.items():      # accuracy per logits tensor, named as the reference names them (:90-101)
+                if "logits" in key and torch.is_tensor(val):
+                    pred = val.mean(dim=0).argmax(1) if val.dim() == 3 else val.argmax(1)
+                    parts = key.split("_")
+                    meters["acc" if len(parts) == 1 else f"acc_{parts[1]}"].update(
+                        (pred == labels.argmax(1)).float().mean().item(), n)
+        return {"codes": output["codes"], "labels": labels}

@@ -1,0 +1,100 @@
+"""`utils.datasets` (un-vendored in the reference; call sites configs/dataset/cub200.yaml:10-70): list-file image
+datasets with one-hot targets, plus a synthetic variant for machines without the images (there are none in the
+reference snapshot)."""
+from __future__ import annotations
+
+import os
+
+import torch
+from torch.utils.data import Dataset
+
+
+class OneHot:
+    def __init__(self, nclass: int):
+        self.nclass = int(nclass)
+
+    def __call__(self, label):
+        t = torch.zeros(self.nclass)
+        t[int(label)] = 1.0
+        return t
+
+
+def read_list(path: str):
+    """`<relative/path.jpg> <label>` per line."""
+    items = []
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if line:
+                p, _, lab = line.rpartition(" ")
+                items.append((p, int(lab)))
+    return items
+
+
+class HashingDataset(Dataset):
+    """Returns (image, target, index), as the trainers unpack it (trainers/coop.py:62)."""
+
+    def __init__(self, root, filename="train.txt", transform=None, target_transform=None, num_classes=None, num_shots=0,
+                 separate_multiclass=False, **kwargs):
+        from utils.transforms import Compose
+        self.root = root
+        self.items = read_list(os.path.join(root, filename))
+        if num_shots:
+            per, keep = {}, []
+            for it in self.items:
+                if per.setdefault(it[1], 0) < num_shots:
+                    per[it[1]] += 1
+                    keep.append(it)
+            self.items = keep
+        self.transform = Compose(transform) if isinstance(transform, (list, tuple)) else transform
+        self.target_transform = target_transform
+
+    def __len__(self):
+        return len(self.items)
+
+    def _resolve(self, rel):
+        for cand in (rel, os.path.join(self.root, rel), os.path.join(os.path.dirname(os.path.dirname(self.root)), rel)):
+            if os.path.exists(cand):
+                return cand
+        raise FileNotFoundError(f"image '{rel}' not found (list root {self.root}); use dataset=synthetic_* without images")
+
+    def __getitem__(self, index):
+        from PIL import Image
+        rel, lab = self.items[index]
+        img = Image.open(self._resolve(rel)).convert("RGB")
+        if self.transform is not None:
+            img = self.transform(img)
+        target = self.target_transform(lab) if self.target_transform is not None else lab
+        return img, target, index
+
+
+class SyntheticHashingDataset(Dataset):
+    """Seeded N(0,1) 'post-normalisation' images with the label vector of a real list file (or uniform labels):
+    exercises the whole encode-and-retrieve path where the images themselves are unavailable."""
+    in_memory = True
+
+    def __init__(self, nclass, size=0, root=None, filename=None, image_size=224, seed=0, dtype="float32", limit=0, **kwargs):
+        self.nclass = int(nclass)
+        if root is not None and filename is not None and os.path.exists(os.path.join(root, filename)):
+            labels = torch.tensor([lab for _, lab in read_list(os.path.join(root, filename))], dtype=torch.int64)
+        else:
+            g = torch.Generator().manual_seed(seed + 17)
+            labels = torch.randint(0, self.nclass, (int(size),), generator=g)
+        if limit:
+            labels = labels[:: max(1, len(labels) // int(limit))][: int(limit)]
+        self.labels = labels
+        self.image_size, self.seed = int(image_size), int(seed)
+        self.dtype = getattr(torch, dtype)
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, index):
+        g = torch.Generator().manual_seed(self.seed * 1_000_003 + index)
+        # class-dependent mean so that the codes carry some label signal even with random weights
+        lab = int(self.labels[index])
+        img = torch.randn(3, self.image_size, self.image_size, generator=g)
+        img += 0.5 * torch.sin(torch.arange(3).view(3, 1, 1) * 1.7 + lab * 0.37)
+        target = torch.zeros(self.nclass)
+        target[lab] = 1.0
+        return img.to(self.dtype), target, index

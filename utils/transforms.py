@@ -1,0 +1,78 @@
+"""`utils.transforms` (un-vendored in the reference; call sites configs/dataset/cub200.yaml:10-47) plus the four
+torchvision eval transforms those configs name -- torchvision is not installed in the target image, so
+`concepthash_amd.config.locate` maps `torchvision.transforms.{Resize, CenterCrop, ToTensor, Compose}` here.
+
+`normalize_transform(norm)`: the reference's constants live in the missing module; `norm=3` is what the ConceptHash
+config selects (configs/model/concept_hash_final_v1_nosa_apt.yaml:72-73) and is taken to be the CLIP statistics
+(unpinned); `norm=2` ImageNet, `norm=1` 0.5/0.5, `norm=0` identity."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from PIL import Image
+
+_NORMS = {
+    0: ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)),
+    1: ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)),
+    2: ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)),
+    3: ((0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)),
+}
+
+
+def interpolation(name: str):
+    return {"nearest": Image.NEAREST, "bilinear": Image.BILINEAR, "bicubic": Image.BICUBIC, "lanczos": Image.LANCZOS}[name]
+
+
+class Normalize:
+    def __init__(self, mean, std):
+        self.mean = torch.tensor(mean).view(3, 1, 1)
+        self.std = torch.tensor(std).view(3, 1, 1)
+
+    def __call__(self, x):
+        return (x - self.mean) / self.std
+
+
+def normalize_transform(norm: int):
+    return Normalize(*_NORMS[int(norm)])
+
+
+class Resize:
+    def __init__(self, size, interpolation=Image.BILINEAR):
+        self.size, self.interp = size, interpolation
+
+    def __call__(self, img):
+        if isinstance(self.size, int):          # shorter side -> size, aspect kept (torchvision semantics)
+            w, h = img.size
+            if w <= h:
+                nw, nh = self.size, max(1, int(round(h * self.size / w)))
+            else:
+                nw, nh = max(1, int(round(w * self.size / h))), self.size
+            return img.resize((nw, nh), self.interp)
+        return img.resize((self.size[1], self.size[0]), self.interp)
+
+
+class CenterCrop:
+    def __init__(self, size):
+        self.size = (size, size) if isinstance(size, int) else tuple(size)
+
+    def __call__(self, img):
+        w, h = img.size
+        th, tw = self.size
+        left, top = int(round((w - tw) / 2.0)), int(round((h - th) / 2.0))
+        return img.crop((left, top, left + tw, top + th))
+
+
+class ToTensor:
+    def __call__(self, img):
+        a = np.asarray(img.convert("RGB"), dtype=np.uint8)
+        return torch.from_numpy(a).permute(2, 0, 1).float().div_(255.0)
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
