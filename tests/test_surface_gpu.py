@@ -113,4 +113,6 @@ def test_main_v2_validation_end_to_end(tmp_path):
     assert abs(h2["mAP"][1] - ho.mean_ap(q, q, ql, ql, R=-1, remove_first=True)["mAP"]) < 1e-12
 
     h3, _ = run(["compute_mAP=False"], "ev3")
-    assert h3["Rs"][-1] == 96 and len(h3["recalls"]) == len(h3["Rs"]) and abs(h3["recalls"][-1] - 1.0) < 1e-12
+    has_rel = float(np.mean([(gl == c).any() for c in ql]))          # recall@G is 1 for queries with >= 1 relevant row, else 0
+    assert h3["Rs"][-1] == 96 and len(h3["recalls"]) == len(h3["Rs"]) and abs(h3["recalls"][-1] - has_rel) < 1e-12
+    assert abs(h3["precisions"][0] - ref["precisions"][0]) < 1e-12   # P@1 of the curve == P@1 of the mAP run
