@@ -174,7 +174,7 @@ int launch(const GemmParams &p, hipStream_t s) {
 
 }  // namespace
 
-int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
+int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s) {
     CH_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem");
     CH_REQUIRE(epi == EPI_PATCH || p.bias != nullptr, "gemm: bias is required");
     CH_REQUIRE(p.N % BN == 0, "gemm: N must be a multiple of 128");
@@ -190,4 +190,13 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
     }
     ch_set_error("gemm: unknown epilogue");
     return 2;
+}
+
+// ---- dispatcher: the 256x256 ping-pong kernel when the shape allows it, this file's 128x128 kernel otherwise ---------
+static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128 two-phase), 2 force pp (256x256 ping-pong)
+void ch_gemm_set_variant(int v) { g_gemm_variant = v; }
+int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
+    if (g_gemm_variant == 1) return ch_gemm_bf16_v1(p, epi, s);
+    if (g_gemm_variant == 2) return ch_gemm_bf16_pp(p, epi, s);
+    return ch_gemm_pp_supported(p) ? ch_gemm_bf16_pp(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
 }

@@ -1,0 +1,315 @@
+// bf16 MFMA GEMM, 256x256x64 block tile, 8 waves, ping-pong ("8-phase") schedule for gfx950.
+//
+//   C[m][n] = sum_k X[m][k] * W[n][k]      (same contract and fused epilogues as gemm_bf16.hip; see kernels.h)
+//
+// Structure (after the 256^2 8-phase template of the CDNA4 guide):
+//   * 8 waves = 2 (M) x 4 (N); a wave owns a 128(M) x 64(N) sub-tile: acc[4 n-tiles][8 m-tiles] of
+//     v_mfma_f32_16x16x32_bf16 (weights are the MFMA A operand, activations the B operand -> a lane holds 4 contiguous n).
+//   * a K-tile (64 deep) is staged as FOUR half-tiles of 128 rows x 128 B (16 KB, two global_load_lds_dwordx4 per wave):
+//       X_h0 / X_h1 = the first / second 64 rows of every wave-row's 128 M-rows, W_h0 / W_h1 = the first / second 32 rows of
+//       every wave-column's 64 N-rows -- i.e. split by which QUADRANT phase consumes them, not by position in the tile.
+//     Two K-tile buffers (even/odd), 128 KB of LDS; rows are XOR-swizzled on the 16-B chunk index with (row & 7), applied
+//     on the per-lane global source address (the LDS-DMA image is lane-linear) and on the ds_read_b128 address.
+//   * per K-tile four phases, 16 MFMAs each (one 64x32 quadrant of the wave's tile over the whole K-tile):
+//       P1 reads W_h0 (4 x b128) + X_h0 (8 x b128) -> Q(m0,n0);  P2 reads W_h1 (4) -> Q(m0,n1);
+//       P3 reads X_h1 (8) -> Q(m1,n1);                          P4 reads nothing -> Q(m1,n0) (W_h0 fragments kept).
+//     every phase also issues ONE half-tile of prefetch; loads are retired only by a counted `s_waitcnt vmcnt(6)` at
+//     phases 4 and 8 (three half-tiles stay in flight across all barriers; never vmcnt(0) in the steady state).
+//   * each phase is {LDS reads + prefetch issue + waits} s_barrier {16 MFMA} s_barrier; waves 4-7 run one barrier behind
+//     waves 0-3, so on every SIMD one wave is in its MFMA segment while its partner is in its memory segment.
+//   Buffer-reuse distances (proved in DESIGN.md section 3): a half-tile is re-staged no earlier than the phase after its
+//   last LDS read -- and that read is complete (lgkmcnt(0)) before the reading wave's barrier; a half-tile is first read
+//   one phase after the vmcnt/barrier that retires it.
+// K must be a multiple of 128 (an even number of K-tiles), N a multiple of 256, X padded to a multiple of 256 rows.
+#include "ch_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;       // 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES;      // 64 KiB: [X_h0][X_h1][W_h0][W_h1]
+constexpr int NTHREADS = 512;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+#define PP_BARRIER()                       \
+    do {                                   \
+        __builtin_amdgcn_sched_barrier(0); \
+        __builtin_amdgcn_s_barrier();      \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+#define PP_WAIT_LGKM0()                                       \
+    do {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                    \
+    } while (0)
+#define PP_WAIT_VM(n)                                         \
+    do {                                                      \
+        asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                    \
+    } while (0)
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;  // wr also selects the stagger group (waves 4-7 run one barrier behind)
+
+    const int tiles_n = p.N / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- prefetch addressing.  A half-tile = 16 wave-instructions of 8 local rows; wave w issues instructions 2w, 2w+1:
+    // lane l -> local row lr = 16w + 8j + (l>>3), LDS chunk (l&7) <- source chunk (l&7)^(lr&7) = (l&7)^(l>>3).
+    // local row -> tile row:  X_h{h}: lr = r*64 + i  ->  m = r*128 + h*64 + i      (r = lr >> 6, i = lr & 63)
+    //                         W_h{h}: lr = c*32 + i  ->  n = c*64  + h*32 + i      (c = lr >> 5, i = lr & 31)
+    const int src_chunk = (lane & 7) ^ (lane >> 3);
+    uint32_t xoff[2][2], woff[2][2];  // [half][instr j] byte offsets from p.X / p.W (k-tile 0)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lr = wid * 16 + j * 8 + (lane >> 3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int xm = (lr >> 6) * 128 + h * 64 + (lr & 63);
+            const int wn = (lr >> 5) * 64 + h * 32 + (lr & 31);
+            xoff[h][j] = (uint32_t)(((size_t)(m0 + xm) * p.K + src_chunk * 8) * 2);
+            woff[h][j] = (uint32_t)(((size_t)(n0 + wn) * p.K + src_chunk * 8) * 2);
+        }
+    }
+    const char *Xb = (const char *)p.X;
+    const char *Wb = (const char *)p.W;
+    // which: 0 X_h0, 1 X_h1, 2 W_h0, 3 W_h1 ; kt = K-tile index ; buf = kt & 1
+    auto issue = [&](int which, int kt) {
+        char *dst = smem + (kt & 1) * BUF_BYTES + which * HALF_BYTES + wid * 2048;
+        const uint32_t kb = (uint32_t)kt * (BK * 2);
+        const char *base = which < 2 ? Xb : Wb;
+        const uint32_t o0 = which == 0 ? xoff[0][0] : which == 1 ? xoff[1][0] : which == 2 ? woff[0][0] : woff[1][0];
+        const uint32_t o1 = which == 0 ? xoff[0][1] : which == 1 ? xoff[1][1] : which == 2 ? woff[0][1] : woff[1][1];
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(base + (o0 + kb)), (lds_void_t *)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t *)(base + (o1 + kb)), (lds_void_t *)(dst + 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addressing (bytes inside a half-tile): row = base_row + t*16 + (lane&15); (row&7) == (lane&7)
+    const int fr = lane & 15, fq = lane >> 4;
+    const int sw0 = ((fq ^ (lane & 7)) << 4);         // kk = 0 chunk, swizzled
+    const int sw1 = (((4 + fq) ^ (lane & 7)) << 4);   // kk = 1
+    const int xrow = (wr * 64 + fr) * 128;            // + mt*2048
+    const int wrow = (wc * 32 + fr) * 128;            // + nt*2048
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 Wa[2][2], Wbf[2][2], Xf[4][2];  // [tile][kk]
+
+    auto read_w = [&](bf16x8 (&dst)[2][2], int buf, int h) {
+        const char *b = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES + wrow;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            dst[nt][0] = *(const bf16x8 *)(b + nt * 2048 + sw0);
+            dst[nt][1] = *(const bf16x8 *)(b + nt * 2048 + sw1);
+        }
+    };
+    auto read_x = [&](int buf, int h) {
+        const char *b = smem + buf * BUF_BYTES + h * HALF_BYTES + xrow;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            Xf[mt][0] = *(const bf16x8 *)(b + mt * 2048 + sw0);
+            Xf[mt][1] = *(const bf16x8 *)(b + mt * 2048 + sw1);
+        }
+    };
+#define PP_MFMA(WF, NH, MH)                                                                                              \
+    do {                                                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                                   \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)               \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc[(NH) * 2 + nt][(MH) * 4 + mt] =                         \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[nt][kk], Xf[mt][kk], acc[(NH) * 2 + nt][(MH) * 4 + mt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                   \
+    } while (0)
+
+    const int nk = p.K / BK;  // even, >= 2
+    const int J = nk >> 1;
+
+    // ---- prologue: K-tile 0 complete (4 half-tiles) + 3 half-tiles of K-tile 1; retire K-tile 0 with vmcnt(6)
+    issue(0, 0);
+    issue(2, 0);
+    issue(3, 0);
+    issue(1, 0);
+    issue(0, 1);
+    issue(2, 1);
+    issue(3, 1);
+    PP_WAIT_VM(6);
+    PP_BARRIER();
+    if (wr == 1) PP_BARRIER();  // stagger: waves 4-7 run one barrier behind waves 0-3
+
+    for (int j = 0; j < J; ++j) {
+        const bool more = (j + 1 < J);  // K-tiles 2j+2 / 2j+3 exist
+        const int ke = 2 * j, ko = 2 * j + 1;
+        // ================= even buffer, K-tile ke =================
+        // phase 1
+        read_w(Wa, 0, 0);
+        read_x(0, 0);
+        issue(1, ko);  // X_h1[odd] of K-tile 2j+1 (always exists)
+        PP_WAIT_LGKM0();
+        PP_BARRIER();
+        PP_MFMA(Wa, 0, 0);
+        PP_BARRIER();
+        // phase 2
+        read_w(Wbf, 0, 1);
+        if (more) issue(0, ke + 2);
+        PP_WAIT_LGKM0();
+        PP_BARRIER();
+        PP_MFMA(Wbf, 1, 0);
+        PP_BARRIER();
+        // phase 3
+        read_x(0, 1);
+        if (more) issue(2, ke + 2);
+        PP_WAIT_LGKM0();
+        PP_BARRIER();
+        PP_MFMA(Wbf, 1, 1);
+        PP_BARRIER();
+        // phase 4: retire the odd buffer (everything issued up to phase 1)
+        if (more) {
+            issue(3, ke + 2);
+            PP_WAIT_VM(6);
+        } else {
+            PP_WAIT_VM(0);
+        }
+        PP_BARRIER();
+        PP_MFMA(Wa, 0, 1);
+        PP_BARRIER();
+        // ================= odd buffer, K-tile ko =================
+        // phase 5
+        read_w(Wa, 1, 0);
+        read_x(1, 0);
+        if (more) issue(1, ke + 2);
+        PP_WAIT_LGKM0();
+        PP_BARRIER();
+        PP_MFMA(Wa, 0, 0);
+        PP_BARRIER();
+        // phase 6
+        read_w(Wbf, 1, 1);
+        if (more) issue(0, ko + 2);
+        PP_WAIT_LGKM0();
+        PP_BARRIER();
+        PP_MFMA(Wbf, 1, 0);
+        PP_BARRIER();
+        // phase 7
+        read_x(1, 1);
+        if (more) issue(2, ko + 2);
+        PP_WAIT_LGKM0();
+        PP_BARRIER();
+        PP_MFMA(Wbf, 1, 1);
+        PP_BARRIER();
+        // phase 8: retire the even buffer of the next iteration (everything issued up to phase 5)
+        if (more) {
+            issue(3, ko + 2);
+            PP_WAIT_VM(6);
+        }
+        PP_BARRIER();
+        PP_MFMA(Wa, 0, 1);
+        PP_BARRIER();
+    }
+    if (wr == 0) PP_BARRIER();  // balance the stagger barrier
+
+    // ---- epilogue: lane owns n = .. + 0..3 (contiguous) for row m
+    float scale = 1.0f;
+    if constexpr (EPI == EPI_SCALE_RESID) scale = *p.scale_ptr;
+#pragma unroll
+    for (int mtile = 0; mtile < 8; ++mtile) {
+        const int m = m0 + wr * 128 + (mtile >> 2) * 64 + (mtile & 3) * 16 + fr;
+        if (m >= p.M) continue;
+        size_t orow = (size_t)m;
+        const float *posrow = nullptr;
+        if constexpr (EPI == EPI_PATCH) {
+            const int img = m / p.patches_per_img, pp = m - img * p.patches_per_img;
+            orow = (size_t)img * p.tokens_per_img + 1 + pp;
+            posrow = p.pos + (size_t)(1 + pp) * p.N;
+        }
+#pragma unroll
+        for (int ntile = 0; ntile < 4; ++ntile) {
+            const int n = n0 + wc * 64 + (ntile >> 1) * 32 + (ntile & 1) * 16 + fq * 4;
+            f32x4 v = acc[ntile][mtile];
+            if constexpr (EPI != EPI_PATCH) v += *(const f32x4 *)(p.bias + n);
+            if constexpr (EPI == EPI_BIAS_QUICKGELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+            }
+            if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+            }
+            if constexpr (EPI == EPI_PATCH) {
+                const f32x4 pe = *(const f32x4 *)(posrow + n);
+                *(f32x4 *)(p.resid + orow * p.ldr + n) = v + pe;
+            }
+            if constexpr (EPI == EPI_BIAS_RESID) {
+                f32x4 *hp = (f32x4 *)(p.resid + orow * p.ldr + n);
+                *hp = *hp + v;
+            }
+            if constexpr (EPI == EPI_SCALE_RESID) {
+                f32x4 *hp = (f32x4 *)(p.resid + orow * p.ldr + n);
+                *hp = *hp + v * scale;
+            }
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QUICKGELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *(uint2 *)(p.out_bf16 + orow * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch_pp(const GemmParams &p, hipStream_t s) {
+    const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         2 * BUF_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_pp_kernel<EPI>, dim3(tiles), dim3(NTHREADS), 2 * BUF_BYTES, s, p);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+bool ch_gemm_pp_supported(const GemmParams &p) {
+    return p.N % BN == 0 && p.K % (2 * BK) == 0 && p.X_rows_alloc >= round_up64(p.M, BM) &&
+           (size_t)round_up64(p.M, BM) * p.K * 2 < (1ull << 32) && (size_t)p.N * p.K * 2 < (1ull << 32);
+}
+
+int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s) {
+    CH_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem");
+    CH_REQUIRE(epi == EPI_PATCH || p.bias != nullptr, "gemm: bias is required");
+    CH_REQUIRE(ch_gemm_pp_supported(p), "gemm_pp: needs N % 256 == 0, K % 128 == 0, X padded to 256 rows, operands < 4 GiB");
+    switch (epi) {
+        case EPI_BIAS: return launch_pp<EPI_BIAS>(p, s);
+        case EPI_BIAS_QUICKGELU: return launch_pp<EPI_BIAS_QUICKGELU>(p, s);
+        case EPI_BIAS_GELU: return launch_pp<EPI_BIAS_GELU>(p, s);
+        case EPI_BIAS_RESID: return launch_pp<EPI_BIAS_RESID>(p, s);
+        case EPI_SCALE_RESID: return launch_pp<EPI_SCALE_RESID>(p, s);
+        case EPI_PATCH: return launch_pp<EPI_PATCH>(p, s);
+    }
+    ch_set_error("gemm: unknown epilogue");
+    return 2;
+}

@@ -27,7 +27,11 @@ struct GemmParams {
     int tokens_per_img;      // EPI_PATCH: N tokens per image in the residual stream
     int patches_per_img;     // EPI_PATCH: Np
 };
-int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);
+int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);      // dispatcher
+int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s);   // gemm_bf16.hip: 128x128x64, two-phase
+int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s);   // gemm_pp.hip: 256x256x64, ping-pong 8-phase
+bool ch_gemm_pp_supported(const GemmParams &p);
+void ch_gemm_set_variant(int v);
 
 // ---- rowops.hip ----------------------------------------------------------------------------------------------
 // im2col for the patch-embed conv (k = s = patch, no bias): out[b*Np + p][c*pp + ky*patch + kx], zero padded to Kp.

@@ -299,8 +299,8 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
     if (!B.ok) return 4;
 
     // ---- workspace (rows padded to the GEMM block tile; padding rows are zero and never read back)
-    const int64_t rows = round_up64((int64_t)c.max_batch * m->ntok, 128);
-    const int64_t prows = round_up64((int64_t)c.max_batch * np, 128);
+    const int64_t rows = round_up64((int64_t)c.max_batch * m->ntok, 256);
+    const int64_t prows = round_up64((int64_t)c.max_batch * np, 256);
     m->rows_alloc = rows;
     m->prow_alloc = prows;
     m->H = (float *)B.alloc(sizeof(float) * rows * D);
@@ -544,3 +544,19 @@ extern "C" int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *la
     m->prof_n = 0;
     return 0;
 }
+
+// ---- test / bench tap: one GEMM launch on caller buffers (tests/test_gemm_gpu.py, tools/gemm_bench.py) -----------------
+extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_alloc, const void *W, const float *bias,
+                             int32_t M, int32_t N, int32_t K, int32_t epi, void *out_bf16, int32_t ldo, float *resid,
+                             int32_t ldr, const float *scale_ptr, void *stream) {
+    CH_REQUIRE(X && W, "debug_gemm: null operand");
+    CH_REQUIRE(epi >= EPI_BIAS && epi <= EPI_SCALE_RESID, "debug_gemm: epilogue must be one of the non-patch modes");
+    GemmParams p{};
+    p.X = (const bf16_t *)X; p.W = (const bf16_t *)W; p.M = M; p.N = N; p.K = K; p.X_rows_alloc = X_rows_alloc;
+    p.bias = bias; p.out_bf16 = (bf16_t *)out_bf16; p.ldo = ldo; p.resid = resid; p.ldr = ldr; p.scale_ptr = scale_ptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (variant == 1) return ch_gemm_bf16_v1(p, epi, s);
+    if (variant == 2) return ch_gemm_bf16_pp(p, epi, s);
+    return ch_gemm_bf16(p, epi, s);
+}
+extern "C" void ch_debug_set_gemm_variant(int32_t v) { ch_gemm_set_variant(v); }

@@ -1,0 +1,96 @@
+"""GPU: the fused-epilogue bf16 GEMM kernels in isolation (C-ABI test tap `ch_debug_gemm`).
+  * each kernel against a plain PyTorch fp32 reference of the same op on the same bf16-rounded operands
+    (tolerance: fp32 accumulation-order differences only, atol 2e-3 on O(1) outputs; bf16 output rounding 2^-8 rel);
+  * the 256x256 ping-pong kernel against the 128x128 two-phase kernel BIT FOR BIT (same MFMA instruction and the same
+    k order per output element, so any difference is a staging race), repeated as a race screen with an L2-warm and an
+    L2-cold pattern."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_BIAS_RESID, EPI_SCALE_RESID = range(5)
+
+
+def _gemm(variant, X, W, bias, M, epi, out=None, resid=None, scale=None):
+    from concepthash_amd import _lib
+    lib = _lib.load()
+    N, K = W.shape
+    _lib.check(lib.ch_debug_gemm(variant, _lib.ptr(X), X.shape[0], _lib.ptr(W), _lib.ptr(bias), M, N, K, epi, _lib.ptr(out),
+                                 N if out is not None else 0, _lib.ptr(resid), N if resid is not None else 0,
+                                 _lib.ptr(scale), _lib.stream_ptr()), "ch_debug_gemm")
+
+
+def _ref(X, W, bias, M, epi, resid0=None, scale=None):
+    v = X[:M].float() @ W.float().t() + bias
+    if epi == EPI_QGELU:
+        v = v * torch.sigmoid(1.702 * v)
+    if epi == EPI_GELU:
+        v = torch.nn.functional.gelu(v)
+    if epi == EPI_BIAS_RESID:
+        return v, resid0[:M] + v
+    if epi == EPI_SCALE_RESID:
+        return None, resid0[:M] + scale * v
+    return v, None
+
+
+def _inputs(M, N, K, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    Mp = (M + 255) // 256 * 256
+    X = torch.zeros(Mp, K, dtype=torch.bfloat16, device="cuda")
+    X[:M] = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device="cuda")
+    resid = torch.randn(Mp, N, generator=g, device="cuda")
+    return X, W, bias, resid
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 768, 768), (2011, 2304, 768), (513, 768, 3072), (700, 3072, 768),
+                                   (300, 768, 384), (257, 256, 640)])
+def test_gemm_against_torch_fp32(variant, M, N, K):
+    X, W, bias, resid0 = _inputs(M, N, K)
+    scale = torch.tensor([0.7], device="cuda")
+    for epi in (EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_BIAS_RESID, EPI_SCALE_RESID):
+        out = torch.full((X.shape[0], N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        resid = resid0.clone()
+        _gemm(variant, X, W, bias, M, epi, out=out if epi != EPI_SCALE_RESID else None,
+              resid=resid if epi >= EPI_BIAS_RESID else None, scale=scale)
+        torch.cuda.synchronize()
+        v, r = _ref(X, W, bias, M, epi, resid0, 0.7)
+        if v is not None:
+            assert torch.allclose(out[:M].float(), v, atol=2e-3 + 1e-2, rtol=2 ** -7), (epi, float((out[:M].float() - v).abs().max()))
+            assert bool(torch.isnan(out[M:].float()).all())                      # rows >= M are never written
+        if r is not None:
+            assert torch.allclose(resid[:M], r, atol=2e-3, rtol=1e-4), (epi, float((resid[:M] - r).abs().max()))
+            assert torch.equal(resid[M:], resid0[M:])
+
+
+@pytest.mark.parametrize("M,N,K", [(51456, 768, 768), (4096, 2304, 768), (3000, 3072, 768), (2500, 768, 3072), (1500, 768, 384)])
+def test_pingpong_equals_two_phase_bitwise_and_is_race_free(M, N, K):
+    X, W, bias, resid0 = _inputs(M, N, K, seed=1)
+    ref = torch.empty(X.shape[0], N, dtype=torch.bfloat16, device="cuda")
+    r_ref = resid0.clone()
+    _gemm(1, X, W, bias, M, EPI_BIAS_RESID, out=ref, resid=r_ref)
+    junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")   # 256 MiB: evicts L2 + MALL when written
+    for it in range(6):
+        out = torch.zeros_like(ref)
+        r = resid0.clone()
+        if it % 2:
+            junk.fill_(float(it))
+        _gemm(2, X, W, bias, M, EPI_BIAS_RESID, out=out, resid=r)
+        torch.cuda.synchronize()
+        assert torch.equal(out[:M].view(torch.int16), ref[:M].view(torch.int16)), f"iteration {it}"
+        assert torch.equal(r[:M], r_ref[:M]), f"iteration {it}"
+
+
+def test_unsupported_shapes_are_rejected_loudly():
+    X, W, bias, _ = _inputs(256, 384, 768)
+    out = torch.empty(256, 384, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError, match="gemm_pp"):
+        _gemm(2, X, W, bias, 256, EPI_BIAS, out=out)             # N % 256 != 0 -> only the 128x128 kernel takes it
+    _gemm(0, X, W, bias, 256, EPI_BIAS, out=out)                 # auto dispatch falls to the 128x128 kernel
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        _gemm(1, X, W[:100], bias, 256, EPI_BIAS, out=out)
