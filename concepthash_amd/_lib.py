@@ -36,7 +36,7 @@ SIGNATURES = {
     "ch_model_profile_begin": (c_int, [c_void_p, c_int32]),
     "ch_model_profile_end": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "ch_debug_gemm": (c_int, [c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
-                              c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+                              c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "ch_debug_set_gemm_variant": (None, [c_int32]),
     "ch_encode": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p]),

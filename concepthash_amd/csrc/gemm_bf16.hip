@@ -15,6 +15,7 @@
 // a lane owns 4 consecutive n for one m, i.e. 4 contiguous output elements -> 8-B bf16 / 16-B fp32 stores.
 #include "ch_common.h"
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -25,8 +26,6 @@ constexpr int NTHREADS = 256;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 // XCD-aware, bijective block remap: blocks b and b+8 share an XCD (observed round-robin dispatch; speed only).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -109,53 +108,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
         cur ^= 1;
     }
 
-    // ---- epilogue: lane owns n = nb + 0..3 (contiguous) for row m
-    float scale = 1.0f;
-    if constexpr (EPI == EPI_SCALE_RESID) scale = *p.scale_ptr;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + frow;
-        if (m >= p.M) continue;
-        size_t orow = (size_t)m;
-        const float *posrow = nullptr;
-        if constexpr (EPI == EPI_PATCH) {
-            const int img = m / p.patches_per_img, pp = m - img * p.patches_per_img;
-            orow = (size_t)img * p.tokens_per_img + 1 + pp;
-            posrow = p.pos + (size_t)(1 + pp) * p.N;
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-            f32x4 v = acc[nt][mt];
-            if constexpr (EPI != EPI_PATCH) v += *(const f32x4 *)(p.bias + n);
-            if constexpr (EPI == EPI_BIAS_QUICKGELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-            }
-            if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-            }
-            if constexpr (EPI == EPI_PATCH) {
-                const f32x4 pe = *(const f32x4 *)(posrow + n);
-                *(f32x4 *)(p.resid + orow * p.ldr + n) = v + pe;
-            }
-            if constexpr (EPI == EPI_BIAS_RESID) {
-                f32x4 *hp = (f32x4 *)(p.resid + orow * p.ldr + n);
-                *hp = *hp + v;
-            }
-            if constexpr (EPI == EPI_SCALE_RESID) {
-                f32x4 *hp = (f32x4 *)(p.resid + orow * p.ldr + n);
-                *hp = *hp + v * scale;
-            }
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QUICKGELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
-                uint2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                *(uint2 *)(p.out_bf16 + orow * p.ldo + n) = o;
-            }
-        }
-    }
+    // ---- epilogue (gemm_epilogue.h): transpose through this wave's 16 KB of the idle staging LDS, full-line stores.
+    // The loop's last __syncthreads() guarantees no wave still reads staged operands.
+    ch_epi::store_tile<EPI, 4>(p, acc, smem + wid * 16384, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 template <int EPI>

@@ -23,6 +23,7 @@
 // K must be a multiple of 128 (an even number of K-tiles), N a multiple of 256, X padded to a multiple of 256 rows.
 #include "ch_common.h"
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -34,8 +35,6 @@ constexpr int NTHREADS = 512;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
@@ -60,7 +59,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
         __builtin_amdgcn_sched_barrier(0);                    \
     } while (0)
 
-template <int EPI>
+// DBG bits (timing-only builds, results are garbage): 1 = no global loads, 2 = no LDS fragment reads, 4 = no epilogue
+template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const char *Wb = (const char *)p.W;
     // which: 0 X_h0, 1 X_h1, 2 W_h0, 3 W_h1 ; kt = K-tile index ; buf = kt & 1
     auto issue = [&](int which, int kt) {
+        if constexpr (DBG & 1) return;
         char *dst = smem + (kt & 1) * BUF_BYTES + which * HALF_BYTES + wid * 2048;
         const uint32_t kb = (uint32_t)kt * (BK * 2);
         const char *base = which < 2 ? Xb : Wb;
@@ -116,9 +117,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 Wa[2][2], Wbf[2][2], Xf[4][2];  // [tile][kk]
+    bf16x8 Wa[2][2] = {}, Wbf[2][2] = {}, Xf[4][2] = {};  // [tile][kk]
 
     auto read_w = [&](bf16x8 (&dst)[2][2], int buf, int h) {
+        if constexpr (DBG & 2) {
+            asm volatile("" : "+v"(dst[0][0]), "+v"(dst[0][1]), "+v"(dst[1][0]), "+v"(dst[1][1]));
+            return;
+        }
         const char *b = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES + wrow;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -127,6 +132,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
         }
     };
     auto read_x = [&](int buf, int h) {
+        if constexpr (DBG & 2) {
+            asm volatile("" : "+v"(Xf[0][0]), "+v"(Xf[0][1]), "+v"(Xf[1][0]), "+v"(Xf[1][1]), "+v"(Xf[2][0]), "+v"(Xf[2][1]), "+v"(Xf[3][0]), "+v"(Xf[3][1]));
+            return;
+        }
         const char *b = smem + buf * BUF_BYTES + h * HALF_BYTES + xrow;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -228,53 +237,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     }
     if (wr == 0) PP_BARRIER();  // balance the stagger barrier
 
-    // ---- epilogue: lane owns n = .. + 0..3 (contiguous) for row m
-    float scale = 1.0f;
-    if constexpr (EPI == EPI_SCALE_RESID) scale = *p.scale_ptr;
+    if constexpr (DBG & 4) {  // keep the accumulators alive with one store per lane
+        f32x4 t = acc[0][0];
 #pragma unroll
-    for (int mtile = 0; mtile < 8; ++mtile) {
-        const int m = m0 + wr * 128 + (mtile >> 2) * 64 + (mtile & 3) * 16 + fr;
-        if (m >= p.M) continue;
-        size_t orow = (size_t)m;
-        const float *posrow = nullptr;
-        if constexpr (EPI == EPI_PATCH) {
-            const int img = m / p.patches_per_img, pp = m - img * p.patches_per_img;
-            orow = (size_t)img * p.tokens_per_img + 1 + pp;
-            posrow = p.pos + (size_t)(1 + pp) * p.N;
-        }
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int ntile = 0; ntile < 4; ++ntile) {
-            const int n = n0 + wc * 64 + (ntile >> 1) * 32 + (ntile & 1) * 16 + fq * 4;
-            f32x4 v = acc[ntile][mtile];
-            if constexpr (EPI != EPI_PATCH) v += *(const f32x4 *)(p.bias + n);
-            if constexpr (EPI == EPI_BIAS_QUICKGELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-            }
-            if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-            }
-            if constexpr (EPI == EPI_PATCH) {
-                const f32x4 pe = *(const f32x4 *)(posrow + n);
-                *(f32x4 *)(p.resid + orow * p.ldr + n) = v + pe;
-            }
-            if constexpr (EPI == EPI_BIAS_RESID) {
-                f32x4 *hp = (f32x4 *)(p.resid + orow * p.ldr + n);
-                *hp = *hp + v;
-            }
-            if constexpr (EPI == EPI_SCALE_RESID) {
-                f32x4 *hp = (f32x4 *)(p.resid + orow * p.ldr + n);
-                *hp = *hp + v * scale;
-            }
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_QUICKGELU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) {
-                uint2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                *(uint2 *)(p.out_bf16 + orow * p.ldo + n) = o;
-            }
-        }
+            for (int b = 0; b < 8; ++b) t += acc[a][b];
+        if (t[0] == 12345.678f) p.out_bf16[tid] = (bf16_t)1;
+        return;
     }
+    // ---- epilogue (gemm_epilogue.h): every wave has passed the balance barrier, so no wave still reads staged operands
+    // and no LDS-DMA is in flight (vmcnt(0) in the last iteration); each wave transposes through its own 16 KB.
+    ch_epi::store_tile<EPI, 8>(p, acc, smem + wid * 16384, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
 template <int EPI>
@@ -296,6 +270,27 @@ int launch_pp(const GemmParams &p, hipStream_t s) {
 bool ch_gemm_pp_supported(const GemmParams &p) {
     return p.N % BN == 0 && p.K % (2 * BK) == 0 && p.X_rows_alloc >= round_up64(p.M, BM) &&
            (size_t)round_up64(p.M, BM) * p.K * 2 < (1ull << 32) && (size_t)p.N * p.K * 2 < (1ull << 32);
+}
+
+int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s) {
+    const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    if (!ch_gemm_pp_supported(p)) return 2;
+#define PP_DBG_CASE(D)                                                                                                   \
+    case D:                                                                                                              \
+        (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI_BIAS, D>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  2 * BUF_BYTES);                                                                        \
+        hipLaunchKernelGGL((gemm_pp_kernel<EPI_BIAS, D>), dim3(tiles), dim3(NTHREADS), 2 * BUF_BYTES, s, p);             \
+        break;
+    switch (dbg) {
+        PP_DBG_CASE(1)
+        PP_DBG_CASE(2)
+        PP_DBG_CASE(3)
+        PP_DBG_CASE(4)
+        PP_DBG_CASE(7)
+        default: return 2;
+    }
+    CH_LAUNCH_CHECK();
+    return 0;
 }
 
 int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s) {

@@ -8,7 +8,7 @@ enum GemmEpilogue {
     EPI_BIAS_QUICKGELU = 1, // out_bf16 = quick_gelu(acc + bias)
     EPI_BIAS_GELU = 2,      // out_bf16 = gelu_erf(acc + bias)
     EPI_BIAS_RESID = 3,     // v = acc + bias; resid += v; out_bf16 = v
-    EPI_SCALE_RESID = 4,    // resid += *scale_ptr * (acc + bias)
+    EPI_SCALE_RESID = 4,    // resid += [addend] + *scale_ptr * (acc + bias)
     EPI_PATCH = 5,          // resid[token row of patch m] = acc + pos[1 + patch]
 };
 
@@ -23,6 +23,8 @@ struct GemmParams {
     float *resid;          // fp32 residual stream [rows, ldr]
     int ldr;
     const float *scale_ptr;  // device scalar (adapter scale)
+    const bf16_t *addend;    // EPI_SCALE_RESID: optional bf16 [M, ld_addend] added to the residual as well (or nullptr)
+    int ld_addend;
     const float *pos;        // EPI_PATCH: position embedding [1 + Np, N]
     int tokens_per_img;      // EPI_PATCH: N tokens per image in the residual stream
     int patches_per_img;     // EPI_PATCH: Np
@@ -31,6 +33,7 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);      // dispatche
 int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s);   // gemm_bf16.hip: 128x128x64, two-phase
 int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s);   // gemm_pp.hip: 256x256x64, ping-pong 8-phase
 bool ch_gemm_pp_supported(const GemmParams &p);
+int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s);  // timing-only builds (garbage results)
 void ch_gemm_set_variant(int v);
 
 // ---- rowops.hip ----------------------------------------------------------------------------------------------

@@ -357,9 +357,10 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
 
     // cat / n_true / k_true: profiler category and the un-padded (algorithmic) GEMM extents
     auto gemm = [&](int cat, int n_true, int k_true, const bf16_t *X, const bf16_t *W, int N, int K, const float *bias,
-                    int epi, bf16_t *out, int ldo, const float *scale) {
+                    int epi, bf16_t *out, int ldo, const float *scale, const bf16_t *addend = nullptr) {
         mark(m, cat, 2.0 * rows * (double)n_true * k_true, s);
         GemmParams p{};
+        p.addend = addend; p.ld_addend = D;
         p.X = X; p.W = W; p.M = rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
         p.out_bf16 = out; p.ldo = ldo; p.resid = m->H; p.ldr = D; p.scale_ptr = scale;
         return ch_gemm_bf16(p, epi, s);
@@ -372,8 +373,9 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
         if (int e = gemm(CH_CAT_GEMM_DOWN, c.adapter_dim, D, m->Xn, aw.down_w, m->bpad, D, aw.down_b, EPI_BIAS_GELU, m->AD,
                          m->bpad, nullptr))
             return e;
+        // one fp32 read-modify-write of the residual per sub-block: H += a + scale * (up(...) + bias), `a` read back as bf16
         return gemm(CH_CAT_GEMM_UP, D, c.adapter_dim, m->AD, aw.up_w, D, m->bpad, aw.up_b, EPI_SCALE_RESID, nullptr, 0,
-                    aw.scale);
+                    aw.scale, m->A);
     };
 
     for (int i = 0; i < nlayers; ++i) {
@@ -386,12 +388,17 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
         mark(m, CH_CAT_ATTENTION, 4.0 * B * (double)ntok * ntok * D, s);
         if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s)) return e;
         // h = r + a  (+ adapter_1(a) below);  a kept as bf16 in m->A for the adapter branch
-        if (int e = gemm(CH_CAT_GEMM_OUT, D, D, m->AO, w.out_w, D, D, w.out_b, EPI_BIAS_RESID, m->A, D, nullptr)) return e;
+        // with adapters the residual add of `a` is deferred to the adapter's up-projection epilogue (see adapter())
+        if (int e = gemm(CH_CAT_GEMM_OUT, D, D, m->AO, w.out_w, D, D, w.out_b, w.ad[0].down_w ? EPI_BIAS : EPI_BIAS_RESID, m->A,
+                         D, nullptr))
+            return e;
         if (int e = adapter(w.ad[0])) return e;
         mark(m, CH_CAT_ROWOPS, 0.0, s);
         if (int e = ch_layernorm_f32(m->H, rows, D, w.ln2_w, w.ln2_b, c.ln_eps, m->Xn, s)) return e;
         if (int e = gemm(CH_CAT_GEMM_FC1, M, D, m->Xn, w.fc1_w, M, D, w.fc1_b, act_epi, m->F1, M, nullptr)) return e;
-        if (int e = gemm(CH_CAT_GEMM_FC2, D, M, m->F1, w.fc2_w, D, M, w.fc2_b, EPI_BIAS_RESID, m->A, D, nullptr)) return e;
+        if (int e = gemm(CH_CAT_GEMM_FC2, D, M, m->F1, w.fc2_w, D, M, w.fc2_b, w.ad[1].down_w ? EPI_BIAS : EPI_BIAS_RESID, m->A,
+                         D, nullptr))
+            return e;
         if (int e = adapter(w.ad[1])) return e;
     }
     return 0;
@@ -548,15 +555,16 @@ extern "C" int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *la
 // ---- test / bench tap: one GEMM launch on caller buffers (tests/test_gemm_gpu.py, tools/gemm_bench.py) -----------------
 extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_alloc, const void *W, const float *bias,
                              int32_t M, int32_t N, int32_t K, int32_t epi, void *out_bf16, int32_t ldo, float *resid,
-                             int32_t ldr, const float *scale_ptr, void *stream) {
+                             int32_t ldr, const float *scale_ptr, const void *addend, void *stream) {
     CH_REQUIRE(X && W, "debug_gemm: null operand");
     CH_REQUIRE(epi >= EPI_BIAS && epi <= EPI_SCALE_RESID, "debug_gemm: epilogue must be one of the non-patch modes");
     GemmParams p{};
     p.X = (const bf16_t *)X; p.W = (const bf16_t *)W; p.M = M; p.N = N; p.K = K; p.X_rows_alloc = X_rows_alloc;
-    p.bias = bias; p.out_bf16 = (bf16_t *)out_bf16; p.ldo = ldo; p.resid = resid; p.ldr = ldr; p.scale_ptr = scale_ptr;
+    p.bias = bias; p.out_bf16 = (bf16_t *)out_bf16; p.ldo = ldo; p.resid = resid; p.ldr = ldr; p.scale_ptr = scale_ptr; p.addend = (const bf16_t *)addend; p.ld_addend = N;
     hipStream_t s = (hipStream_t)stream;
     if (variant == 1) return ch_gemm_bf16_v1(p, epi, s);
     if (variant == 2) return ch_gemm_bf16_pp(p, epi, s);
+    if (variant >= 21 && variant <= 27) return ch_gemm_bf16_pp_dbg(p, variant - 20, s);  // timing-only builds
     return ch_gemm_bf16(p, epi, s);
 }
 extern "C" void ch_debug_set_gemm_variant(int32_t v) { ch_gemm_set_variant(v); }

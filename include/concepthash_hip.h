@@ -108,10 +108,10 @@ int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *launches_per_
 /* Test / bench taps (not part of the product path): one fused-epilogue GEMM launch on caller buffers, and a global
  * override of the GEMM kernel selection (0 auto, 1 = 128x128 two-phase kernel, 2 = 256x256 ping-pong kernel).
  * X [X_rows_alloc, K] bf16, W [N, K] bf16, bias [N] fp32; epi: 0 bias, 1 bias+quick_gelu, 2 bias+gelu,
- * 3 bias + (resid += v) + bf16 out, 4 resid += *scale_ptr * (acc + bias). */
+ * 3 bias + (resid += v) + bf16 out, 4 resid += [addend bf16 [M,N]] + *scale_ptr * (acc + bias). */
 int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_alloc, const void *W, const float *bias, int32_t M,
                   int32_t N, int32_t K, int32_t epi, void *out_bf16, int32_t ldo, float *resid, int32_t ldr,
-                  const float *scale_ptr, void *stream);
+                  const float *scale_ptr, const void *addend, void *stream);
 void ch_debug_set_gemm_variant(int32_t variant);
 
 /* Algorithmic FLOPs of one image through ch_encode (SURVEY.md section 8d formula). */

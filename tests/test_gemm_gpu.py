@@ -14,13 +14,13 @@ pytestmark = pytest.mark.gpu
 EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_BIAS_RESID, EPI_SCALE_RESID = range(5)
 
 
-def _gemm(variant, X, W, bias, M, epi, out=None, resid=None, scale=None):
+def _gemm(variant, X, W, bias, M, epi, out=None, resid=None, scale=None, addend=None):
     from concepthash_amd import _lib
     lib = _lib.load()
     N, K = W.shape
     _lib.check(lib.ch_debug_gemm(variant, _lib.ptr(X), X.shape[0], _lib.ptr(W), _lib.ptr(bias), M, N, K, epi, _lib.ptr(out),
                                  N if out is not None else 0, _lib.ptr(resid), N if resid is not None else 0,
-                                 _lib.ptr(scale), _lib.stream_ptr()), "ch_debug_gemm")
+                                 _lib.ptr(scale), _lib.ptr(addend), _lib.stream_ptr()), "ch_debug_gemm")
 
 
 def _ref(X, W, bias, M, epi, resid0=None, scale=None):
@@ -66,6 +66,14 @@ def test_gemm_against_torch_fp32(variant, M, N, K):
         if r is not None:
             assert torch.allclose(resid[:M], r, atol=2e-3, rtol=1e-4), (epi, float((resid[:M] - r).abs().max()))
             assert torch.equal(resid[M:], resid0[M:])
+    # EPI_SCALE_RESID with the deferred bf16 addend: resid += addend + scale * (acc + bias)
+    addend = torch.randn(X.shape[0], N, device="cuda").to(torch.bfloat16)
+    resid = resid0.clone()
+    _gemm(variant, X, W, bias, M, EPI_SCALE_RESID, resid=resid, scale=scale, addend=addend)
+    torch.cuda.synchronize()
+    _, r = _ref(X, W, bias, M, EPI_SCALE_RESID, resid0, 0.7)
+    assert torch.allclose(resid[:M], r + addend[:M].float(), atol=2e-3, rtol=1e-4)
+    assert torch.equal(resid[M:], resid0[M:])
 
 
 @pytest.mark.parametrize("M,N,K", [(51456, 768, 768), (4096, 2304, 768), (3000, 3072, 768), (2500, 768, 3072), (1500, 768, 384)])
