@@ -13,6 +13,8 @@
 // which makes every fragment read conflict free.
 // The MFMA A operand is the WEIGHT tile and the B operand the ACTIVATION tile, so the accumulator holds D[n][m]:
 // a lane owns 4 consecutive n for one m, i.e. 4 contiguous output elements -> 8-B bf16 / 16-B fp32 stores.
+#include <cstdlib>
+
 #include "ch_common.h"
 #include "kernels.h"
 #include "gemm_epilogue.h"
@@ -45,7 +47,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
     const int tiles_n = p.N / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    // tile order inside an XCD's contiguous chunk: n-tiles are taken in groups of p.group_n whose weight panels stay
+    // L2-resident (<= ~2.4 MB) while the m-tiles sweep past; inside a group n is fastest so the co-resident workgroups of
+    // an XCD share activation panels too.  (host: gemm_group_n)
+    const int per_group = tiles_m * p.group_n;
+    const int g = wg / per_group, rem = wg - g * per_group;
+    const int gn = min(p.group_n, tiles_n - g * p.group_n);
+    const int tm = rem / gn, tn = g * p.group_n + (rem - tm * gn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- staging addresses: the stage image is [X rows 0..127 ; W rows 0..127] x 128 B, 8 rows per wave-instruction.
@@ -114,7 +122,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
 }
 
 template <int EPI>
-int launch(const GemmParams &p, hipStream_t s) {
+int launch(const GemmParams &p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     static bool attr_set = false;
     if (!attr_set) {
@@ -145,6 +155,28 @@ int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s) {
     }
     ch_set_error("gemm: unknown epilogue");
     return 2;
+}
+
+// Estimated beyond-L2 read traffic for n-groups of gn tiles: every group re-streams X once; a group's weight panels are
+// fetched once per XCD if they fit in ~60 % of the 4 MB L2, otherwise once per round of co-resident tiles.
+int ch_gemm_group_n(int M, int N, int K, int bm, int bn) {
+    const int tiles_n = N / bn, tiles_m = (M + bm - 1) / bm;
+    const double xbytes = 2.0 * M * K, wpanel = 2.0 * bn * K, wbytes = 2.0 * N * K;
+    const double rounds = (double)tiles_m * tiles_n / 256.0 + 1.0;
+    const char *env = getenv("CH_GEMM_GROUP_N");
+    if (env && atoi(env) > 0) return atoi(env) < tiles_n ? atoi(env) : tiles_n;
+    int best = tiles_n;
+    double best_cost = 1e300;
+    for (int gn = 1; gn <= tiles_n; ++gn) {
+        const int ng = (tiles_n + gn - 1) / gn;
+        const bool fits = gn * wpanel <= 2.4e6;
+        const double cost = xbytes * ng + wbytes * 8.0 * (fits ? 1.0 : rounds);
+        if (cost < best_cost - 1.0) {
+            best_cost = cost;
+            best = gn;
+        }
+    }
+    return best;
 }
 
 // ---- dispatcher: the 256x256 ping-pong kernel when the shape allows it, this file's 128x128 kernel otherwise ---------

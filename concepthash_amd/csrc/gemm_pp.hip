@@ -71,7 +71,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const int tiles_n = p.N / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    // tile order inside an XCD's contiguous chunk: n-tiles are taken in groups of p.group_n whose weight panels stay
+    // L2-resident (<= ~2.4 MB) while the m-tiles sweep past; inside a group n is fastest so the co-resident workgroups of
+    // an XCD share activation panels too.  (host: gemm_group_n)
+    const int per_group = tiles_m * p.group_n;
+    const int g = wg / per_group, rem = wg - g * per_group;
+    const int gn = min(p.group_n, tiles_n - g * p.group_n);
+    const int tm = rem / gn, tn = g * p.group_n + (rem - tm * gn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- prefetch addressing.  A half-tile = 16 wave-instructions of 8 local rows; wave w issues instructions 2w, 2w+1:
@@ -252,7 +258,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
 }
 
 template <int EPI>
-int launch_pp(const GemmParams &p, hipStream_t s) {
+int launch_pp(const GemmParams &p0, hipStream_t s) {
+    GemmParams p = p0;
+    p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     static bool attr_set = false;
     if (!attr_set) {
@@ -272,7 +280,9 @@ bool ch_gemm_pp_supported(const GemmParams &p) {
            (size_t)round_up64(p.M, BM) * p.K * 2 < (1ull << 32) && (size_t)p.N * p.K * 2 < (1ull << 32);
 }
 
-int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s) {
+int ch_gemm_bf16_pp_dbg(const GemmParams &p0, int dbg, hipStream_t s) {
+    GemmParams p = p0;
+    p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (!ch_gemm_pp_supported(p)) return 2;
 #define PP_DBG_CASE(D)                                                                                                   \

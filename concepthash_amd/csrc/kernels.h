@@ -25,6 +25,7 @@ struct GemmParams {
     const float *scale_ptr;  // device scalar (adapter scale)
     const bf16_t *addend;    // EPI_SCALE_RESID: optional bf16 [M, ld_addend] added to the residual as well (or nullptr)
     int ld_addend;
+    int group_n;             // n-tiles per L2-resident weight group (set by the launcher)
     const float *pos;        // EPI_PATCH: position embedding [1 + Np, N]
     int tokens_per_img;      // EPI_PATCH: N tokens per image in the residual stream
     int patches_per_img;     // EPI_PATCH: Np
@@ -35,6 +36,8 @@ int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s);   // gemm_pp.h
 bool ch_gemm_pp_supported(const GemmParams &p);
 int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s);  // timing-only builds (garbage results)
 void ch_gemm_set_variant(int v);
+// n-tiles per weight group for a block tile of bn columns: minimises X re-fetches + W re-fetches
+int ch_gemm_group_n(int M, int N, int K, int bm, int bn);
 
 // ---- rowops.hip ----------------------------------------------------------------------------------------------
 // im2col for the patch-embed conv (k = s = patch, no bias): out[b*Np + p][c*pp + ky*patch + kx], zero padded to Kp.

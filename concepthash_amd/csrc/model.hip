@@ -1,6 +1,7 @@
 // ch_model: weights + workspace + the per-batch launch sequence of the ConceptHash encoder (C-ABI in
 // include/concepthash_hip.h).  Restates LGHWithFixedPrompt.forward (models/arch/coop.py:524-598) as a fixed chain of
 // HIP launches on one stream; see DESIGN.md for the kernel list and data layout.
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
