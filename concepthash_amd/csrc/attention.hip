@@ -5,14 +5,16 @@
 // materialises every layer's (B,heads,N,N) probability map (output_attentions=True, models/arch/coop.py:474-479); retrieval
 // never reads it, so this kernel keeps scores in registers and never writes them.
 //
-// One workgroup (4 waves) per (image, head).  The head's whole K (row-major, XOR-swizzled 128-B rows) and V (transposed,
-// Vt[d][key], row stride == 16 mod 256 bytes so the 8-byte fragment reads are bank-conflict free) live in LDS.
-// Each wave takes 16-query tiles round robin:
-//   S^T = K Q^T      v_mfma_f32_16x16x32_bf16 with A = K tile, B = Q^T fragment (loaded straight from global):
-//                    a lane then holds, for ONE query (lane & 15), 4 consecutive keys per 16-key tile -> the softmax
-//                    reductions are in-register plus two cross-lane steps (xor 16, xor 32);
-//   O^T = V^T P^T    the exponentiated scores, converted to bf16 in place, already ARE the B operand of this product
-//                    (k index permuted identically on the V^T fragment), so P never goes through LDS.
+// One workgroup (4 waves) per (image, head).  The head's whole K and V are staged ROW-MAJOR into LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, all 14 requests of a wave in flight at once); rows are 128 B with the
+// 16-B chunk index XOR (row & 7) applied on the per-lane source address.  Each wave takes 16-query tiles round robin:
+//   S^T = K Q^T      v_mfma_f32_16x16x32_bf16 with A = K tile (ds_read_b128, conflict free), B = Q^T fragment straight
+//                    from global: a lane holds, for ONE query (lane & 15), 4 consecutive keys per 16-key tile, so the
+//                    softmax reductions are in-register plus two cross-lane steps (xor 16, xor 32);
+//   O^T = V^T P^T    the exponentiated scores, converted to bf16 in place, already ARE the B operand of this product; the
+//                    A operand V^T comes from the row-major V image through the hardware transpose read
+//                    ds_read_b64_tr_b16 (a 16-lane group fetches 4 keys x 16 features and each lane receives one feature
+//                    column) -- conflict free with the same swizzle.  P never goes through LDS.
 //   out = O / rowsum (fp32), 4 consecutive d per lane -> 8-byte bf16 stores.
 #include "ch_common.h"
 #include "kernels.h"
@@ -20,15 +22,19 @@
 namespace {
 
 constexpr int HD = 64;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s lds_v4s;
 
 template <int KB>  // number of 32-key blocks (keys padded to KB*32)
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ qkv, int ntok, int heads, int vs_bytes,
-                                                        float scale_log2e, bf16_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ qkv, int ntok, int heads, float scale_log2e,
+                                                        bf16_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KT = KB * 2;     // 16-key tiles
-    constexpr int KP = KB * 32;    // padded keys
-    char *Ks = smem;               // [KP][128 B]
-    char *Vt = smem + KP * 128;    // [64][vs_bytes]
+    constexpr int KT = KB * 2;   // 16-key tiles
+    constexpr int KP = KB * 32;  // padded keys
+    char *Ks = smem;             // [KP][128 B]
+    char *Vs = smem + KP * 128;  // [KP][128 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -37,34 +43,35 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
     const size_t ld = (size_t)3 * D;
     const bf16_t *base = qkv + (size_t)b * ntok * ld + h * HD;
 
-    // ---- stage K (swizzled rows) and V (transposed) ----
-    for (int c = tid; c < KP * 8; c += 256) {
-        const int row = c >> 3, ch = c & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (row < ntok) {
-            kv = *(const uint4 *)(base + (size_t)row * ld + D + ch * 8);
-            vv = *(const uint4 *)(base + (size_t)row * ld + 2 * D + ch * 8);
-        }
-        *(uint4 *)(Ks + row * 128 + ((ch ^ (row & 7)) << 4)) = kv;
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bf16_t val = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffff);
-            *(bf16_t *)(Vt + (size_t)(ch * 8 + e) * vs_bytes + row * 2) = val;
+    // ---- stage K and V: instruction i covers rows 8i..8i+7 (1 KB); rows past the sequence re-read the last row (finite
+    // data; those keys are masked to -inf and get probability 0)
+    {
+        const int lrow = lane >> 3;
+        const int src_chunk = (lane & 7) ^ lrow;
+        for (int i = wid; i < KP / 8; i += 4) {
+            int row = i * 8 + lrow;
+            row = row < ntok ? row : ntok - 1;
+            const bf16_t *src = base + (size_t)row * ld + src_chunk * 8;
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + D), (lds_void_t *)(Ks + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + 2 * D), (lds_void_t *)(Vs + i * 1024), 16, 0, 0);
         }
     }
-    __syncthreads();
-
     const int fr = lane & 15, fq = lane >> 4;
     const int QT = (ntok + 15) >> 4;
-    for (int qt = wid; qt < QT; qt += 4) {
-        int q = qt * 16 + fr;
-        const bool qvalid = q < ntok;
-        if (!qvalid) q = ntok - 1;
-        const bf16_t *qp = base + (size_t)q * ld + fq * 8;
-        const bf16x8 qf0 = *(const bf16x8 *)(qp);
-        const bf16x8 qf1 = *(const bf16x8 *)(qp + 32);
+    // first query tile's Q fragments overlap the staging latency
+    int q = wid * 16 + fr;
+    bool qvalid = q < ntok;
+    if (!qvalid) q = ntok - 1;
+    bf16x8 qf0 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8);
+    bf16x8 qf1 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8 + 32);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
+    // transpose-read addressing: lane i = 4*qq + pp of a 16-lane group supplies row (key0 + qq), features 4pp..4pp+3 of the
+    // 16-feature tile dt: chunk = dt*2 + (pp >> 1), half = pp & 1
+    const int tq = fr >> 2, tp = fr & 3;
+
+    for (int qt = wid; qt < QT; qt += 4) {
         f32x4 st[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -75,6 +82,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
             st[kt] = a;
+        }
+        const bool cur_valid = qvalid;
+        const int cur_q = q;
+        // prefetch the next tile's Q fragments
+        if (qt + 4 < QT) {
+            q = (qt + 4) * 16 + fr;
+            qvalid = q < ntok;
+            if (!qvalid) q = ntok - 1;
+            qf0 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8);
+            qf1 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8 + 32);
         }
         // ---- softmax over keys for query (lane & 15): lane holds keys kt*16 + 4*fq + r
         float mx = -1e30f;
@@ -88,12 +105,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxs = mx * scale_log2e;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = exp2f((st[kt][r] - mx) * scale_log2e);
+                const float e = __builtin_amdgcn_exp2f(st[kt][r] * scale_log2e - mxs);
                 st[kt][r] = e;
                 sum += e;
             }
@@ -115,20 +133,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             pf.u[1] = pack_bf16x2(st[2 * kb][2], st[2 * kb][3]);
             pf.u[2] = pack_bf16x2(st[2 * kb + 1][0], st[2 * kb + 1][1]);
             pf.u[3] = pack_bf16x2(st[2 * kb + 1][2], st[2 * kb + 1][3]);
+            const int r0 = kb * 32 + fq * 4 + tq;  // key row this lane addresses for elements 0..3; +16 for 4..7
+            const int r1 = r0 + 16;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const char *vrow = Vt + (size_t)(dt * 16 + fr) * vs_bytes + (kb * 32 + fq * 4) * 2;
+                const int chunk = dt * 2 + (tp >> 1);
                 union {
                     bf16x8 v;
-                    uint2 h[2];
+                    v4s h[2];
                 } vf;
-                vf.h[0] = *(const uint2 *)(vrow);
-                vf.h[1] = *(const uint2 *)(vrow + 32);
+                vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_v4s *)(Vs + r0 * 128 + ((chunk ^ (r0 & 7)) << 4) + (tp & 1) * 8));
+                vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_v4s *)(Vs + r1 * 128 + ((chunk ^ (r1 & 7)) << 4) + (tp & 1) * 8));
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
             }
         }
-        if (qvalid) {
-            bf16_t *op = out + ((size_t)b * ntok + q) * D + h * HD + fq * 4;
+        if (cur_valid) {
+            bf16_t *op = out + ((size_t)b * ntok + cur_q) * D + h * HD + fq * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 w;
@@ -143,9 +165,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
 template <int KB>
 int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s) {
     const int KP = KB * 32;
-    int vs = KP * 2;
-    vs = ((vs - 16 + 255) / 256) * 256 + 16;  // smallest value >= KP*2 that is == 16 (mod 256)
-    const size_t lds = (size_t)KP * 128 + (size_t)64 * vs;
+    const size_t lds = (size_t)KP * 128 * 2;
     CH_REQUIRE(lds <= 160 * 1024, "attention: sequence too long for the LDS-resident K/V kernel");
     static bool attr_set = false;
     if (!attr_set) {
@@ -154,7 +174,7 @@ int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipS
         attr_set = true;
     }
     const float scale_log2e = 0.125f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e), head_dim = 64
-    hipLaunchKernelGGL(attention_kernel<KB>, dim3(B * heads), dim3(256), lds, s, qkv, ntok, heads, vs, scale_log2e, out);
+    hipLaunchKernelGGL(attention_kernel<KB>, dim3(B * heads), dim3(256), lds, s, qkv, ntok, heads, scale_log2e, out);
     CH_LAUNCH_CHECK();
     return 0;
 }

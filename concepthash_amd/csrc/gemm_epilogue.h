@@ -102,37 +102,60 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // Two batches of 8 wave-instructions: ALL global loads of a batch are issued before the first store (the
+            // compiler cannot hoist them itself: loads and stores of `resid` may alias), so a wave has 8-16 requests in
+            // flight instead of one dependent round trip per row group.
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = i * 4 + lrow;
-                const int chunk = pos ^ (row & 15);
-                f32x4 v = *(const f32x4 *)(wave_lds + row * 256 + pos * 16);
-                const int m = m_base + pass * 64 + row;
-                if (m >= p.M) continue;
-                const int n = n_base + chunk * 4;
-                if constexpr (EPI == EPI_PATCH) {
-                    const int img = m / p.patches_per_img, pp = m - img * p.patches_per_img;
-                    const size_t orow = (size_t)img * p.tokens_per_img + 1 + pp;
-                    const f32x4 pe = *(const f32x4 *)(p.pos + (size_t)(1 + pp) * p.N + n);
-                    *(f32x4 *)(p.resid + orow * p.ldr + n) = v + pe;
-                } else if constexpr (EPI == EPI_BIAS_RESID) {
-                    f32x4 *hp = (f32x4 *)(p.resid + (size_t)m * p.ldr + n);
-                    *hp = *hp + v;
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *(uint2 *)(p.out_bf16 + (size_t)m * p.ldo + n) = o;
-                } else {  // EPI_SCALE_RESID: H += [addend] + scale * (acc + bias)
-                    f32x4 *hp = (f32x4 *)(p.resid + (size_t)m * p.ldr + n);
-                    f32x4 h = *hp + v * scale;
-                    if (p.addend) {
-                        const uint2 a = *(const uint2 *)(p.addend + (size_t)m * p.ld_addend + n);
-                        h[0] += bf2f((bf16_t)(a.x & 0xffff));
-                        h[1] += bf2f((bf16_t)(a.x >> 16));
-                        h[2] += bf2f((bf16_t)(a.y & 0xffff));
-                        h[3] += bf2f((bf16_t)(a.y >> 16));
+            for (int batch = 0; batch < 2; ++batch) {
+                f32x4 hv[8], lv[8];
+                uint2 av[8];
+                size_t off[8];
+                bool ok[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = (batch * 8 + i) * 4 + lrow;
+                    const int chunk = pos ^ (row & 15);
+                    const int m = m_base + pass * 64 + row;
+                    const int n = n_base + chunk * 4;
+                    ok[i] = m < p.M;
+                    const int mc = ok[i] ? m : p.M - 1;  // clamp: padding rows read a valid row, never stored
+                    lv[i] = *(const f32x4 *)(wave_lds + row * 256 + pos * 16);
+                    if constexpr (EPI == EPI_PATCH) {
+                        const int img = mc / p.patches_per_img, pp = mc - img * p.patches_per_img;
+                        off[i] = ((size_t)img * p.tokens_per_img + 1 + pp) * p.ldr + n;
+                        hv[i] = *(const f32x4 *)(p.pos + (size_t)(1 + pp) * p.N + n);
+                    } else {
+                        off[i] = (size_t)mc * p.ldr + n;
+                        hv[i] = *(const f32x4 *)(p.resid + off[i]);
+                        if constexpr (EPI == EPI_SCALE_RESID) {
+                            av[i] = make_uint2(0u, 0u);
+                            if (p.addend) av[i] = *(const uint2 *)(p.addend + (size_t)mc * p.ld_addend + n);
+                        }
                     }
-                    *hp = h;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (!ok[i]) continue;
+                    const f32x4 v = lv[i];
+                    if constexpr (EPI == EPI_PATCH) {
+                        *(f32x4 *)(p.resid + off[i]) = v + hv[i];
+                    } else if constexpr (EPI == EPI_BIAS_RESID) {
+                        *(f32x4 *)(p.resid + off[i]) = hv[i] + v;
+                        const int row = (batch * 8 + i) * 4 + lrow;
+                        const int m = m_base + pass * 64 + row;
+                        const int n = n_base + (pos ^ (row & 15)) * 4;
+                        uint2 o;
+                        o.x = pack_bf16x2(v[0], v[1]);
+                        o.y = pack_bf16x2(v[2], v[3]);
+                        *(uint2 *)(p.out_bf16 + (size_t)m * p.ldo + n) = o;
+                    } else {  // EPI_SCALE_RESID: H += [addend] + scale * (acc + bias)
+                        f32x4 h = hv[i] + v * scale;
+                        h[0] += bf2f((bf16_t)(av[i].x & 0xffff));
+                        h[1] += bf2f((bf16_t)(av[i].x >> 16));
+                        h[2] += bf2f((bf16_t)(av[i].y & 0xffff));
+                        h[3] += bf2f((bf16_t)(av[i].y >> 16));
+                        *(f32x4 *)(p.resid + off[i]) = h;
+                    }
                 }
             }
         }

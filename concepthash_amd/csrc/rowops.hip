@@ -87,6 +87,68 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void *x, int64_t r
     row_store_bf16(r, npass, lane, out + row * D);
 }
 
+// bf16 rows -> bf16 rows with 16-byte accesses: a lane owns 8 consecutive features per chunk, chunks lane and lane + 64
+// (D <= 1024).  Twice the bytes per memory instruction of the generic kernel above.
+__global__ __launch_bounds__(256) void layernorm_bf16_wide_kernel(const bf16_t *__restrict__ x, int64_t rows, int D,
+                                                                  const float *__restrict__ w, const float *__restrict__ b,
+                                                                  float eps, bf16_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int chunks = D >> 3;
+    float v[2][8];
+    bool on[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = lane + 64 * j;
+        on[j] = c < chunks;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (on[j]) u = *(const uint4 *)(x + row * D + c * 8);
+        const uint32_t ww[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[j][2 * e] = bf2f((bf16_t)(ww[e] & 0xffff));
+            v[j][2 * e + 1] = bf2f((bf16_t)(ww[e] >> 16));
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[j][e];  // inactive chunks hold zeros
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (on[j]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[j][e] - mean;
+                q += d * d;
+            }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (on[j]) {
+            const int c = lane + 64 * j;
+            const f32x4 w0 = *(const f32x4 *)(w + c * 8), w1 = *(const f32x4 *)(w + c * 8 + 4);
+            const f32x4 b0 = *(const f32x4 *)(b + c * 8), b1 = *(const f32x4 *)(b + c * 8 + 4);
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (v[j][e] - mean) * rstd * w0[e] + b0[e];
+                y[4 + e] = (v[j][4 + e] - mean) * rstd * w1[e] + b1[e];
+            }
+            uint4 o;
+            o.x = pack_bf16x2(y[0], y[1]);
+            o.y = pack_bf16x2(y[2], y[3]);
+            o.z = pack_bf16x2(y[4], y[5]);
+            o.w = pack_bf16x2(y[6], y[7]);
+            *(uint4 *)(out + row * D + c * 8) = o;
+        }
+}
+
 __global__ __launch_bounds__(256) void assemble_preln_kernel(float *H, int64_t rows, int ntok, int np, int D,
                                                              const float *cls_pos0, const float *ctx,
                                                              const float *pre_w, const float *pre_b,
@@ -163,6 +225,12 @@ int ch_layernorm_bf16(const bf16_t *x, int64_t rows, int D, const float *w, cons
                       hipStream_t s) {
     CH_REQUIRE(D % 128 == 0 && D <= 128 * MAXP, "layernorm: D must be a multiple of 128 and <= 1280");
     if (rows == 0) return 0;
+    if (D <= 1024) {
+        hipLaunchKernelGGL(layernorm_bf16_wide_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, s, x, rows, D, w, b,
+                           eps, out);
+        CH_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, s, x, rows, D, w, b,
                        eps, out);
     CH_LAUNCH_CHECK();
