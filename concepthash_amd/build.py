@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libconcepthash_hip.so")
-SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip"]
-HEADERS = ["ch_common.h", "kernels.h", os.path.join("..", "..", "include", "concepthash_hip.h")]
+SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_dp.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip"]
+HEADERS = ["ch_common.h", "kernels.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "concepthash_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -180,10 +180,15 @@ int ch_gemm_group_n(int M, int N, int K, int bm, int bn) {
 }
 
 // ---- dispatcher: the 256x256 ping-pong kernel when the shape allows it, this file's 128x128 kernel otherwise ---------
-static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128 two-phase), 2 force pp (256x256 ping-pong)
+static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128 two-phase), 2 force pp (256x256 ping-pong), 3 force dp
 void ch_gemm_set_variant(int v) { g_gemm_variant = v; }
 int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
     if (g_gemm_variant == 1) return ch_gemm_bf16_v1(p, epi, s);
     if (g_gemm_variant == 2) return ch_gemm_bf16_pp(p, epi, s);
-    return ch_gemm_pp_supported(p) ? ch_gemm_bf16_pp(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
+    if (g_gemm_variant == 3) return ch_gemm_bf16_dp(p, epi, s);
+    // Short-K GEMMs (the adapter up-projection, K = 384) are epilogue/HBM bound: two 128x128 workgroups per CU overlap one's
+    // read-modify-write epilogue with the other's K loop and win there (measured: 152 -> 97 us per launch in the pipeline);
+    // the 256x256 ping-pong kernel wins from K = 512 up.
+    static const int min_k = getenv("CH_GEMM_PP_MIN_K") ? atoi(getenv("CH_GEMM_PP_MIN_K")) : 512;
+    return (ch_gemm_pp_supported(p) && p.K >= min_k) ? ch_gemm_bf16_pp(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
 }
