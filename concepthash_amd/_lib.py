@@ -38,6 +38,7 @@ SIGNATURES = {
     "ch_debug_gemm": (c_int, [c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                               c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "ch_debug_set_gemm_variant": (None, [c_int32]),
+    "ch_debug_attention": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "ch_encode": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p]),
     "ch_encode_hidden": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

@@ -12,6 +12,8 @@ OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libconcepthash_hip.so")
 SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_dp.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip"]
 HEADERS = ["ch_common.h", "kernels.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "concepthash_hip.h")]
+# attention post-processes every MFMA result on the VALU: keep accumulators in VGPRs (no v_accvgpr_read round trips)
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -40,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", sp, "-o", op])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:

@@ -70,14 +70,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
     // transpose-read addressing: lane i = 4*qq + pp of a 16-lane group supplies row (key0 + qq), features 4pp..4pp+3 of the
     // 16-feature tile dt: chunk = dt*2 + (pp >> 1), half = pp & 1
     const int tq = fr >> 2, tp = fr & 3;
+    // (row & 7) of the rows a lane addresses is lane-constant: rows are kb*32 + fq*4 + tq (+16)
+    const int trow7 = ((fq & 1) << 2) | tq;
+    int voff[4];  // byte offset of this lane's 8-byte piece inside the 32-key block, per 16-feature tile dt
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        voff[dt] = (fq * 4 + tq) * 128 + (((dt * 2 + (tp >> 1)) ^ trow7) << 4) + (tp & 1) * 8;
+    const int koff0 = fr * 128 + ((fq ^ (fr & 7)) << 4), koff1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
 
     for (int qt = wid; qt < QT; qt += 4) {
         f32x4 st[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            const int row = kt * 16 + fr;
-            const bf16x8 k0 = *(const bf16x8 *)(Ks + row * 128 + (((0 + fq) ^ (row & 7)) << 4));
-            const bf16x8 k1 = *(const bf16x8 *)(Ks + row * 128 + (((4 + fq) ^ (row & 7)) << 4));
+            const bf16x8 k0 = *(const bf16x8 *)(Ks + kt * 2048 + koff0);
+            const bf16x8 k1 = *(const bf16x8 *)(Ks + kt * 2048 + koff1);
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
@@ -94,15 +100,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             qf1 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8 + 32);
         }
         // ---- softmax over keys for query (lane & 15): lane holds keys kt*16 + 4*fq + r
+        // keys >= ntok exist only in the last (KP - ntok + 15) / 16 <= 2 key tiles: mask those under a wave-uniform test
+#pragma unroll
+        for (int kt = KT - 2; kt < KT; ++kt)
+            if (kt >= 0 && kt * 16 + 16 > ntok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + fq * 4 + r >= ntok) st[kt][r] = -1e30f;
+            }
         float mx = -1e30f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + fq * 4 + r;
-                if (key >= ntok) st[kt][r] = -1e30f;
-                mx = fmaxf(mx, st[kt][r]);
-            }
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mxs = mx * scale_log2e;
@@ -133,19 +143,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             pf.u[1] = pack_bf16x2(st[2 * kb][2], st[2 * kb][3]);
             pf.u[2] = pack_bf16x2(st[2 * kb + 1][0], st[2 * kb + 1][1]);
             pf.u[3] = pack_bf16x2(st[2 * kb + 1][2], st[2 * kb + 1][3]);
-            const int r0 = kb * 32 + fq * 4 + tq;  // key row this lane addresses for elements 0..3; +16 for 4..7
-            const int r1 = r0 + 16;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const int chunk = dt * 2 + (tp >> 1);
                 union {
                     bf16x8 v;
                     v4s h[2];
                 } vf;
-                vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_v4s *)(Vs + r0 * 128 + ((chunk ^ (r0 & 7)) << 4) + (tp & 1) * 8));
-                vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_v4s *)(Vs + r1 * 128 + ((chunk ^ (r1 & 7)) << 4) + (tp & 1) * 8));
+                // keys 32kb + 4fq + 0..3 (elements 0..3) and + 16 (elements 4..7): immediate offsets off one lane base
+                vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Vs + kb * 4096 + voff[dt]));
+                vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Vs + kb * 4096 + 2048 + voff[dt]));
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
             }
         }

@@ -17,7 +17,13 @@ __device__ __forceinline__ bf16_t f2bf(float x) {
     return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ float bf2f(bf16_t x) { return __builtin_bit_cast(float, (uint32_t)x << 16); }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two fp32 -> packed bf16x2 (lo in bits 0..15) with ONE v_cvt_pk_bf16_f32 (the scalar-cast form costs 2 cvt + shift + or)
+typedef __bf16 ch_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float ch_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const ch_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ch_bf16x2_t));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

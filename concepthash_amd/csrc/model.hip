@@ -570,3 +570,8 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
     return ch_gemm_bf16(p, epi, s);
 }
 extern "C" void ch_debug_set_gemm_variant(int32_t v) { ch_gemm_set_variant(v); }
+
+extern "C" int ch_debug_attention(const void *qkv, int32_t B, int32_t ntok, int32_t heads, void *out, void *stream) {
+    CH_REQUIRE(qkv && out, "debug_attention: null pointer");
+    return ch_attention((const bf16_t *)qkv, B, ntok, heads, (bf16_t *)out, (hipStream_t)stream);
+}

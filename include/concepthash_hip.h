@@ -113,6 +113,8 @@ int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_alloc, const vo
                   int32_t N, int32_t K, int32_t epi, void *out_bf16, int32_t ldo, float *resid, int32_t ldr,
                   const float *scale_ptr, const void *addend, void *stream);
 void ch_debug_set_gemm_variant(int32_t variant);
+/* qkv [B*ntok, 3*heads*64] bf16 (q | k | v) -> out [B*ntok, heads*64] bf16: softmax(q k^T / 8) v per (image, head). */
+int ch_debug_attention(const void *qkv, int32_t B, int32_t ntok, int32_t heads, void *out, void *stream);
 
 /* Algorithmic FLOPs of one image through ch_encode (SURVEY.md section 8d formula). */
 double ch_model_flops_per_image(const ch_model *m);
