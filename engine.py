@@ -22,6 +22,22 @@ def dataloader(d, bs=256, shuffle=False, workers=-1, drop_last=False, sampler=No
                       pin_memory=workers > 0)
 
 
+class _SequentialSubset(torch.utils.data.Sampler):
+    def __init__(self, indices):
+        self.indices = list(indices)
+
+    def __iter__(self):
+        return iter(self.indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+
+def get_sequential_sampler(idxs):
+    """Fixed-order subset sampler (reference engine.py:36-38)."""
+    return _SequentialSubset(idxs)
+
+
 def seeding(seed):
     if seed != -1:
         torch.manual_seed(seed)

@@ -72,3 +72,51 @@ def test_shard_bounds():
     assert shard_bounds(10, 3) == [0, 4, 7, 10]
     assert shard_bounds(2, 4) == [0, 1, 2, 2, 2]
     assert shard_bounds(0, 2) == [0, 0, 0]
+
+
+# ---- the trainer's rank-sharded encode loop + gather (host logic, CPU stand-in model) --------------------------------------
+def _trainer_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from concepthash_amd.config import DictConfig
+        from trainers.coop import COOPTrainer
+        from utils.datasets import SyntheticHashingDataset
+
+        class FakeModel(torch.nn.Module):          # codes = a deterministic function of the image, so order is checkable
+            def forward(self, x):
+                codes = x.flatten(1)[:, :8].float()
+                z = torch.zeros(x.shape[0], 5)
+                return None, {"codes": codes, "logits_cont": z, "logits_bin": z}
+
+        class FakeCriterion(torch.nn.Module):
+            losses = {}
+
+            def forward(self, out, y):
+                return out["codes"].sum() * 0
+
+        cfg = DictConfig(device="cpu", batch_size=7, model=DictConfig(), dataset=DictConfig(multiclass=False))
+        tr = COOPTrainer(cfg)
+        tr.dataset = {"train": [], "test": SyntheticHashingDataset(5, size=23, image_size=4, seed=1),
+                      "db": SyntheticHashingDataset(5, size=40, image_size=4, seed=2)}
+        tr.load_dataloader()
+        tr.model, tr.criterion = FakeModel(), FakeCriterion()
+        meters, out = tr.inference_one_epoch("db", True)
+        torch.save({"codes": out["codes"], "labels": out["labels"], "n": meters["loss"].count}, os.path.join(out_dir, f"t{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_shards_encode_and_gathers_in_dataset_order(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from utils.datasets import SyntheticHashingDataset
+    mp.spawn(_trainer_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ds = SyntheticHashingDataset(5, size=40, image_size=4, seed=2)
+    want = torch.stack([ds[i][0].flatten()[:8] for i in range(40)])
+    labels = torch.stack([ds[i][1] for i in range(40)])
+    for r in range(2):
+        got = torch.load(tmp_path / f"t{r}.pt")
+        assert torch.equal(got["codes"], want) and torch.equal(got["labels"], labels) and got["n"] == 40

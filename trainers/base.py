@@ -32,6 +32,12 @@ class BaseTrainer:
         self.current_epoch = 0
         self.inference_datakey = ""
         self.device = torch.device(config["device"])
+        import torch.distributed as dist
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.distributed else 0
+        self.world_size = dist.get_world_size() if self.distributed else 1
+        if self.distributed and self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
 
     # ---- loading -------------------------------------------------------------------------------------------------
     def load_criterion(self):
@@ -91,9 +97,20 @@ class BaseTrainer:
         res = {}
         for key, vals in ret.items():
             if isinstance(vals[0], torch.Tensor):
-                res[key] = torch.cat(vals).cpu()  # one device->host copy per output per epoch
+                t = torch.cat(vals)
+                if self.distributed:              # ranks hold contiguous blocks -> rank-major concatenation == dataset order
+                    from concepthash_amd.distributed import _all_gather_ragged
+                    t, _ = _all_gather_ragged(t.contiguous())
+                res[key] = t.cpu()                # one device->host copy per output per epoch
             else:
                 res[key] = np.concatenate(vals)
+        if self.distributed:                      # meters: sample-weighted average over ranks
+            import torch.distributed as dist
+            for k in sorted(meters):
+                v = torch.tensor([meters[k].sum, float(meters[k].count)], dtype=torch.float64, device=self.device)
+                dist.all_reduce(v)
+                meters[k].sum, meters[k].count = float(v[0]), int(v[1])
+                meters[k].avg = meters[k].sum / max(meters[k].count, 1)
         return meters, res
 
     # ---- training: out of scope ----------------------------------------------------------------------------------

@@ -24,9 +24,19 @@ class COOPTrainer(BaseTrainer):
         logging.info("Number of Query data: %d; Database data: %d", len(self.dataset["test"]), len(self.dataset["db"]))
 
     def load_dataloader(self):
+        """One process per GPU: every rank encodes a contiguous block of each split (SURVEY.md section 8e -- encode shards by
+        image, no collective in the loop); `inference_one_epoch` all-gathers the per-rank outputs afterwards."""
         assert self.dataset is not None
         bs = self.config.batch_size
-        self.dataloader = {k: engine.dataloader(self.dataset[k], bs, shuffle=False, drop_last=False) for k in ("test", "db")}
+        self.dataloader = {}
+        for k in ("test", "db"):
+            ds = self.dataset[k]
+            sampler = None
+            if self.world_size > 1 and len(ds) > 0:
+                from concepthash_amd.distributed import shard_bounds
+                b = shard_bounds(len(ds), self.world_size)
+                sampler = engine.get_sequential_sampler(list(range(b[self.rank], b[self.rank + 1])))
+            self.dataloader[k] = engine.dataloader(ds, bs, shuffle=False, drop_last=False, sampler=sampler)
         self.dataloader["train"] = []
 
     def parse_model_output(self, output):
