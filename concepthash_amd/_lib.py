@@ -38,6 +38,7 @@ SIGNATURES = {
     "ch_debug_gemm": (c_int, [c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                               c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "ch_debug_set_gemm_variant": (None, [c_int32]),
+    "ch_debug_adapter": (c_int, [c_void_p] * 2 + [c_int32] * 3 + [c_void_p] * 10 + [c_int32, c_void_p]),
     "ch_debug_attention": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "ch_encode": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p]),
@@ -56,7 +57,7 @@ SIGNATURES = {
 }
 
 CATEGORIES = ("im2col", "gemm_patch", "rowops", "gemm_qkv", "attention", "gemm_out", "gemm_down", "gemm_up", "gemm_fc1",
-              "gemm_fc2", "head", "end")
+              "gemm_fc2", "head", "adapter_fused", "end")
 
 _lib = None
 

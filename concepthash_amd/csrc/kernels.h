@@ -41,6 +41,24 @@ void ch_gemm_set_variant(int v);
 // n-tiles per weight group for a block tile of bn columns: minimises X re-fetches + W re-fetches
 int ch_gemm_group_n(int M, int N, int K, int bm, int bn);
 
+// ---- adapter_fused.hip --------------------------------------------------------------------------------------------
+struct AdapterParams {
+    const bf16_t *A;      // sub-block output a [M, D] bf16 (read twice: statistics + MFMA operand, and as the residual addend)
+    float *H;             // residual stream [M, D] fp32, updated in place
+    int M, D, bpad;
+    const bf16_t *Wd;     // [bpad, D]  bf16(Wd * gamma), zero rows past b
+    const float *c, *d;   // [bpad]     LayerNorm fold constants (see adapter_fused.hip)
+    const bf16_t *Wu;     // [D, bpad]  up_proj weight, zero columns past b
+    const float *bu;      // [D]
+    const float *scale;   // device scalar
+    float eps;
+    int dbg;              // timing-only ablations (bit 1: skip phase 0, 2: skip phase A loop, 4: skip phase C loop, 8: skip epilogues)
+};
+bool ch_adapter_fused_supported(int D, int bpad);
+int ch_adapter_fused(const AdapterParams &p, hipStream_t s);
+int ch_fold_ln(const float *Wd, const float *bd, const float *gamma, const float *beta, int b, int bpad, int D, bf16_t *Wdf,
+               float *c, float *d, hipStream_t s);
+
 // ---- rowops.hip ----------------------------------------------------------------------------------------------
 // im2col for the patch-embed conv (k = s = patch, no bias): out[b*Np + p][c*pp + ky*patch + kx], zero padded to Kp.
 int ch_im2col(const void *images, int image_dtype, int B, int image, int patch, int Kp, bf16_t *out, hipStream_t s);

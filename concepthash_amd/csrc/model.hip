@@ -19,6 +19,9 @@ namespace {
 struct AdapterW {
     const float *ln_w = nullptr, *ln_b = nullptr, *down_b = nullptr, *up_b = nullptr, *scale = nullptr;
     const bf16_t *down_w = nullptr, *up_w = nullptr;
+    // fused path (adapter_fused.hip): LayerNorm folded into the down projection
+    const bf16_t *down_wf = nullptr;
+    const float *fold_c = nullptr, *fold_d = nullptr;
 };
 struct LayerW {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *out_b, *fc1_b, *fc2_b;
@@ -42,6 +45,9 @@ struct ch_model {
     const float *post_w = nullptr, *post_b = nullptr, *vis_proj = nullptr;
     // launch profiler (bench.py): one hipEvent before every launch + one after the last; elapsed(e[j], e[j+1]) is
     // attributed to launch j's category
+    // adapter_fused.hip is correct (parity-tested) but measured slower than the three-launch chain on MI355X (200 vs 179 us
+    // per call at B=256: its HBM phases and MFMA phases do not overlap) -> opt-in only
+    bool use_fused_adapter = false;
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_cat;
@@ -199,6 +205,17 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
             aw.down_b = db;
             aw.up_w = uw;
             aw.up_b = B.f32(ap + "up_proj.bias", D);
+            if (B.ok && ch_adapter_fused_supported(D, m->bpad)) {
+                const float *wd32 = B.f32(ap + "down_proj.weight", (int64_t)b * D);
+                const float *bd32 = B.f32(ap + "down_proj.bias", b);
+                bf16_t *wf = (bf16_t *)B.alloc(sizeof(bf16_t) * (size_t)m->bpad * D);
+                float *fc = (float *)B.alloc(sizeof(float) * m->bpad), *fd = (float *)B.alloc(sizeof(float) * m->bpad);
+                if (!B.ok) break;
+                if (ch_fold_ln(wd32, bd32, aw.ln_w, aw.ln_b, b, m->bpad, D, wf, fc, fd, B.s)) B.ok = false;
+                aw.down_wf = wf;
+                aw.fold_c = fc;
+                aw.fold_d = fd;
+            }
         }
     }
     if (!B.ok) return 4;
@@ -368,6 +385,14 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
     };
     auto adapter = [&](const AdapterW &aw) -> int {
         if (!aw.down_w) return 0;
+        if (aw.down_wf && m->use_fused_adapter) {
+            // LN + down + GELU + up + residual in one launch (adapter_fused.hip); a = m->A (bf16), H updated in place
+            mark(m, CH_CAT_ADAPTER, 4.0 * rows * (double)D * c.adapter_dim, s);
+            AdapterParams ap{};
+            ap.A = m->A; ap.H = m->H; ap.M = rows; ap.D = D; ap.bpad = m->bpad; ap.Wd = aw.down_wf; ap.c = aw.fold_c;
+            ap.d = aw.fold_d; ap.Wu = aw.up_w; ap.bu = aw.up_b; ap.scale = aw.scale; ap.eps = 1e-5f;
+            return ch_adapter_fused(ap, s);
+        }
         // Adapter (models/layers/adapter.py:46-60) on the bf16 copy of the sub-block output held in m->A
         mark(m, CH_CAT_ROWOPS, 0.0, s);
         if (int e = ch_layernorm_bf16(m->A, rows, D, aw.ln_w, aw.ln_b, 1e-5f, m->Xn, s)) return e;
@@ -439,6 +464,7 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
     m->np = grid * grid;
     m->ntok = 1 + m->np + cfg->ncontext;
     m->Kp = (int)round_up64(3 * cfg->patch * cfg->patch, 64);
+    if (const char *e = getenv("CH_FUSED_ADAPTER")) m->use_fused_adapter = atoi(e) != 0;
     m->bpad = (int)round_up64(cfg->adapter_dim, 128);
     int e = build_model(m, tensors, ntensors);
     if (e == 0 && hipDeviceSynchronize() != hipSuccess) {
@@ -574,4 +600,17 @@ extern "C" void ch_debug_set_gemm_variant(int32_t v) { ch_gemm_set_variant(v); }
 extern "C" int ch_debug_attention(const void *qkv, int32_t B, int32_t ntok, int32_t heads, void *out, void *stream) {
     CH_REQUIRE(qkv && out, "debug_attention: null pointer");
     return ch_attention((const bf16_t *)qkv, B, ntok, heads, (bf16_t *)out, (hipStream_t)stream);
+}
+
+extern "C" int ch_debug_adapter(const void *A, float *H, int32_t M, int32_t D, int32_t b, const float *Wd, const float *bd,
+                                const float *gamma, const float *beta, const void *Wu_bf16_padded, const float *bu,
+                                const float *scale, void *work_wdf, float *work_c, float *work_d, int32_t dbg, void *stream) {
+    // Wd [b, D] fp32, Wu [D, bpad] bf16 (already padded); work_*: caller scratch for the folded weights ([bpad, D] bf16, [bpad] x2)
+    const int bpad = (int)round_up64(b, 128);
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = ch_fold_ln(Wd, bd, gamma, beta, b, bpad, D, (bf16_t *)work_wdf, work_c, work_d, s)) return e;
+    AdapterParams p{};
+    p.A = (const bf16_t *)A; p.H = H; p.M = M; p.D = D; p.bpad = bpad; p.Wd = (const bf16_t *)work_wdf; p.c = work_c; p.d = work_d;
+    p.Wu = (const bf16_t *)Wu_bf16_padded; p.bu = bu; p.scale = scale; p.eps = 1e-5f; p.dbg = dbg;
+    return ch_adapter_fused(p, s);
 }

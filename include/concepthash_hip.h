@@ -100,7 +100,7 @@ int ch_encode_hidden(ch_model *m, const void *images, int32_t image_dtype, int32
  * (ms), the number of launches and their algorithmic FLOPs. */
 enum {
     CH_CAT_IM2COL = 0, CH_CAT_GEMM_PATCH, CH_CAT_ROWOPS, CH_CAT_GEMM_QKV, CH_CAT_ATTENTION, CH_CAT_GEMM_OUT,
-    CH_CAT_GEMM_DOWN, CH_CAT_GEMM_UP, CH_CAT_GEMM_FC1, CH_CAT_GEMM_FC2, CH_CAT_HEAD, CH_CAT_END, CH_NCAT
+    CH_CAT_GEMM_DOWN, CH_CAT_GEMM_UP, CH_CAT_GEMM_FC1, CH_CAT_GEMM_FC2, CH_CAT_HEAD, CH_CAT_ADAPTER, CH_CAT_END, CH_NCAT
 };
 int ch_model_profile_begin(ch_model *m, int32_t max_launches);
 int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *launches_per_cat, double *flops_per_cat);
@@ -113,6 +113,11 @@ int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_alloc, const vo
                   int32_t N, int32_t K, int32_t epi, void *out_bf16, int32_t ldo, float *resid, int32_t ldr,
                   const float *scale_ptr, const void *addend, void *stream);
 void ch_debug_set_gemm_variant(int32_t variant);
+/* One fused adapter call H += a + scale * (GELU(LN(a) Wd^T + bd) Wu^T + bu) on caller buffers (a [M,D] bf16, H [M,D] fp32,
+ * Wd [b,D] fp32, Wu [D, roundup(b,128)] bf16 zero-padded); work_* are caller scratch for the LayerNorm-folded weights. */
+int ch_debug_adapter(const void *A, float *H, int32_t M, int32_t D, int32_t b, const float *Wd, const float *bd,
+                     const float *gamma, const float *beta, const void *Wu_bf16_padded, const float *bu, const float *scale,
+                     void *work_wdf, float *work_c, float *work_d, int32_t dbg, void *stream);
 /* qkv [B*ntok, 3*heads*64] bf16 (q | k | v) -> out [B*ntok, heads*64] bf16: softmax(q k^T / 8) v per (image, head). */
 int ch_debug_attention(const void *qkv, int32_t B, int32_t ntok, int32_t heads, void *out, void *stream);
 

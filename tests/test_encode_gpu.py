@@ -136,3 +136,21 @@ def test_errors_are_loud(dev):
     bad["hash_bn.weight"] = torch.zeros(3)
     with pytest.raises(RuntimeError, match="hash_bn.weight"):
         _encoder(bad, cfg["heads"])
+
+
+def test_fused_adapter_kernel_matches_unfused_chain(dev, monkeypatch):
+    """adapter_fused.hip (opt-in, CH_FUSED_ADAPTER=1): LayerNorm folded into the down projection, bottleneck in LDS.
+    Same inputs, different rounding points -> compare against the oracle with the encode tolerances, and against the
+    default three-launch chain."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_b16"])
+    cfg["L"] = 3
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    x = eo.synthetic_images(3, cfg["image"])
+    base = _encoder(sd, cfg["heads"], max_batch=4).encode(x.to(dev))["codes"].cpu()
+    monkeypatch.setenv("CH_FUSED_ADAPTER", "1")
+    fused = _encoder(sd, cfg["heads"], max_batch=4).encode(x.to(dev))["codes"].cpu()
+    monkeypatch.delenv("CH_FUSED_ADAPTER")
+    ref = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False)["codes"]
+    assert not torch.equal(fused, base)                       # really a different code path
+    assert _rel_err(fused, ref) < 4e-2 and _rel_err(fused, base) < 2e-2
