@@ -60,6 +60,7 @@ def main():
     if world != args.gpus:
         log(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal: several ranks may share the one visible GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -67,7 +68,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")   # nccl = RCCL over xGMI; gloo only for rehearsals on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from concepthash_amd import retrieval as rt
     from concepthash_amd.encoder import ConceptHashEncoder
@@ -163,6 +168,27 @@ def main():
             "kernel_ms_per_step": {c: round(p["ms"] / args.steps, 4) for c, p in prof.items()},
             "kernel_ms_per_step_total": round(total_ms / args.steps, 3),
         }
+
+    # ---- PCIe-inclusive variant (outside the timed region): the same step fed from pinned host memory each time -----
+    if rank == 0:
+        host = images.cpu().pin_memory()
+        dev_in = torch.empty_like(images)
+
+        def step_h2d():
+            dev_in.copy_(host, non_blocking=True)
+            return enc.encode(dev_in, want=("codes", "packed"))
+
+        step_h2d()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step_h2d()
+        torch.cuda.synchronize()
+        pcie_s = (time.perf_counter() - t0) / 5
+        result["pcie_inclusive"] = {"images_per_s": round(B / pcie_s, 1), "ms_per_step": round(pcie_s * 1e3, 3),
+                                    "note": f"encode only, batch copied from pinned host memory every step on the same stream "
+                                            f"({host.numel() * 2 / 2**20:.0f} MiB bf16, no overlap); never used for `value`"}
+        del host, dev_in
 
     # ---- Hamming scan at BASELINE config-5 size (outside the timed region; per rank, reported by rank 0) -----------
     if rank == 0 and not args.no_hamming_scan:
