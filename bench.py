@@ -100,11 +100,12 @@ def main():
             q = allq
         idx, dst = rt.hamming_topk(q, gallery, TOPK, g_index_base=rank * GALLERY_ROWS)
         if world > 1:
-            li = torch.empty(world, q.shape[0], TOPK, dtype=torch.int64, device=dev)
-            ld = torch.empty(world, q.shape[0], TOPK, dtype=torch.int32, device=dev)
+            nq = q.shape[0]        # output = concatenation along dim 0 (the form every backend accepts), viewed per shard
+            li = torch.empty(world * nq, TOPK, dtype=torch.int64, device=dev)
+            ld = torch.empty(world * nq, TOPK, dtype=torch.int32, device=dev)
             dist.all_gather_into_tensor(li, idx)
             dist.all_gather_into_tensor(ld, dst)
-            idx, dst = rt.topk_merge(li, ld)
+            idx, dst = rt.topk_merge(li.view(world, nq, TOPK), ld.view(world, nq, TOPK))
         return out["codes"], idx, dst
 
     for _ in range(args.warmup):
