@@ -77,9 +77,7 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(const uint64_t *__res
 #pragma unroll
     for (int i = 0; i < KREG; ++i) list[i] = 0xFFFFFFFFu;
     const uint64_t *gp = g + g0 * W;
-    for (int j = 0; j < n; ++j) {
-        const int d = hamming<W>(qw, gp + (size_t)j * W);
-        uint32_t key = ((uint32_t)d << KEY_SHIFT) | (uint32_t)j;
+    auto insert = [&](uint32_t key) {
         if (__builtin_amdgcn_ballot_w64(key < list[KREG - 1]) != 0ull) {
 #pragma unroll
             for (int i = 0; i < KREG; ++i) {
@@ -88,7 +86,36 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(const uint64_t *__res
                 list[i] = lo;
             }
         }
+    };
+    // four gallery rows per trip: one wide scalar load (the next block is requested before this one is consumed), four
+    // XOR/popcount keys, ONE threshold test on their minimum; the insertion network runs only if some lane beats its list.
+    constexpr int UB = 4;
+    uint64_t cur[UB * W], nxt[UB * W];
+    int j = 0;
+    if (n >= UB) {
+#pragma unroll
+        for (int t = 0; t < UB * W; ++t) cur[t] = gp[t];
     }
+    for (; j + UB <= n; j += UB) {
+        const bool more = j + 2 * UB <= n;
+        if (more) {
+#pragma unroll
+            for (int t = 0; t < UB * W; ++t) nxt[t] = gp[(size_t)(j + UB) * W + t];
+        }
+        uint32_t key[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) key[u] = ((uint32_t)hamming<W>(qw, cur + u * W) << KEY_SHIFT) | (uint32_t)(j + u);
+        const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+        if (__builtin_amdgcn_ballot_w64(kmin < list[KREG - 1]) != 0ull) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) insert(key[u]);
+        }
+        if (more) {
+#pragma unroll
+            for (int t = 0; t < UB * W; ++t) cur[t] = nxt[t];
+        }
+    }
+    for (; j < n; ++j) insert(((uint32_t)hamming<W>(qw, gp + (size_t)j * W) << KEY_SHIFT) | (uint32_t)j);
     if (qi < Qn) {
         uint32_t *o = part + ((size_t)seg * Qn + qi) * k;
 #pragma unroll
