@@ -41,7 +41,7 @@ SIGNATURES = {
     "ch_debug_adapter": (c_int, [c_void_p] * 2 + [c_int32] * 3 + [c_void_p] * 10 + [c_int32, c_void_p]),
     "ch_debug_attention": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "ch_encode": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_void_p]),
+                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_encode_hidden": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "ch_pack_sign": (c_int, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "ch_hamming_dist": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

@@ -29,7 +29,7 @@ typedef __attribute__((address_space(3))) v4s lds_v4s;
 
 template <int KB>  // number of 32-key blocks (keys padded to KB*32)
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ qkv, int ntok, int heads, float scale_log2e,
-                                                        bf16_t *__restrict__ out) {
+                                                        bf16_t *__restrict__ out, float *__restrict__ cattn, int ncon) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = KB * 2;   // 16-key tiles
     constexpr int KP = KB * 32;  // padded keys
@@ -128,6 +128,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+        // optional interpretability tap (last layer only): softmax rows of the `ncon` concept tokens over the patch tokens,
+        // = attn_cache[-1][:, :, -Q:, 1:-Q] of the reference (models/arch/coop.py:481-482, models/loss/coop.py:164-176)
+        if (cattn != nullptr && cur_valid && cur_q >= ntok - ncon) {
+            const int np = ntok - ncon - 1;
+            float *dst = cattn + (((size_t)b * heads + h) * ncon + (cur_q - (ntok - ncon))) * np;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + fq * 4 + r;
+                    if (key >= 1 && key <= np) dst[key - 1] = st[kt][r] * inv;
+                }
+        }
 
         // ---- O^T = V^T P^T ; logical k = 8*fq + j  <->  key 32*kb + (j < 4 ? 4*fq + j : 16 + 4*fq + j - 4)
         f32x4 o[4];
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
 }
 
 template <int KB>
-int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s) {
+int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, float *cattn, int ncon, hipStream_t s) {
     const int KP = KB * 32;
     const size_t lds = (size_t)KP * 128 * 2;
     CH_REQUIRE(lds <= 160 * 1024, "attention: sequence too long for the LDS-resident K/V kernel");
@@ -180,26 +193,26 @@ int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipS
         attr_set = true;
     }
     const float scale_log2e = 0.125f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e), head_dim = 64
-    hipLaunchKernelGGL(attention_kernel<KB>, dim3(B * heads), dim3(256), lds, s, qkv, ntok, heads, scale_log2e, out);
+    hipLaunchKernelGGL(attention_kernel<KB>, dim3(B * heads), dim3(256), lds, s, qkv, ntok, heads, scale_log2e, out, cattn, ncon);
     CH_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
-int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s) {
+int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s, float *cattn, int ncon) {
     CH_REQUIRE(B > 0 && ntok > 0 && heads > 0, "attention: empty problem");
     const int KB = (ntok + 31) / 32;
     switch (KB) {
-        case 1: return launch_attn<1>(qkv, B, ntok, heads, out, s);
-        case 2: return launch_attn<2>(qkv, B, ntok, heads, out, s);
-        case 3: return launch_attn<3>(qkv, B, ntok, heads, out, s);
-        case 4: return launch_attn<4>(qkv, B, ntok, heads, out, s);
-        case 5: return launch_attn<5>(qkv, B, ntok, heads, out, s);
-        case 6: return launch_attn<6>(qkv, B, ntok, heads, out, s);
-        case 7: return launch_attn<7>(qkv, B, ntok, heads, out, s);
-        case 8: return launch_attn<8>(qkv, B, ntok, heads, out, s);
-        case 9: return launch_attn<9>(qkv, B, ntok, heads, out, s);
+        case 1: return launch_attn<1>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        case 2: return launch_attn<2>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        case 3: return launch_attn<3>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        case 4: return launch_attn<4>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        case 5: return launch_attn<5>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        case 6: return launch_attn<6>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        case 7: return launch_attn<7>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        case 8: return launch_attn<8>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        case 9: return launch_attn<9>(qkv, B, ntok, heads, out, cattn, ncon, s);
     }
     ch_set_error("attention: more than 288 tokens per image is not supported");
     return 2;

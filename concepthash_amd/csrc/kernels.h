@@ -76,7 +76,9 @@ int ch_layernorm_bf16(const bf16_t *x, int64_t rows, int D, const float *w, cons
 
 // ---- attention.hip -------------------------------------------------------------------------------------------
 // qkv [B*ntok, 3D] bf16 (q | k | v, head h at columns h*64), out [B*ntok, D] bf16.  head_dim == 64.
-int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s);
+// cattn (optional): [B, heads, ncon, ntok - ncon - 1] fp32 softmax rows of the last `ncon` tokens over tokens 1 .. ntok-ncon-1
+int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s, float *cattn = nullptr,
+                 int ncon = 0);
 
 // ---- head.hip ------------------------------------------------------------------------------------------------
 struct HeadParams {

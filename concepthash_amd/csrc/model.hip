@@ -352,7 +352,8 @@ inline void mark(ch_model *m, int cat, double flops, hipStream_t s) {
 }
 
 // encoder up to `nlayers` layers; leaves the residual stream in m->H
-int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nlayers, hipStream_t s) {
+int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nlayers, hipStream_t s,
+                float *concept_attn = nullptr) {
     const ch_model_config &c = m->cfg;
     const int D = c.dim, M = c.ffn, ntok = m->ntok, np = m->np;
     const int rows = B * ntok;
@@ -412,7 +413,8 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
         }
         if (int e = gemm(CH_CAT_GEMM_QKV, 3 * D, D, m->Xn, w.qkv_w, 3 * D, D, w.qkv_b, EPI_BIAS, m->QKV, 3 * D, nullptr)) return e;
         mark(m, CH_CAT_ATTENTION, 4.0 * B * (double)ntok * ntok * D, s);
-        if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s)) return e;
+        if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, i == nlayers - 1 ? concept_attn : nullptr, c.ncontext))
+            return e;
         // h = r + a  (+ adapter_1(a) below);  a kept as bf16 in m->A for the adapter branch
         // with adapters the residual add of `a` is deferred to the adapter's up-projection epilogue (see adapter())
         if (int e = gemm(CH_CAT_GEMM_OUT, D, D, m->AO, w.out_w, D, D, w.out_b, w.ad[0].down_w ? EPI_BIAS : EPI_BIAS_RESID, m->A,
@@ -499,14 +501,14 @@ extern "C" double ch_model_flops_per_image(const ch_model *m) {
 
 extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, float *out_codes,
                          uint64_t *out_packed, float *out_logits_cont, float *out_logits_bin, float *out_logits_concept,
-                         float *out_hash_features, float *out_image_features, void *stream) {
+                         float *out_hash_features, float *out_image_features, float *out_concept_attn, void *stream) {
     CH_REQUIRE(m != nullptr && images != nullptr && out_codes != nullptr, "null model / images / out_codes");
     CH_REQUIRE(image_dtype == 0 || image_dtype == 1, "image_dtype must be 0 (fp32) or 1 (bf16)");
     CH_REQUIRE(B >= 1 && B <= m->cfg.max_batch, "batch outside [1, max_batch]");
     CH_REQUIRE(!out_logits_concept || m->concept_cent_l2, "model has no concept classifier (concept_ce.centroids)");
     CH_REQUIRE(!out_image_features || m->vis_proj, "model has no post_layernorm / visual_projection");
     hipStream_t s = (hipStream_t)stream;
-    if (int e = run_encoder(m, images, image_dtype, B, m->cfg.layers, s)) return e;
+    if (int e = run_encoder(m, images, image_dtype, B, m->cfg.layers, s, out_concept_attn)) return e;
     const ch_model_config &c = m->cfg;
     HeadParams p{};
     p.H = m->H; p.B = B; p.ntok = m->ntok; p.D = c.dim; p.Q = c.ncontext; p.nbit = c.nbit; p.C = c.nclass; p.P = c.proj_dim;

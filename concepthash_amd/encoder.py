@@ -130,12 +130,13 @@ class ConceptHashEncoder:
             raise ValueError(f"images are on {images.device}, the model is on {self.device}")
 
     def encode(self, images: torch.Tensor, want: Iterable[str] = ("codes", "packed"), stream=None) -> Dict[str, torch.Tensor]:
-        """want: subset of {codes, packed, logits_cont, logits_bin, logits_concept, hash_features, image_features};
+        """want: subset of {codes, packed, logits_cont, logits_bin, logits_concept, hash_features, image_features, concept_attn};
         'codes' is always produced.  Batches larger than max_batch are processed in chunks on the same stream."""
         self._check_images(images)
         images = images.contiguous()
         want = set(want) | {"codes"}
-        unknown = want - {"codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features", "image_features"}
+        unknown = want - {"codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features", "image_features",
+                          "concept_attn"}
         if unknown:
             raise KeyError(f"unknown outputs {sorted(unknown)}")
         B = images.shape[0]
@@ -152,6 +153,9 @@ class ConceptHashEncoder:
             out["hash_features"] = torch.empty(B, c["ncontext"], c["dim"], dtype=torch.float32, device=dev)
         if "image_features" in want:
             out["image_features"] = torch.empty(B, c["proj_dim"], dtype=torch.float32, device=dev)
+        if "concept_attn" in want:   # last-layer attention of the concept tokens over the patch tokens [B, heads, Q, Np]
+            out["concept_attn"] = torch.empty(B, c["heads"], c["ncontext"], self.ntok - 1 - c["ncontext"], dtype=torch.float32,
+                                              device=dev)
         concept_chunks = []
         dt = 0 if images.dtype == torch.float32 else 1
         sp = _lib.stream_ptr(stream)
@@ -169,7 +173,7 @@ class ConceptHashEncoder:
 
                 _lib.check(self.lib.ch_encode(self._h, _lib.ptr(images[b0:b1]), dt, b1 - b0, sl("codes"), sl("packed"),
                                               sl("logits_cont"), sl("logits_bin"), _lib.ptr(lc), sl("hash_features"),
-                                              sl("image_features"), sp), "ch_encode")
+                                              sl("image_features"), sl("concept_attn"), sp), "ch_encode")
         if concept_chunks:
             out["logits_concept"] = concept_chunks[0] if len(concept_chunks) == 1 else torch.cat(concept_chunks, dim=1)
         return out

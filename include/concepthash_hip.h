@@ -83,10 +83,12 @@ size_t ch_model_device_bytes(const ch_model *m);
  *   out_logits_concept [Q,B,C] fp32 (coop.py:269-276)                                      (optional)
  *   out_hash_features  [B,Q,D] fp32 raw last-layer concept-token states (coop.py:503-509) (optional)
  *   out_image_features [B,P] fp32 pooled CLS -> post-LN -> visual_projection (coop.py:498-501) (optional)
+ *   out_concept_attn   [B,heads,Q,Np] fp32 last-layer attention of the Q concept tokens over the Np patch tokens
+ *                      = attn_cache[-1][:, :, -Q:, 1:-Q] (coop.py:481-482; consumer models/loss/coop.py:164-176)  (optional)
  * B must be in [1, max_batch]. */
 int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, float *out_codes,
               uint64_t *out_packed, float *out_logits_cont, float *out_logits_bin, float *out_logits_concept,
-              float *out_hash_features, float *out_image_features, void *stream);
+              float *out_hash_features, float *out_image_features, float *out_concept_attn, void *stream);
 
 /* Parity tap (tests only): run the encoder for `layer` layers (0 = embeddings + concept tokens + pre-LN) and copy the
  * fp32 residual stream [B*N, D], N = 1 + patches + Q, to out_hidden.  Mirrors `image_hidden_states[layer]`

@@ -103,6 +103,7 @@ class LGHWithoutText(nn.Module):
             self.trainable_params["concept_pe"] = self.concept_pe
             self.concept_ce = CosSim(D, nclass)
             self.trainable_params["concept_ce_centroids"] = self.concept_ce.centroids
+        self.return_concept_attention = bool(kwargs.get("return_concept_attention", False))
         self._engine: Optional[ConceptHashEncoder] = None
         self._engine_key = None
         self.eval()
@@ -177,6 +178,8 @@ class LGHWithoutText(nn.Module):
             raise RuntimeError("LGHWithFixedPrompt.forward needs a GPU tensor; there is no CPU fallback")
         eng = self._ensure_engine(x.device)
         want = ["codes", "logits_cont", "logits_bin", "hash_features"]
+        if self.return_concept_attention:
+            want.append("concept_attn")
         if self.concept_reg:
             want.append("logits_concept")
         if eng.has_pooled:
@@ -186,6 +189,9 @@ class LGHWithoutText(nn.Module):
                    # the reference returns every layer's hidden state / attention map; the fused path does not
                    # materialise them (retrieval never reads them)
                    "image_hidden_states": (), "hash_features": out["hash_features"], "attn_cache": None}
+        if self.return_concept_attention:
+            # what the reference's consumers slice out of attn_cache[-1]: [:, :, -Q:, 1:-Q]  (B, heads, Q, Np)
+            outputs["concept_attention"] = out["concept_attn"]
         if self.concept_reg:
             outputs["logits_concept"] = out["logits_concept"]
         return out.get("image_features"), outputs

@@ -154,3 +154,24 @@ def test_fused_adapter_kernel_matches_unfused_chain(dev, monkeypatch):
     ref = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False)["codes"]
     assert not torch.equal(fused, base)                       # really a different code path
     assert _rel_err(fused, ref) < 4e-2 and _rel_err(fused, base) < 2e-2
+
+
+def test_concept_token_attention_maps(dev):
+    """Optional interpretability output: last-layer attention of the Q concept tokens over the patch tokens, i.e. the slice
+    attn_cache[-1][:, :, -Q:, 1:-Q] the reference's visualisation / attention-diversity code consumes."""
+    from oracle import encoder_oracle as eo
+    sd, z = load_fixture("encode_hd64")
+    heads = int(z["meta/heads"])
+    x = torch.from_numpy(z["in/images"])
+    enc = _encoder(sd, heads, max_batch=4)
+    out = enc.encode(x.to(dev), want=("codes", "concept_attn"))
+    st = {}
+    eo.encode(sd, x, heads=heads, stages=st)
+    Q = 4
+    ref = st["attn1"][:, :, -Q:, 1:-Q]                      # last of the 2 layers
+    got = out["concept_attn"].cpu()
+    assert got.shape == ref.shape == (4, heads, Q, 16)
+    assert float((got - ref).abs().max()) < 2e-3            # probabilities; bf16 q/k operands
+    assert torch.allclose(got.sum(-1), ref.sum(-1), atol=2e-3)
+    base = enc.encode(x.to(dev))["codes"]
+    assert torch.equal(base, out["codes"])                  # the tap does not perturb the encode

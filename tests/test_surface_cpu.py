@@ -149,3 +149,31 @@ def test_utils_hashing_rejects_unbuilt_options_before_touching_the_gpu():
     with pytest.raises(NotImplementedError):
         hashing.calculate_mAP(c, l, c, l, -1, threshold=0.5)
     assert hashing.pr_curve_points(5994)[-1] == 5994 and hashing.pr_curve_points(5994)[:4] == [1, 2, 5, 10]
+
+
+def test_clip_backbone_from_local_hf_directory(tmp_path):
+    """`model.backbone.name=<local dir>` (HF layout: config.json + model.safetensors) replaces the reference's
+    from_pretrained(<hub name>) (models/backbone/clip.py:112-118), which needs the network."""
+    import json
+    from safetensors.torch import save_file
+    from models.backbone.clip import CLIP, CLIPModelShell
+    dims = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, patch_size=16,
+                image_size=64, projection_dim=64, hidden_act="quick_gelu")
+    torch.manual_seed(5)
+    src = CLIPModelShell(dims, text_dim=32)
+    sd = {k: v.detach().clone() + 0.01 for k, v in src.state_dict().items()}
+    sd["text_model.embeddings.token_embedding.weight"] = torch.zeros(4, 32)      # extra text-tower tensors are ignored
+    d = tmp_path / "clip_local"
+    d.mkdir()
+    save_file(sd, str(d / "model.safetensors"))
+    json.dump({"projection_dim": 64, "vision_config": dict(dims), "text_config": {"hidden_size": 32}}, open(d / "config.json", "w"))
+    bb = CLIP(str(d))
+    got = bb.model.state_dict()
+    for k in ("vision_model.embeddings.patch_embedding.weight", "vision_model.encoder.layers.1.mlp.fc2.bias",
+              "vision_model.pre_layrnorm.weight", "visual_projection.weight"):
+        assert torch.equal(got[k], sd[k]), k
+    assert bb.features_size == 128 and bb.model.vision_model.config.projection_dim == 64
+    (d / "model.safetensors").unlink()
+    save_file({k: v for k, v in sd.items() if "fc2" not in k}, str(d / "model.safetensors"))
+    with pytest.raises(KeyError, match="missing"):
+        CLIP(str(d))
