@@ -50,10 +50,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="vit_b16")
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--streams", type=int, default=1, help="2: two micro-batches on two HIP streams (DESIGN.md section 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming-scan", action="store_true")
     args = ap.parse_args()
 
+    os.environ["CH_STREAMS"] = str(args.streams)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -157,6 +159,7 @@ def main():
             "config": {"workload": f"CUB-200 64-bit concept_hash, {args.model} bf16 (CLIP-structured, Q=4 concept tokens, "
                                    f"adapters b=384), batch={B}/GPU, top-{TOPK} Hamming vs {GALLERY_ROWS}-row gallery shard/GPU",
                        "per_gpu_batch": B, "global_batch": world * B, "gallery_rows_per_gpu": GALLERY_ROWS,
+                       "hip_streams": args.streams,
                        "parallelism": f"images x{world} (no collective), gallery rows x{world} (RCCL all_gather of packed "
                                       f"queries + lists)" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all fused-epilogue variants)",

@@ -175,3 +175,20 @@ def test_concept_token_attention_maps(dev):
     assert torch.allclose(got.sum(-1), ref.sum(-1), atol=2e-3)
     base = enc.encode(x.to(dev))["codes"]
     assert torch.equal(base, out["codes"])                  # the tap does not perturb the encode
+
+
+def test_two_stream_micro_batches_give_identical_codes(dev, monkeypatch):
+    """CH_STREAMS=2 splits the batch into two micro-batches on two HIP streams; rows are independent, so codes are bit-equal."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_s16"])
+    cfg["L"] = 2
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    x = eo.synthetic_images(7, cfg["image"]).to(dev)
+    one = _encoder(sd, cfg["heads"], max_batch=8).encode(x, want=("codes", "packed", "concept_attn"))
+    monkeypatch.setenv("CH_STREAMS", "2")
+    enc2 = _encoder(sd, cfg["heads"], max_batch=8)
+    for _ in range(3):
+        two = enc2.encode(x, want=("codes", "packed", "concept_attn"))
+        torch.cuda.synchronize()
+        for k in ("codes", "packed", "concept_attn"):
+            assert torch.equal(one[k], two[k]), k
