@@ -77,19 +77,18 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from concepthash_amd import retrieval as rt
+    from concepthash_amd import synthetic as syn
     from concepthash_amd.encoder import ConceptHashEncoder
-    from oracle import encoder_oracle as eo     # synthetic weights/inputs (+ the cpu_baseline leg below)
-    from oracle import hamming_oracle as ho
 
-    cfg = eo.CONFIGS[args.model]
+    cfg = syn.CONFIGS[args.model]
     B = args.batch
     t_setup = time.perf_counter()
-    sd = eo.synthetic_state_dict(cfg, nbit=NBIT, nclass=NCLASS, seed=42)
+    sd = syn.synthetic_state_dict(cfg, nbit=NBIT, nclass=NCLASS, seed=42)
     log(f"[bench r{rank}] synthetic weights ready ({time.perf_counter() - t_setup:.1f} s)")
     enc = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=B, device=dev)
     log(f"[bench r{rank}] model on device: {enc.device_bytes / 2**20:.0f} MiB ({time.perf_counter() - t_setup:.1f} s)")
-    images = eo.synthetic_images(B, cfg["image"], seed=42 + rank).to(dev).to(torch.bfloat16)
-    g_np, gl_np = ho.synthetic_codes(GALLERY_ROWS, NBIT, seed=1234 + rank, nclass=NCLASS)
+    images = syn.synthetic_images(B, cfg["image"], seed=42 + rank).to(dev).to(torch.bfloat16)
+    g_np, gl_np = syn.synthetic_codes(GALLERY_ROWS, NBIT, seed=1234 + rank, nclass=NCLASS)
     gallery = torch.from_numpy(g_np.view(np.int64)).to(dev)
     W = gallery.shape[1]
 
@@ -223,7 +222,7 @@ def main():
         }
         del g5, q5
         # mAP@all + P@k/R@k at the CUB-200 size (5,794 queries x 5,994 gallery rows x 64 bit, real class-count statistics)
-        qn_np, ql_np = ho.synthetic_codes(5794, NBIT, seed=77, nclass=NCLASS)
+        qn_np, ql_np = syn.synthetic_codes(5794, NBIT, seed=77, nclass=NCLASS)
         qn = torch.from_numpy(qn_np.view(np.int64)).to(dev)
         qlab, glab = torch.from_numpy(ql_np).to(dev), torch.from_numpy(gl_np).to(dev)
         rt.evaluate(qn, gallery, qlab, glab)
@@ -239,11 +238,13 @@ def main():
 
     # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N == 1 only) ---------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import encoder_oracle as eo     # the ONLY use of oracle/ in this file: the CPU baseline being timed
+        from oracle import hamming_oracle as ho
         # the box exposes all host cores to os.cpu_count() but grants a CPU share: use the affinity mask, capped at 16
         cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         torch.set_num_threads(cores)
         bs = 8
-        x = eo.synthetic_images(bs, cfg["image"], seed=42)
+        x = syn.synthetic_images(bs, cfg["image"], seed=42)
         eo.encode(sd, x[:1], heads=cfg["heads"], with_pooled=False)  # warm-up
         log(f"[bench] cpu baseline: {cores} threads, warm-up done")
         t0 = time.perf_counter()
@@ -259,7 +260,7 @@ def main():
                                   "sample": f"{nb} batches of {bs} images: oracle/encoder_oracle.py (PyTorch CPU fp32 "
                                             f"restatement of the reference forward) + oracle/hamming_oracle.c pack + "
                                             f"top-{TOPK} vs the same {GALLERY_ROWS}-row gallery; {cpu_s:.1f} s"}
-        hq, hg = ho.synthetic_codes(32, 128, seed=1)[0], ho.synthetic_codes(1_000_000, 128, seed=2)[0]
+        hq, hg = syn.synthetic_codes(32, 128, seed=1)[0], syn.synthetic_codes(1_000_000, 128, seed=2)[0]
         log("[bench] cpu hamming baseline inputs ready")
         t0 = time.perf_counter()
         ho.bench_topk(hq, hg, TOPK)

@@ -258,84 +258,6 @@ def encode(sd: Dict[str, torch.Tensor], images: torch.Tensor, heads: int, upt_he
     return out
 
 
-# ---------------------------------------------------------------------------------------------------------
-# synthetic weights in the reference state_dict layout (SURVEY.md section 8d "Encode synthetic inputs")
-# ---------------------------------------------------------------------------------------------------------
-CONFIGS = {
-    # name: D, L, heads, M(ffn), patch, image, P(projection), b(adapter)
-    "tiny": dict(D=64, L=2, heads=4, M=128, patch=16, image=64, P=32, b=384),
-    "vit_s16": dict(D=384, L=12, heads=6, M=1536, patch=16, image=224, P=512, b=384),
-    "vit_b32": dict(D=768, L=12, heads=12, M=3072, patch=32, image=224, P=512, b=384),
-    "vit_b16": dict(D=768, L=12, heads=12, M=3072, patch=16, image=224, P=512, b=384),
-    "vit_l14": dict(D=1024, L=24, heads=16, M=4096, patch=14, image=224, P=768, b=384),
-}
-
-
-def synthetic_state_dict(cfg: dict, nbit: int, nclass: int, Q: int = 4, seed: int = 42,
-                         center_dim: int = 512) -> Dict[str, torch.Tensor]:
-    """Seeded random weights: N(0,0.02) linears, LN gamma=1+N(0,.02) beta=N(0,.02), non-zero adapter up-proj
-    (the reference zero-inits up_proj, models/layers/adapter.py:42, which would make adapters a no-op),
-    BN running mean N(0,0.1) / var U(0.5,1.5)."""
-    g = torch.Generator().manual_seed(seed)
-    D, L, M, p, P, b = cfg["D"], cfg["L"], cfg["M"], cfg["patch"], cfg["P"], cfg["b"]
-    npos = (cfg["image"] // p) ** 2 + 1
-
-    def n(*shape, std=0.02):
-        return torch.randn(*shape, generator=g) * std
-
-    sd = {}
-
-    def ln(prefix, dim):
-        sd[prefix + ".weight"] = 1.0 + n(dim)
-        sd[prefix + ".bias"] = n(dim)
-
-    def lin(prefix, out_f, in_f, bias=True, std=0.02):
-        sd[prefix + ".weight"] = n(out_f, in_f, std=std)
-        if bias:
-            sd[prefix + ".bias"] = n(out_f)
-
-    sd[VM + "embeddings.class_embedding"] = n(D)
-    sd[VM + "embeddings.patch_embedding.weight"] = n(D, 3, p, p)
-    sd[VM + "embeddings.position_embedding.weight"] = n(npos, D)
-    ln(VM + "pre_layrnorm", D)
-    for i in range(L):
-        pre = VM + f"encoder.layers.{i}."
-        for nm in ("k_proj", "v_proj", "q_proj", "out_proj"):
-            lin(pre + f"self_attn.{nm}", D, D)
-        ln(pre + "layer_norm1", D)
-        lin(pre + "mlp.fc1", M, D)
-        lin(pre + "mlp.fc2", D, M)
-        ln(pre + "layer_norm2", D)
-        for a in ("adapt_mlp_1.", "adapt_mlp_2."):
-            sd[pre + a + "scale"] = torch.ones(1) + n(1)
-            ln(pre + a + "adapter_layer_norm", D)
-            lin(pre + a + "down_proj", b, D)
-            lin(pre + a + "up_proj", D, b)
-    ln(VM + "post_layernorm", D)
-    sd["backbone.visual_projection.weight"] = n(P, D)
-    sd["hash_pe"] = n(1, Q, D, std=1.0)
-    sd["hash_queries"] = n(1, Q, P, std=1.0)
-    sd["concept_pe"] = n(1, Q, D)
-    sd["center"] = torch.randn(nclass, center_dim, generator=g).sign()
-    sd["hash_fc.weight"] = n(nbit // Q, D, std=0.05)
-    sd["hash_bn.weight"] = 1.0 + n(nbit)
-    sd["hash_bn.bias"] = n(nbit)
-    sd["hash_bn.running_mean"] = n(nbit, std=0.1)
-    sd["hash_bn.running_var"] = 0.5 + torch.rand(nbit, generator=g)
-    sd["hash_attention.sa.in_proj_weight"] = n(3 * P, P)
-    sd["hash_attention.sa.in_proj_bias"] = n(3 * P)
-    lin("hash_attention.sa.out_proj", P, P)
-    lin("hash_attention.ffn.0", P, P)
-    lin("hash_attention.ffn.3", P, P)
-    ln("hash_attention.norm1", P)
-    ln("hash_attention.norm2", P)
-    lin("hash_attention.ffn2", D, P)
-    sd["concept_ce.centroids"] = n(nclass, D, std=1.0)
-    lin("text_projection.0", center_dim, center_dim)
-    lin("text_projection.2", nbit, center_dim)
-    return sd
-
-
-def synthetic_images(batch: int, image: int, seed: int = 42) -> torch.Tensor:
-    g = torch.Generator().manual_seed(seed)
-    return torch.randn(batch, 3, image, image, generator=g)
+# synthetic workloads live in concepthash_amd/synthetic.py (bench.py must not reach into oracle/ for its inputs); re-exported
+# here for the tests' convenience
+from concepthash_amd.synthetic import CONFIGS, synthetic_images, synthetic_state_dict  # noqa: E402,F401

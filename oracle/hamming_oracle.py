@@ -144,21 +144,4 @@ def bench_topk(q: np.ndarray, g: np.ndarray, k: int) -> int:
                                    ctypes.c_int64(g.shape[0]), ctypes.c_int(q.shape[1]), ctypes.c_int(k)))
 
 
-def synthetic_codes(rows: int, nbit: int, seed: int = 1234, nclass: int = 0, flip: float = 0.1):
-    """i.i.d. Bernoulli(0.5) bits, or (nclass>0) clustered: class centre + `flip` bit noise. Returns
-    (packed uint64 [rows, W], labels int32 [rows])."""
-    rng = np.random.default_rng(seed)
-    W = (nbit + 63) // 64
-    if nclass > 0:
-        # class centres depend on (nclass, nbit) only, so query and gallery sets drawn with different seeds share them
-        centres = np.random.default_rng(1000003 * nclass + nbit).integers(0, 2, size=(nclass, nbit), dtype=np.uint8)
-        labels = rng.integers(0, nclass, size=rows, dtype=np.int32)
-        bits = centres[labels] ^ (rng.random((rows, nbit)) < flip).astype(np.uint8)
-    else:
-        labels = rng.integers(0, 1 << 30, size=rows, dtype=np.int32)
-        bits = rng.integers(0, 2, size=(rows, nbit), dtype=np.uint8)
-    pad = W * 64 - nbit
-    if pad:
-        bits = np.concatenate([bits, np.zeros((rows, pad), np.uint8)], axis=1)
-    out = np.ascontiguousarray(np.packbits(bits, axis=1, bitorder="little")).view("<u8").reshape(rows, W)
-    return out, labels
+from concepthash_amd.synthetic import synthetic_codes  # noqa: E402,F401  (generator shared with bench.py)
