@@ -296,6 +296,8 @@ int ch_gemm_bf16_pp_dbg(const GemmParams &p0, int dbg, hipStream_t s) {
         PP_DBG_CASE(2)
         PP_DBG_CASE(3)
         PP_DBG_CASE(4)
+        PP_DBG_CASE(5)
+        PP_DBG_CASE(6)
         PP_DBG_CASE(7)
         default: return 2;
     }

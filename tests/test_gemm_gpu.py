@@ -102,3 +102,26 @@ def test_unsupported_shapes_are_rejected_loudly():
     _gemm(0, X, W, bias, 256, EPI_BIAS, out=out)                 # auto dispatch falls to the 128x128 kernel
     with pytest.raises(RuntimeError, match="multiple of 128"):
         _gemm(1, X, W[:100], bias, 256, EPI_BIAS, out=out)
+
+
+@pytest.mark.parametrize("M,N,K", [(51456, 2304, 768), (51456, 768, 768), (4000, 3072, 768), (2500, 768, 3072), (256, 256, 128),
+                                   (70000, 256, 256)])
+def test_persistent_pingpong_equals_two_phase_bitwise(M, N, K):
+    """gemm_ppp.hip (variant 5): tiles streamed by persistent workgroups with cross-tile prefetch; bf16-output epilogues.
+    Same MFMA / k order as the 128x128 kernel -> bit-identical outputs; repeated with cold and warm caches as a race screen."""
+    X, W, bias, _ = _inputs(M, N, K, seed=2)
+    junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    for epi in (EPI_BIAS, EPI_QGELU):
+        ref = torch.empty(X.shape[0], N, dtype=torch.bfloat16, device="cuda")
+        _gemm(1, X, W, bias, M, epi, out=ref)
+        for it in range(4):
+            out = torch.zeros_like(ref)
+            if it % 2:
+                junk.fill_(float(it))
+            _gemm(5, X, W, bias, M, epi, out=out)
+            torch.cuda.synchronize()
+            assert torch.equal(out[:M].view(torch.int16), ref[:M].view(torch.int16)), (epi, it)
+            assert not bool(out[M:].any())                    # padding rows untouched
+    resid = torch.zeros(X.shape[0], N, device="cuda")
+    with pytest.raises(RuntimeError, match="gemm_ppp"):
+        _gemm(5, X, W, bias, M, EPI_BIAS_RESID, out=ref, resid=resid)
