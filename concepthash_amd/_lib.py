@@ -37,6 +37,9 @@ SIGNATURES = {
     "ch_model_profile_end": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "ch_debug_gemm": (c_int, [c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                               c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ch_debug_gemm_ln": (c_int, [c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                 c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                 c_void_p]),
     "ch_debug_set_gemm_variant": (None, [c_int32]),
     "ch_debug_adapter": (c_int, [c_void_p] * 2 + [c_int32] * 3 + [c_void_p] * 10 + [c_int32, c_void_p]),
     "ch_debug_attention": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

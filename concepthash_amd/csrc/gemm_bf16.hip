@@ -86,8 +86,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
     const int frow = lane & 15, fq = lane >> 4;
     const int nk = p.K / BK;
 
+    f32x4 fold_v[5];
+    if constexpr (ch_epi::traits<EPI>::fold) ch_epi::fold_stats_issue(p, m0, tid, fold_v);
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ch_epi::traits<EPI>::fold)  // per-row (mean, rstd) of the LN-folded input
+        ch_epi::fold_stats_finish(p, tid, fold_v, (float *)(smem + 2 * STAGE_BYTES));
     __syncthreads();
 
     int cur = 0;
@@ -118,7 +123,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
 
     // ---- epilogue (gemm_epilogue.h): transpose through this wave's 16 KB of the idle staging LDS, full-line stores.
     // The loop's last __syncthreads() guarantees no wave still reads staged operands.
-    ch_epi::store_tile<EPI, 4>(p, acc, smem + wid * 16384, m0 + wm * 64, n0 + wn * 64, lane);
+    ch_epi::store_tile<EPI, 4>(p, acc, smem + wid * 16384, m0 + wm * 64, n0 + wn * 64, lane,
+                               (const float *)(smem + 2 * STAGE_BYTES) + 2 * (wm * 64));
 }
 
 template <int EPI>
@@ -126,13 +132,13 @@ int launch(const GemmParams &p0, hipStream_t s) {
     GemmParams p = p0;
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    constexpr int lds = 2 * STAGE_BYTES + (ch_epi::traits<EPI>::fold ? CH_FOLD_LDS_BYTES : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         2 * STAGE_BYTES));
+        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(NTHREADS), 2 * STAGE_BYTES, s, p);
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(NTHREADS), lds, s, p);
     CH_LAUNCH_CHECK();
     return 0;
 }
@@ -152,6 +158,11 @@ int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s) {
         case EPI_BIAS_RESID: return launch<EPI_BIAS_RESID>(p, s);
         case EPI_SCALE_RESID: return launch<EPI_SCALE_RESID>(p, s);
         case EPI_PATCH: return launch<EPI_PATCH>(p, s);
+        case EPI_BIAS_STATS: return launch<EPI_BIAS_STATS>(p, s);
+        case EPI_SCALE_RESID_STATS: return launch<EPI_SCALE_RESID_STATS>(p, s);
+        case EPI_FOLD_BIAS: return launch<EPI_FOLD_BIAS>(p, s);
+        case EPI_FOLD_QUICKGELU: return launch<EPI_FOLD_QUICKGELU>(p, s);
+        case EPI_FOLD_GELU: return launch<EPI_FOLD_GELU>(p, s);
     }
     ch_set_error("gemm: unknown epilogue");
     return 2;
@@ -183,6 +194,11 @@ int ch_gemm_group_n(int M, int N, int K, int bm, int bn) {
 static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128 two-phase), 2 force pp (256x256 ping-pong), 3 force dp
 void ch_gemm_set_variant(int v) { g_gemm_variant = v; }
 int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
+    if (epi == EPI_FOLD_BIAS || epi == EPI_FOLD_QUICKGELU || epi == EPI_FOLD_GELU)
+        CH_REQUIRE(p.stats_in && p.fold_c && p.K % 128 == 0 && p.K <= 1280 && p.ln_eps > 0.f,
+                   "gemm: LN-folded epilogue needs stats_in, fold_c, ln_eps and K % 128 == 0, K <= 1280");
+    if (epi == EPI_BIAS_STATS || epi == EPI_SCALE_RESID_STATS)
+        CH_REQUIRE(p.stats_out && (epi == EPI_BIAS_STATS || p.hb_out), "gemm: statistics epilogue needs stats_out (and hb_out)");
     if (g_gemm_variant == 1) return ch_gemm_bf16_v1(p, epi, s);
     if (g_gemm_variant == 2) return ch_gemm_bf16_pp(p, epi, s);
     if (g_gemm_variant == 3) return ch_gemm_bf16_dp(p, epi, s);

@@ -33,24 +33,85 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 }
 
 template <int EPI>
+struct traits {
+    static constexpr bool fold = (EPI == EPI_FOLD_BIAS || EPI == EPI_FOLD_QUICKGELU || EPI == EPI_FOLD_GELU);
+    static constexpr bool quick = (EPI == EPI_BIAS_QUICKGELU || EPI == EPI_FOLD_QUICKGELU);
+    static constexpr bool erf = (EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU);
+    static constexpr bool bf16_only = (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS || quick || erf || fold);
+    static constexpr bool scale_resid = (EPI == EPI_SCALE_RESID || EPI == EPI_SCALE_RESID_STATS);
+    static constexpr bool stats = (EPI == EPI_BIAS_STATS || EPI == EPI_SCALE_RESID_STATS);
+};
+
+template <int EPI>
 __device__ __forceinline__ f32x4 activate(f32x4 v) {
-    if constexpr (EPI == EPI_BIAS_QUICKGELU) {
+    if constexpr (traits<EPI>::quick) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
     }
-    if constexpr (EPI == EPI_BIAS_GELU) {
+    if constexpr (traits<EPI>::erf) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
     }
     return v;
 }
 
-// wave_lds: this wave's 16 KB staging region; m_base / n_base: global row / column of the wave's sub-tile origin.
+// sums over aligned groups of 8 / 16 lanes with DPP only (no LDS traffic): xor-1, xor-2 inside a quad, then the half-row /
+// row mirrors (after the quad steps every lane of a quad holds the quad's sum, so a mirror is as good as an xor)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float sum16(float v) {
+    v = sum8(v);
+    v += dpp_f<0x140>(v);  // row_mirror
+    return v;
+}
+
+// LayerNorm-fold consumers: two threads per row (blockDim = 2 * ROWS) turn the producer's partial sums of rows
+// m0 .. m0 + ROWS - 1 into (mean, rstd) in LDS.  The loads are inline asm, issued BEFORE the block's first LDS-DMA and
+// consumed after the prologue's counted vmcnt wait (vmcnt retires in issue order, so they are complete by then): written as
+// ordinary loads the compiler would drain the whole DMA prologue with vmcnt(0) at their first use.
+__device__ __forceinline__ void fold_stats_issue(const GemmParams &p, int m0, int tid, f32x4 (&v)[5]) {
+    const int m = min(m0 + (tid >> 1), p.M - 1);
+    const int n4 = p.K >> 7, H = (n4 + 1) >> 1;  // float4 = two 64-column slices; this thread reads float4 [half*H, half*H + H)
+    const f32x4 *st = (const f32x4 *)(p.stats_in + (size_t)m * (p.K >> 6) * 2);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const f32x4 *src = st + min((tid & 1) * H + i, n4 - 1);  // clamped: every load is issued unconditionally
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[i]) : "v"(src) : "memory");
+    }
+}
+__device__ __forceinline__ void fold_stats_finish(const GemmParams &p, int tid, const f32x4 (&v)[5], float *row_ms) {
+    const int n4 = p.K >> 7, H = (n4 + 1) >> 1, first = (tid & 1) * H;
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const bool valid = i < H && first + i < n4;
+        sm += valid ? v[i][0] + v[i][2] : 0.f;
+        sq += valid ? v[i][1] + v[i][3] : 0.f;
+    }
+    sm += dpp_f<0xB1>(sm);  // the row's other half (lane ^ 1)
+    sq += dpp_f<0xB1>(sq);
+    const float inv = 1.0f / (float)p.K;
+    const float mean = sm * inv;
+    const float var = fmaxf(sq * inv - mean * mean, 0.f);
+    if (!(tid & 1)) *(ch_f32x2_t *)(row_ms + (tid & ~1)) = ch_f32x2_t{mean, rsqrtf(var + p.ln_eps)};
+}
+
+// wave_lds: this wave's 16 KB staging region; m_base / n_base: global row / column of the wave's sub-tile origin;
+// row_ms: (EPI_FOLD_*) the block tile's (mean, rstd) table in LDS, already offset to this wave's first row.
 template <int EPI, int MT>
 __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][MT], char *wave_lds, int m_base, int n_base,
-                                           int lane) {
+                                           int lane, const float *row_ms = nullptr) {
     const int fr = lane & 15, fq = lane >> 4;
-    constexpr bool BF16_ONLY = (EPI == EPI_BIAS || EPI == EPI_BIAS_QUICKGELU || EPI == EPI_BIAS_GELU);
+    using T = traits<EPI>;
+    constexpr bool BF16_ONLY = T::bf16_only;
     f32x4 bias[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -62,12 +123,28 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
 
     if constexpr (BF16_ONLY) {
         // ---- stage MT*16 rows x 64 cols of bf16 (128-B rows)
+        f32x4 fc[4];
+        if constexpr (T::fold) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) fc[nt] = (p.dbg & 4) ? bias[nt] : *(const f32x4 *)(p.fold_c + n_base + nt * 16 + fq * 4);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int row = mt * 16 + fr;
+            float rs = 1.0f, nm = 0.f;
+            if constexpr (T::fold) if (!(p.dbg & 2)) {
+                const ch_f32x2_t ms = *(const ch_f32x2_t *)(row_ms + 2 * row);
+                rs = ms[1];
+                nm = -ms[0] * ms[1];
+            }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const f32x4 v = activate<EPI>(acc[nt][mt] + bias[nt]);
+                f32x4 pre;
+                if constexpr (T::fold)
+                    pre = acc[nt][mt] * rs + (fc[nt] * nm + bias[nt]);
+                else
+                    pre = acc[nt][mt] + bias[nt];
+                const f32x4 v = activate<EPI>(pre);
                 uint2 o;
                 o.x = pack_bf16x2(v[0], v[1]);
                 o.y = pack_bf16x2(v[2], v[3]);
@@ -83,11 +160,25 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
             const uint4 v = *(const uint4 *)(wave_lds + row * 128 + pos * 16);
             const int m = m_base + row;
             if (m < p.M) *(uint4 *)(p.out_bf16 + (size_t)m * p.ldo + n_base + chunk * 8) = v;
+            if constexpr (T::stats) {  // partial (sum, sumsq) of this row's 64 rounded outputs: 8 lanes x 8 values
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = bf2f((bf16_t)(w[j] & 0xffff)), b = bf2f((bf16_t)(w[j] >> 16));
+                    sm += a + b;
+                    sq += a * a + b * b;
+                }
+                sm = sum8(sm);
+                sq = sum8(sq);
+                if (pos == 0 && m < p.M)
+                    *(ch_f32x2_t *)(p.stats_out + ((size_t)m * (p.N >> 6) + (n_base >> 6)) * 2) = ch_f32x2_t{sm, sq};
+            }
         }
     } else {
         // ---- fp32 staging, 64 rows (4 m-tiles) per pass: 256-B rows
         float scale = 1.0f;
-        if constexpr (EPI == EPI_SCALE_RESID) scale = *p.scale_ptr;
+        if constexpr (T::scale_resid) scale = *p.scale_ptr;
         const int lrow = lane >> 4, pos = lane & 15;
 #pragma unroll
         for (int pass = 0; pass < MT / 4; ++pass) {
@@ -127,7 +218,7 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                     } else {
                         off[i] = (size_t)mc * p.ldr + n;
                         hv[i] = *(const f32x4 *)(p.resid + off[i]);
-                        if constexpr (EPI == EPI_SCALE_RESID) {
+                        if constexpr (T::scale_resid) {
                             av[i] = make_uint2(0u, 0u);
                             if (p.addend) av[i] = *(const uint2 *)(p.addend + (size_t)mc * p.ld_addend + n);
                         }
@@ -155,6 +246,21 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                         h[2] += bf2f((bf16_t)(av[i].y & 0xffff));
                         h[3] += bf2f((bf16_t)(av[i].y >> 16));
                         *(f32x4 *)(p.resid + off[i]) = h;
+                        if constexpr (T::stats) {  // bf16 copy for the next (LN-folded) GEMM + its row statistics
+                            const int row = (batch * 8 + i) * 4 + lrow;
+                            const int m = m_base + pass * 64 + row;
+                            const int n = n_base + (pos ^ (row & 15)) * 4;
+                            uint2 o;
+                            o.x = pack_bf16x2(h[0], h[1]);
+                            o.y = pack_bf16x2(h[2], h[3]);
+                            *(uint2 *)(p.hb_out + (size_t)m * p.ld_hb + n) = o;
+                            const float a = bf2f((bf16_t)(o.x & 0xffff)), b = bf2f((bf16_t)(o.x >> 16));
+                            const float c = bf2f((bf16_t)(o.y & 0xffff)), d = bf2f((bf16_t)(o.y >> 16));
+                            const float sm = sum16((a + b) + (c + d));
+                            const float sq = sum16((a * a + b * b) + (c * c + d * d));
+                            if (pos == 0)
+                                *(ch_f32x2_t *)(p.stats_out + ((size_t)m * (p.N >> 6) + (n_base >> 6)) * 2) = ch_f32x2_t{sm, sq};
+                        }
                     }
                 }
             }

@@ -162,6 +162,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const int J = nk >> 1;
 
     // ---- prologue: K-tile 0 complete (4 half-tiles) + 3 half-tiles of K-tile 1; retire K-tile 0 with vmcnt(6)
+    f32x4 fold_v[5];
+    if constexpr (ch_epi::traits<EPI>::fold) if (!(p.dbg & 1)) ch_epi::fold_stats_issue(p, m0, tid, fold_v);  // older than every DMA below
     issue(0, 0);
     issue(2, 0);
     issue(3, 0);
@@ -170,6 +172,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     issue(2, 1);
     issue(3, 1);
     PP_WAIT_VM(6);
+    if constexpr (ch_epi::traits<EPI>::fold) if (!(p.dbg & 1)) {  // per-row (mean, rstd) of the LN-folded input
+        ch_epi::fold_stats_finish(p, tid, fold_v, (float *)(smem + 2 * BUF_BYTES));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     PP_BARRIER();
     if (wr == 1) PP_BARRIER();  // stagger: waves 4-7 run one barrier behind waves 0-3
 
@@ -254,7 +260,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     }
     // ---- epilogue (gemm_epilogue.h): every wave has passed the balance barrier, so no wave still reads staged operands
     // and no LDS-DMA is in flight (vmcnt(0) in the last iteration); each wave transposes through its own 16 KB.
-    ch_epi::store_tile<EPI, 8>(p, acc, smem + wid * 16384, m0 + wr * 128, n0 + wc * 64, lane);
+    ch_epi::store_tile<EPI, 8>(p, acc, smem + wid * 16384, m0 + wr * 128, n0 + wc * 64, lane,
+                               (const float *)(smem + 2 * BUF_BYTES) + 2 * (wr * 128));
 }
 
 template <int EPI>
@@ -262,13 +269,13 @@ int launch_pp(const GemmParams &p0, hipStream_t s) {
     GemmParams p = p0;
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    constexpr int lds = 2 * BUF_BYTES + (ch_epi::traits<EPI>::fold ? CH_FOLD_LDS_BYTES : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         2 * BUF_BYTES));
+        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_pp_kernel<EPI>, dim3(tiles), dim3(NTHREADS), 2 * BUF_BYTES, s, p);
+    hipLaunchKernelGGL(gemm_pp_kernel<EPI>, dim3(tiles), dim3(NTHREADS), lds, s, p);
     CH_LAUNCH_CHECK();
     return 0;
 }
@@ -316,6 +323,11 @@ int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s) {
         case EPI_BIAS_RESID: return launch_pp<EPI_BIAS_RESID>(p, s);
         case EPI_SCALE_RESID: return launch_pp<EPI_SCALE_RESID>(p, s);
         case EPI_PATCH: return launch_pp<EPI_PATCH>(p, s);
+        case EPI_BIAS_STATS: return launch_pp<EPI_BIAS_STATS>(p, s);
+        case EPI_SCALE_RESID_STATS: return launch_pp<EPI_SCALE_RESID_STATS>(p, s);
+        case EPI_FOLD_BIAS: return launch_pp<EPI_FOLD_BIAS>(p, s);
+        case EPI_FOLD_QUICKGELU: return launch_pp<EPI_FOLD_QUICKGELU>(p, s);
+        case EPI_FOLD_GELU: return launch_pp<EPI_FOLD_GELU>(p, s);
     }
     ch_set_error("gemm: unknown epilogue");
     return 2;

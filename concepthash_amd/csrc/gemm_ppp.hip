@@ -59,7 +59,7 @@ struct TileOff {  // wave-uniform (lives in SGPRs)
 };
 
 template <int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_ppp_kernel(GemmParams p, int ntiles) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_ppp_kernel(GemmParams p, int ntiles, int skew_ticks, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -144,6 +144,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_ppp_kernel(GemmParams p, int
     int v = blockIdx.x;
     TileOff cur, nxt;
     tile_offsets(v, cur);
+    // start skew: workgroups that own one tile fewer than the busiest ones have a tile time of slack; spreading their start
+    // over it moves their epilogue store bursts away from everyone else's (the stores of a synchronized round otherwise
+    // arrive together and drain at HBM write rate while the matrix cores idle)
+    {
+        const int rem = ntiles % G;
+        if (skew_ticks > 0 && rem != 0 && (int)blockIdx.x >= rem) {
+            const int local = (int)blockIdx.x >> 3, first = rem >> 3, span = (G >> 3) - first;
+            const int slot = (local - first) * 8 + (((int)blockIdx.x & 7) ^ (local & 7));   // neighbours on an XCD differ
+            const long long wait = (long long)skew_ticks * slot / (span * 8);
+            const long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+        }
+    }
 
     // ---- prologue (first tile only): K-tile 0 complete + 3 half-tiles of K-tile 1
     issue(cur, 0, 0);
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_ppp_kernel(GemmParams p, int
                     const int chunk = pos ^ (row & 7);
                     const uint4 val = *(const uint4 *)(wl + row * 128 + pos * 16);
                     const int m = m_base + pass * 32 + row;
-                    if (m < p.M) *(uint4 *)(p.out_bf16 + (size_t)m * p.ldo + n_base + chunk * 8) = val;
+                    if (m < p.M && !(flags & 1)) *(uint4 *)(p.out_bf16 + (size_t)m * p.ldo + n_base + chunk * 8) = val;
                 }
             }
         }
@@ -290,7 +303,9 @@ int launch_ppp(const GemmParams &p0, hipStream_t s) {
         attr_set = true;
     }
     const int grid = tiles < 256 ? tiles : 256;  // one workgroup per CU (160 KB of LDS each)
-    hipLaunchKernelGGL(gemm_ppp_kernel<EPI>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, p, tiles);
+    const char *e1 = getenv("CH_PPP_SKEW_NS"), *e2 = getenv("CH_PPP_FLAGS");
+    const int skew_ticks = e1 ? atoi(e1) / 10 : 0, flags = e2 ? atoi(e2) : 0;   // wall_clock64: 100 MHz
+    hipLaunchKernelGGL(gemm_ppp_kernel<EPI>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, p, tiles, skew_ticks, flags);
     CH_LAUNCH_CHECK();
     return 0;
 }

@@ -10,6 +10,16 @@ enum GemmEpilogue {
     EPI_BIAS_RESID = 3,     // v = acc + bias; resid += v; out_bf16 = v
     EPI_SCALE_RESID = 4,    // resid += [addend] + *scale_ptr * (acc + bias)
     EPI_PATCH = 5,          // resid[token row of patch m] = acc + pos[1 + patch]
+    // ---- LayerNorm folded into the CONSUMER GEMM: the producer of a LayerNorm input emits per-row
+    // partial (sum, sum of squares) over each 64-column slice of its bf16-rounded output; the consumer multiplies the RAW
+    // rows by W' = bf16(W * gamma) and normalises in its epilogue:  y = rstd_m * (acc - mean_m * c_n) + d_n,
+    // c_n = sum_k W'[n][k], d_n = bias_n + sum_k W[n][k] * beta_k.
+    EPI_BIAS_STATS = 6,         // EPI_BIAS + row statistics of out_bf16 -> stats_out
+    EPI_SCALE_RESID_STATS = 7,  // EPI_SCALE_RESID + hb_out = bf16(resid) + row statistics of hb_out -> stats_out
+    EPI_FOLD_BIAS = 8,          // out_bf16 = LN-folded linear (bias = d, fold_c = c, stats_in)
+    EPI_FOLD_QUICKGELU = 9,     // ... then quick_gelu
+    EPI_FOLD_GELU = 10,         // ... then gelu_erf
+    EPI_COUNT = 11,
 };
 
 struct GemmParams {
@@ -29,7 +39,16 @@ struct GemmParams {
     const float *pos;        // EPI_PATCH: position embedding [1 + Np, N]
     int tokens_per_img;      // EPI_PATCH: N tokens per image in the residual stream
     int patches_per_img;     // EPI_PATCH: Np
+    // LayerNorm fold (EPI_*_STATS producers, EPI_FOLD_* consumers)
+    float *stats_out;        // [rows, N/64, 2] partial (sum, sumsq) per 64-column slice of this GEMM's output row
+    bf16_t *hb_out;          // EPI_SCALE_RESID_STATS: bf16 copy of the updated residual [rows, ld_hb]
+    int ld_hb;
+    const float *stats_in;   // [rows, K/64, 2] partials of this GEMM's input rows (written by the producer)
+    const float *fold_c;     // [N]
+    float ln_eps;
+    int dbg;                 // timing experiments only (CH_GEMM_DBG through ch_debug_gemm_ln)
 };
+constexpr int CH_FOLD_LDS_BYTES = 2048;  // per-row (mean, rstd) table of a <= 256-row block tile
 int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);      // dispatcher
 int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s);   // gemm_bf16.hip: 128x128x64, two-phase
 int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s);   // gemm_pp.hip: 256x256x64, ping-pong 8-phase

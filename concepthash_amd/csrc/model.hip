@@ -19,13 +19,16 @@ namespace {
 struct AdapterW {
     const float *ln_w = nullptr, *ln_b = nullptr, *down_b = nullptr, *up_b = nullptr, *scale = nullptr;
     const bf16_t *down_w = nullptr, *up_w = nullptr;
-    // fused path (adapter_fused.hip): LayerNorm folded into the down projection
+    // adapter LayerNorm folded into the down projection (LN-fold chain and adapter_fused.hip)
     const bf16_t *down_wf = nullptr;
     const float *fold_c = nullptr, *fold_d = nullptr;
 };
 struct LayerW {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *out_b, *fc1_b, *fc2_b;
     const bf16_t *qkv_w, *out_w, *fc1_w, *fc2_w;
+    // layer_norm1 / layer_norm2 folded into qkv / fc1: W' = bf16(W * gamma), c = row sums of W', d = bias + W beta
+    const bf16_t *qkv_wf = nullptr, *fc1_wf = nullptr;
+    const float *qkv_c = nullptr, *qkv_d = nullptr, *fc1_c = nullptr, *fc1_d = nullptr;
     AdapterW ad[2];
 };
 }  // namespace
@@ -48,6 +51,9 @@ struct ch_model {
     // adapter_fused.hip is correct (parity-tested) but measured slower than the three-launch chain on MI355X (200 vs 179 us
     // per call at B=256: its HBM phases and MFMA phases do not overlap) -> opt-in only
     bool use_fused_adapter = false;
+    // LayerNorm folded into the consumer GEMMs: no LayerNorm launches inside the layer loop.
+    // Needs adapters (their up-projection epilogue is where the bf16 copy of the residual and its row statistics are made).
+    bool ln_fold = true;
     bool prof_on = false;
     struct Prof {
         std::vector<hipEvent_t> ev;
@@ -65,6 +71,7 @@ struct ch_model {
     // workspace
     int64_t rows_alloc = 0, prow_alloc = 0;
     float *H = nullptr;
+    float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn
     bf16_t *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *A = nullptr, *AD = nullptr, *F1 = nullptr, *PATCH = nullptr;
 };
 
@@ -140,6 +147,38 @@ struct Builder {
         (void)hipFree(tmp);
         return dst;
     }
+    // LayerNorm fold of a Linear made of `nparts` row blocks ([rows_each, D] weights + [rows_each] biases, host fp32):
+    // wf = bf16(W * gamma) [n_pad, D] (rows past the true ones zero), c[n] = sum_k wf[n][k], d[n] = bias[n] + sum_k W[n][k] beta[k]
+    bool fold(const std::string *wnames, const std::string *bnames, int nparts, int rows_each, int n_pad, int D,
+              const float *gamma, const float *beta, const bf16_t **wf, const float **cc, const float **dd) {
+        const int n_true = nparts * rows_each;
+        float *w32 = nullptr, *b32 = nullptr;
+        if (hipMalloc((void **)&w32, sizeof(float) * (size_t)n_true * D) != hipSuccess ||
+            hipMalloc((void **)&b32, sizeof(float) * n_true) != hipSuccess) {
+            ch_set_error("hipMalloc failed (LayerNorm fold staging)");
+            ok = false;
+            (void)hipFree(w32);
+            return false;
+        }
+        for (int j = 0; j < nparts && ok; ++j) {
+            const ch_tensor *wt = find(wnames[j], (int64_t)rows_each * D), *bt = find(bnames[j], rows_each);
+            if (!wt || !bt) break;
+            if (hipMemcpy(w32 + (size_t)j * rows_each * D, wt->data, sizeof(float) * (size_t)rows_each * D,
+                          hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(b32 + (size_t)j * rows_each, bt->data, sizeof(float) * rows_each, hipMemcpyHostToDevice) != hipSuccess)
+                ok = false;
+        }
+        bf16_t *w = (bf16_t *)alloc(sizeof(bf16_t) * (size_t)n_pad * D);
+        float *c = (float *)alloc(sizeof(float) * n_pad), *d = (float *)alloc(sizeof(float) * n_pad);
+        if (ok && ch_fold_ln(w32, b32, gamma, beta, n_true, n_pad, D, w, c, d, s) != 0) ok = false;
+        if (hipStreamSynchronize(s) != hipSuccess) ok = false;
+        (void)hipFree(w32);
+        (void)hipFree(b32);
+        *wf = w;
+        *cc = c;
+        *dd = d;
+        return ok;
+    }
 };
 
 int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
@@ -194,6 +233,13 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
         w.fc1_b = B.f32(pre + "mlp.fc1.bias", M);
         w.fc2_w = B.bf16(pre + "mlp.fc2.weight", D, M, M);
         w.fc2_b = B.f32(pre + "mlp.fc2.bias", D);
+        if (b > 0 && B.ok) {  // LN-fold chain
+            const std::string qw[3] = {pre + "self_attn.q_proj.weight", pre + "self_attn.k_proj.weight", pre + "self_attn.v_proj.weight"};
+            const std::string qb[3] = {pre + "self_attn.q_proj.bias", pre + "self_attn.k_proj.bias", pre + "self_attn.v_proj.bias"};
+            B.fold(qw, qb, 3, D, 3 * D, D, w.ln1_w, w.ln1_b, &w.qkv_wf, &w.qkv_c, &w.qkv_d);
+            const std::string fw = pre + "mlp.fc1.weight", fb = pre + "mlp.fc1.bias";
+            B.fold(&fw, &fb, 1, M, M, D, w.ln2_w, w.ln2_b, &w.fc1_wf, &w.fc1_c, &w.fc1_d);
+        }
         for (int a = 0; a < 2 && B.ok && b > 0; ++a) {
             const std::string ap = pre + "adapt_mlp_" + std::to_string(a + 1) + ".";
             AdapterW &aw = w.ad[a];
@@ -214,16 +260,9 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
             aw.down_b = db;
             aw.up_w = uw;
             aw.up_b = B.f32(ap + "up_proj.bias", D);
-            if (B.ok && ch_adapter_fused_supported(D, m->bpad)) {
-                const float *wd32 = B.f32(ap + "down_proj.weight", (int64_t)b * D);
-                const float *bd32 = B.f32(ap + "down_proj.bias", b);
-                bf16_t *wf = (bf16_t *)B.alloc(sizeof(bf16_t) * (size_t)m->bpad * D);
-                float *fc = (float *)B.alloc(sizeof(float) * m->bpad), *fd = (float *)B.alloc(sizeof(float) * m->bpad);
-                if (!B.ok) break;
-                if (ch_fold_ln(wd32, bd32, aw.ln_w, aw.ln_b, b, m->bpad, D, wf, fc, fd, B.s)) B.ok = false;
-                aw.down_wf = wf;
-                aw.fold_c = fc;
-                aw.fold_d = fd;
+            if (B.ok) {
+                const std::string dwn = ap + "down_proj.weight", dbn = ap + "down_proj.bias";
+                B.fold(&dwn, &dbn, 1, b, m->bpad, D, aw.ln_w, aw.ln_b, &aw.down_wf, &aw.fold_c, &aw.fold_d);
             }
         }
     }
@@ -332,6 +371,8 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
     m->prow_alloc = prows;
     m->H = (float *)B.alloc(sizeof(float) * rows * D);
     m->Xn = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * D);
+    m->statsA = (float *)B.alloc(sizeof(float) * rows * (D / 64) * 2);
+    m->statsH = (float *)B.alloc(sizeof(float) * rows * (D / 64) * 2);
     m->QKV = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * 3 * D);
     m->AO = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * D);
     m->A = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * D);
@@ -341,6 +382,8 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
     if (!B.ok) return 4;
     CH_CHECK_HIP(hipMemset(m->H, 0, sizeof(float) * rows * D));
     CH_CHECK_HIP(hipMemset(m->Xn, 0, sizeof(bf16_t) * rows * D));
+    CH_CHECK_HIP(hipMemset(m->statsA, 0, sizeof(float) * rows * (D / 64) * 2));
+    CH_CHECK_HIP(hipMemset(m->statsH, 0, sizeof(float) * rows * (D / 64) * 2));
     CH_CHECK_HIP(hipMemset(m->QKV, 0, sizeof(bf16_t) * rows * 3 * D));
     CH_CHECK_HIP(hipMemset(m->AO, 0, sizeof(bf16_t) * rows * D));
     CH_CHECK_HIP(hipMemset(m->A, 0, sizeof(bf16_t) * rows * D));
@@ -372,10 +415,10 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
     const size_t row0 = (size_t)img0 * ntok, prow0 = (size_t)img0 * np;
     // view of the workspace for this micro-batch
     struct View {
-        float *H;
+        float *H, *statsA, *statsH;
         bf16_t *Xn, *QKV, *AO, *A, *AD, *F1, *PATCH;
         int64_t rows_alloc, prow_alloc;
-    } v{mm->H + row0 * D, mm->Xn + row0 * D, mm->QKV + row0 * 3 * D, mm->AO + row0 * D, mm->A + row0 * D,
+    } v{mm->H + row0 * D, mm->statsA + row0 * (D / 64) * 2, mm->statsH + row0 * (D / 64) * 2, mm->Xn + row0 * D, mm->QKV + row0 * 3 * D, mm->AO + row0 * D, mm->A + row0 * D,
         mm->AD + row0 * std::max(mm->bpad, 128), mm->F1 + row0 * M, mm->PATCH + prow0 * mm->Kp,
         mm->rows_alloc - (int64_t)row0, mm->prow_alloc - (int64_t)prow0};
     View *m = &v;
@@ -399,18 +442,40 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         return e;
 
     // cat / n_true / k_true: profiler category and the un-padded (algorithmic) GEMM extents
+    // LayerNorm-fold plumbing of one GEMM: statistics it consumes (fold_c != nullptr) and/or produces (stats_out != nullptr)
+    struct Fold {
+        const float *stats_in = nullptr, *fold_c = nullptr;
+        float eps = 0.f;
+        float *stats_out = nullptr;
+        bf16_t *hb_out = nullptr;
+    };
+    const bool fold = mm->ln_fold && c.adapter_dim > 0 && !mm->use_fused_adapter;
     auto gemm = [&](int cat, int n_true, int k_true, const bf16_t *X, const bf16_t *W, int N, int K, const float *bias,
-                    int epi, bf16_t *out, int ldo, const float *scale, const bf16_t *addend = nullptr) {
+                    int epi, bf16_t *out, int ldo, const float *scale, const bf16_t *addend = nullptr, const Fold &f = Fold()) {
         mark(mm, pi, cat, 2.0 * rows * (double)n_true * k_true, s);
         GemmParams p{};
+        p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
         p.X = X; p.W = W; p.M = rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
         p.out_bf16 = out; p.ldo = ldo; p.resid = m->H; p.ldr = D; p.scale_ptr = scale;
         return ch_gemm_bf16(p, epi, s);
     };
-    auto adapter = [&](const AdapterW &aw) -> int {
+    // emit_h: (LN-fold chain) the up-projection also writes bf16(H) to Xn + its row statistics for the next folded GEMM
+    auto adapter = [&](const AdapterW &aw, bool emit_h) -> int {
         if (!aw.down_w) return 0;
-        if (aw.down_wf && mm->use_fused_adapter) {
+        if (fold) {
+            // adapter LayerNorm folded into the down projection, which reads the sub-block output `a` (m->A) directly
+            Fold fd;
+            fd.stats_in = m->statsA; fd.fold_c = aw.fold_c; fd.eps = 1e-5f;
+            if (int e = gemm(CH_CAT_GEMM_DOWN, c.adapter_dim, D, m->A, aw.down_wf, mm->bpad, D, aw.fold_d, EPI_FOLD_GELU, m->AD,
+                             mm->bpad, nullptr, nullptr, fd))
+                return e;
+            Fold fu;
+            if (emit_h) { fu.stats_out = m->statsH; fu.hb_out = m->Xn; }
+            return gemm(CH_CAT_GEMM_UP, D, c.adapter_dim, m->AD, aw.up_w, D, mm->bpad, aw.up_b,
+                        emit_h ? EPI_SCALE_RESID_STATS : EPI_SCALE_RESID, nullptr, 0, aw.scale, m->A, fu);
+        }
+        if (aw.down_wf && mm->use_fused_adapter && ch_adapter_fused_supported(D, mm->bpad)) {
             // LN + down + GELU + up + residual in one launch (adapter_fused.hip); a = m->A (bf16), H updated in place
             mark(mm, pi, CH_CAT_ADAPTER, 4.0 * rows * (double)D * c.adapter_dim, s);
             AdapterParams ap{};
@@ -429,29 +494,45 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
                     aw.scale, m->A);
     };
 
+    Fold stats_a;  // out_proj / fc2 of the LN-fold chain: row statistics of `a` for the adapter's folded LayerNorm
+    if (fold) stats_a.stats_out = m->statsA;
     for (int i = 0; i < nlayers; ++i) {
         const LayerW &w = mm->layers[i];
-        if (i > 0) {
-            mark(mm, pi, CH_CAT_ROWOPS, 0.0, s);
-            if (int e = ch_layernorm_f32(m->H, rows, D, w.ln1_w, w.ln1_b, c.ln_eps, m->Xn, s)) return e;
+        if (i > 0 && fold) {
+            // layer_norm1 folded: Xn holds bf16(H) and statsH its row statistics (previous layer's second up-projection)
+            Fold fq;
+            fq.stats_in = m->statsH; fq.fold_c = w.qkv_c; fq.eps = c.ln_eps;
+            if (int e = gemm(CH_CAT_GEMM_QKV, 3 * D, D, m->Xn, w.qkv_wf, 3 * D, D, w.qkv_d, EPI_FOLD_BIAS, m->QKV, 3 * D, nullptr,
+                             nullptr, fq))
+                return e;
+        } else {
+            if (i > 0) {
+                mark(mm, pi, CH_CAT_ROWOPS, 0.0, s);
+                if (int e = ch_layernorm_f32(m->H, rows, D, w.ln1_w, w.ln1_b, c.ln_eps, m->Xn, s)) return e;
+            }
+            if (int e = gemm(CH_CAT_GEMM_QKV, 3 * D, D, m->Xn, w.qkv_w, 3 * D, D, w.qkv_b, EPI_BIAS, m->QKV, 3 * D, nullptr)) return e;
         }
-        if (int e = gemm(CH_CAT_GEMM_QKV, 3 * D, D, m->Xn, w.qkv_w, 3 * D, D, w.qkv_b, EPI_BIAS, m->QKV, 3 * D, nullptr)) return e;
         mark(mm, pi, CH_CAT_ATTENTION, 4.0 * B * (double)ntok * ntok * D, s);
         if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, i == nlayers - 1 ? concept_attn : nullptr, c.ncontext))
             return e;
         // h = r + a  (+ adapter_1(a) below);  a kept as bf16 in m->A for the adapter branch
         // with adapters the residual add of `a` is deferred to the adapter's up-projection epilogue (see adapter())
-        if (int e = gemm(CH_CAT_GEMM_OUT, D, D, m->AO, w.out_w, D, D, w.out_b, w.ad[0].down_w ? EPI_BIAS : EPI_BIAS_RESID, m->A,
-                         D, nullptr))
-            return e;
-        if (int e = adapter(w.ad[0])) return e;
-        mark(mm, pi, CH_CAT_ROWOPS, 0.0, s);
-        if (int e = ch_layernorm_f32(m->H, rows, D, w.ln2_w, w.ln2_b, c.ln_eps, m->Xn, s)) return e;
-        if (int e = gemm(CH_CAT_GEMM_FC1, M, D, m->Xn, w.fc1_w, M, D, w.fc1_b, act_epi, m->F1, M, nullptr)) return e;
-        if (int e = gemm(CH_CAT_GEMM_FC2, D, M, m->F1, w.fc2_w, D, M, w.fc2_b, w.ad[1].down_w ? EPI_BIAS : EPI_BIAS_RESID, m->A,
-                         D, nullptr))
-            return e;
-        if (int e = adapter(w.ad[1])) return e;
+        const int sub_epi = fold ? EPI_BIAS_STATS : (w.ad[0].down_w ? EPI_BIAS : EPI_BIAS_RESID);
+        if (int e = gemm(CH_CAT_GEMM_OUT, D, D, m->AO, w.out_w, D, D, w.out_b, sub_epi, m->A, D, nullptr, nullptr, stats_a)) return e;
+        if (int e = adapter(w.ad[0], true)) return e;
+        if (fold) {
+            Fold f1;
+            f1.stats_in = m->statsH; f1.fold_c = w.fc1_c; f1.eps = c.ln_eps;
+            if (int e = gemm(CH_CAT_GEMM_FC1, M, D, m->Xn, w.fc1_wf, M, D, w.fc1_d,
+                             c.act == 0 ? EPI_FOLD_QUICKGELU : EPI_FOLD_GELU, m->F1, M, nullptr, nullptr, f1))
+                return e;
+        } else {
+            mark(mm, pi, CH_CAT_ROWOPS, 0.0, s);
+            if (int e = ch_layernorm_f32(m->H, rows, D, w.ln2_w, w.ln2_b, c.ln_eps, m->Xn, s)) return e;
+            if (int e = gemm(CH_CAT_GEMM_FC1, M, D, m->Xn, w.fc1_w, M, D, w.fc1_b, act_epi, m->F1, M, nullptr)) return e;
+        }
+        if (int e = gemm(CH_CAT_GEMM_FC2, D, M, m->F1, w.fc2_w, D, M, w.fc2_b, sub_epi, m->A, D, nullptr, nullptr, stats_a)) return e;
+        if (int e = adapter(w.ad[1], i + 1 < nlayers)) return e;
     }
     return 0;
 }
@@ -506,6 +587,7 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
     m->ntok = 1 + m->np + cfg->ncontext;
     m->Kp = (int)round_up64(3 * cfg->patch * cfg->patch, 64);
     if (const char *e = getenv("CH_FUSED_ADAPTER")) m->use_fused_adapter = atoi(e) != 0;
+    if (const char *e = getenv("CH_LN_FOLD")) m->ln_fold = atoi(e) != 0;
     if (const char *e = getenv("CH_STREAMS")) m->nstreams = atoi(e) >= 2 ? 2 : 1;
     if (hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -655,6 +737,24 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant >= 21 && variant <= 27) return ch_gemm_bf16_pp_dbg(p, variant - 20, s);  // timing-only builds
     return ch_gemm_bf16(p, epi, s);
+}
+extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_alloc, const void *W, const float *bias,
+                                int32_t M, int32_t N, int32_t K, int32_t epi, void *out_bf16, int32_t ldo, float *resid,
+                                int32_t ldr, const float *scale_ptr, const void *addend, const float *stats_in,
+                                const float *fold_c, float ln_eps, float *stats_out, void *hb_out, void *stream) {
+    CH_REQUIRE(X && W, "debug_gemm_ln: null operand");
+    CH_REQUIRE(epi >= EPI_BIAS_STATS && epi <= EPI_FOLD_GELU, "debug_gemm_ln: epilogue must be one of the LayerNorm-fold modes");
+    GemmParams p{};
+    p.X = (const bf16_t *)X; p.W = (const bf16_t *)W; p.M = M; p.N = N; p.K = K; p.X_rows_alloc = X_rows_alloc;
+    p.bias = bias; p.out_bf16 = (bf16_t *)out_bf16; p.ldo = ldo; p.resid = resid; p.ldr = ldr; p.scale_ptr = scale_ptr;
+    p.addend = (const bf16_t *)addend; p.ld_addend = N;
+    p.stats_in = stats_in; p.fold_c = fold_c; p.ln_eps = ln_eps; p.stats_out = stats_out; p.hb_out = (bf16_t *)hb_out; p.ld_hb = N;
+    if (const char *e = getenv("CH_GEMM_DBG")) p.dbg = atoi(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (variant == 1 || variant == 2) ch_gemm_set_variant(variant);
+    const int rc = ch_gemm_bf16(p, epi, s);
+    if (variant == 1 || variant == 2) ch_gemm_set_variant(0);
+    return rc;
 }
 extern "C" void ch_debug_set_gemm_variant(int32_t v) { ch_gemm_set_variant(v); }
 

@@ -114,6 +114,13 @@ int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *launches_per_
 int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_alloc, const void *W, const float *bias, int32_t M,
                   int32_t N, int32_t K, int32_t epi, void *out_bf16, int32_t ldo, float *resid, int32_t ldr,
                   const float *scale_ptr, const void *addend, void *stream);
+/* The LayerNorm-fold epilogues: epi 6 = bias + row statistics of the bf16 output -> stats_out
+ * [M, N/64, 2]; 7 = epi 4 + hb_out = bf16(resid) + its row statistics; 8/9/10 = y = rstd*(acc - mean*fold_c) + bias
+ * [+ quick_gelu / gelu], mean/rstd from stats_in [M, K/64, 2] (partial sums of the rows of X) and ln_eps. */
+int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_alloc, const void *W, const float *bias, int32_t M,
+                     int32_t N, int32_t K, int32_t epi, void *out_bf16, int32_t ldo, float *resid, int32_t ldr,
+                     const float *scale_ptr, const void *addend, const float *stats_in, const float *fold_c, float ln_eps,
+                     float *stats_out, void *hb_out, void *stream);
 void ch_debug_set_gemm_variant(int32_t variant);
 /* One fused adapter call H += a + scale * (GELU(LN(a) Wd^T + bd) Wu^T + bu) on caller buffers (a [M,D] bf16, H [M,D] fp32,
  * Wd [b,D] fp32, Wu [D, roundup(b,128)] bf16 zero-padded); work_* are caller scratch for the LayerNorm-folded weights. */

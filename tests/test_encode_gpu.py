@@ -192,3 +192,28 @@ def test_two_stream_micro_batches_give_identical_codes(dev, monkeypatch):
         torch.cuda.synchronize()
         for k in ("codes", "packed", "concept_attn"):
             assert torch.equal(one[k], two[k]), k
+
+
+def test_layernorm_fold_chain_matches_the_unfolded_chain(dev, monkeypatch):
+    """Default: LayerNorm folded into the consumer GEMMs (bf16 rounding BEFORE the normalisation, no LayerNorm launches in
+    the layer loop).  CH_LN_FOLD=0: LayerNorm as separate launches (rounding after).  Same weights, same images: both
+    within the encode tolerance of the oracle, and close to each other."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_b16"])
+    cfg["L"] = 4
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    x = eo.synthetic_images(5, cfg["image"])
+    enc = _encoder(sd, cfg["heads"], max_batch=8)
+    fold = enc.encode(x.to(dev))["codes"].cpu()
+    hid_fold = enc.hidden_states(x.to(dev), cfg["L"]).cpu()
+    monkeypatch.setenv("CH_LN_FOLD", "0")
+    enc0 = _encoder(sd, cfg["heads"], max_batch=8)
+    plain = enc0.encode(x.to(dev))["codes"].cpu()
+    hid_plain = enc0.hidden_states(x.to(dev), cfg["L"]).cpu()
+    monkeypatch.delenv("CH_LN_FOLD")
+    st = {}
+    ref = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False, stages=st)["codes"]
+    assert not torch.equal(fold, plain)                       # really a different code path
+    assert _rel_err(fold, ref) < 4e-2 and _rel_err(plain, ref) < 4e-2 and _rel_err(fold, plain) < 2e-2
+    assert _rel_err(hid_fold, hid_plain) < 4e-2               # max-abs / RMS of the final residual stream
+    assert float((hid_fold - hid_plain).pow(2).mean().sqrt() / hid_plain.pow(2).mean().sqrt()) < 5e-3

@@ -125,3 +125,96 @@ def test_persistent_pingpong_equals_two_phase_bitwise(M, N, K):
     resid = torch.zeros(X.shape[0], N, device="cuda")
     with pytest.raises(RuntimeError, match="gemm_ppp"):
         _gemm(5, X, W, bias, M, EPI_BIAS_RESID, out=ref, resid=resid)
+
+
+# ---- LayerNorm folded into the consumer GEMM (kernels.h EPI_BIAS_STATS .. EPI_FOLD_GELU, DESIGN.md section 3.6) -----------
+EPI_BIAS_STATS, EPI_SCALE_RESID_STATS, EPI_FOLD_BIAS, EPI_FOLD_QGELU, EPI_FOLD_GELU = 6, 7, 8, 9, 10
+
+
+def _gemm_ln(variant, X, W, bias, M, epi, out=None, resid=None, scale=None, addend=None, stats_in=None, fold_c=None,
+             eps=1e-5, stats_out=None, hb_out=None):
+    from concepthash_amd import _lib
+    lib = _lib.load()
+    N, K = W.shape
+    _lib.check(lib.ch_debug_gemm_ln(variant, _lib.ptr(X), X.shape[0], _lib.ptr(W), _lib.ptr(bias), M, N, K, epi,
+                                    _lib.ptr(out), N if out is not None else 0, _lib.ptr(resid),
+                                    N if resid is not None else 0, _lib.ptr(scale), _lib.ptr(addend), _lib.ptr(stats_in),
+                                    _lib.ptr(fold_c), eps, _lib.ptr(stats_out), _lib.ptr(hb_out), _lib.stream_ptr()),
+               "ch_debug_gemm_ln")
+
+
+def _slice_stats(x_bf16, M):
+    """[M, N/64, 2] (sum, sum of squares) over 64-column slices of the bf16 values, in fp64."""
+    x = x_bf16[:M].double().view(M, -1, 64)
+    return torch.stack([x.sum(-1), (x * x).sum(-1)], dim=-1)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (513, 768, 3072), (300, 768, 384), (2011, 256, 640)])
+def test_statistics_producers(variant, M, N, K):
+    X, W, bias, resid0 = _inputs(M, N, K, seed=3)
+    # bias + statistics: the output is bit-identical to the plain bias epilogue, statistics describe the ROUNDED output
+    ref = torch.zeros(X.shape[0], N, dtype=torch.bfloat16, device="cuda")
+    _gemm(variant, X, W, bias, M, EPI_BIAS, out=ref)
+    out = torch.zeros_like(ref)
+    stats = torch.full((X.shape[0], N // 64, 2), float("nan"), device="cuda")
+    _gemm_ln(variant, X, W, bias, M, EPI_BIAS_STATS, out=out, stats_out=stats)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    want = _slice_stats(out, M)
+    assert torch.allclose(stats[:M].double(), want, rtol=1e-5, atol=1e-4), float((stats[:M].double() - want).abs().max())
+    assert bool(torch.isnan(stats[M:]).all())
+    # residual update + bf16 copy + statistics of the copy
+    scale = torch.tensor([0.7], device="cuda")
+    addend = torch.randn(X.shape[0], N, device="cuda").to(torch.bfloat16)
+    r_ref = resid0.clone()
+    _gemm(variant, X, W, bias, M, EPI_SCALE_RESID, resid=r_ref, scale=scale, addend=addend)
+    r = resid0.clone()
+    hb = torch.zeros(X.shape[0], N, dtype=torch.bfloat16, device="cuda")
+    stats = torch.full((X.shape[0], N // 64, 2), float("nan"), device="cuda")
+    _gemm_ln(variant, X, W, bias, M, EPI_SCALE_RESID_STATS, resid=r, scale=scale, addend=addend, stats_out=stats, hb_out=hb)
+    torch.cuda.synchronize()
+    assert torch.equal(r, r_ref)
+    assert torch.equal(hb[:M].view(torch.int16), r[:M].to(torch.bfloat16).view(torch.int16))
+    assert not bool(hb[M:].any())
+    want = _slice_stats(hb, M)
+    assert torch.allclose(stats[:M].double(), want, rtol=1e-5, atol=1e-4)
+    assert bool(torch.isnan(stats[M:]).all())
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (700, 3072, 768), (515, 384, 768), (300, 256, 128), (257, 512, 1280)])
+def test_layernorm_folded_consumers(variant, M, N, K):
+    """y = act(LN(x) W^T + b) computed as act(rstd * (x W'^T - mean * c) + d) with W' = bf16(W * gamma)."""
+    if variant == 2 and N % 256:
+        pytest.skip("the 256x256 kernel needs N % 256 == 0")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Mp = (M + 255) // 256 * 256
+    x = torch.randn(M, K, generator=g, device="cuda") * (0.5 + 3 * torch.rand(M, 1, generator=g, device="cuda")) \
+        + 2 * torch.randn(M, 1, generator=g, device="cuda")            # per-row scale and a non-zero mean
+    x[:, 5] *= 20                                                       # an outlier channel
+    X = torch.zeros(Mp, K, dtype=torch.bfloat16, device="cuda")
+    X[:M] = x.to(torch.bfloat16)
+    W32 = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    gamma = 1 + 0.3 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.2 * torch.randn(K, generator=g, device="cuda")
+    b = torch.randn(N, generator=g, device="cuda")
+    Wf = (W32 * gamma).to(torch.bfloat16)
+    c = Wf.float().sum(1)
+    d = b + W32 @ beta
+    stats = torch.zeros(Mp, K // 64, 2, device="cuda")
+    stats[:M] = _slice_stats(X, M).float()
+    eps = 1e-5
+    xn = torch.nn.functional.layer_norm(X[:M].double(), (K,), gamma.double(), beta.double(), eps)
+    pre = xn @ W32.double().t() + b.double()
+    for epi, f in ((EPI_FOLD_BIAS, lambda v: v), (EPI_FOLD_QGELU, lambda v: v * torch.sigmoid(1.702 * v)),
+                   (EPI_FOLD_GELU, torch.nn.functional.gelu)):
+        out = torch.full((Mp, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _gemm_ln(variant, X, Wf, d, M, epi, out=out, stats_in=stats, fold_c=c, eps=eps)
+        torch.cuda.synchronize()
+        want = f(pre).float()
+        err = (out[:M].float() - want).abs()
+        # bf16 rounding of W' (2^-9 relative per term, random signs over K terms) + bf16 output rounding
+        assert torch.allclose(out[:M].float(), want, atol=3e-2, rtol=2 ** -7), (epi, float(err.max()))
+        assert float(err.pow(2).mean().sqrt()) < 6e-3, (epi, float(err.pow(2).mean().sqrt()))
+        assert bool(torch.isnan(out[M:].float()).all())

@@ -18,34 +18,62 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=51456)
     ap.add_argument("--rounds", type=int, default=10)
-    ap.add_argument("--variants", default="1,2")
+    ap.add_argument("--variants", default="1,2", help="comma list; '5s12000' = variant 5 with CH_PPP_SKEW_NS=12000, '5f1' = CH_PPP_FLAGS=1")
+    ap.add_argument("--shapes", default="")
+    ap.add_argument("--epi", type=int, default=-1, help="override the epilogue of every shape")
     a = ap.parse_args()
     lib = _lib.load()
     M = a.rows
     Mp = (M + 255) // 256 * 256
-    variants = [int(v) for v in a.variants.split(",")]
+    import re
+    variants = a.variants.split(",")
+
+    def parse(tok):
+        m = re.fullmatch(r"(\d+)(?:s(\d+))?(?:f(\d+))?(?:e(\d+))?(?:d(\d+))?", tok)
+        return int(m.group(1)), m.group(2) or "0", m.group(3) or "0", int(m.group(4)) if m.group(4) else None, m.group(5) or "0"
     scale = torch.tensor([0.5], device="cuda")
     for name, N, K, epi in SHAPES:
+        if a.shapes and name not in a.shapes.split(","):
+            continue
+        if a.epi >= 0:
+            epi = a.epi
         X = torch.randn(Mp, K, device="cuda").to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")
         out = torch.empty(Mp, N, dtype=torch.bfloat16, device="cuda")
         resid = torch.zeros(Mp, N, device="cuda")
+        stats_in = torch.rand(Mp, K // 64, 2, device="cuda") * 64
+        stats_in[..., 1] += 64
+        stats_out = torch.zeros(Mp, N // 64, 2, device="cuda")
+        fold_c = torch.randn(N, device="cuda")
+        hb = torch.empty(Mp, N, dtype=torch.bfloat16, device="cuda")
+        addend = torch.zeros(Mp, N, dtype=torch.bfloat16, device="cuda")
         times = {v: [] for v in variants}
         for r in range(a.rounds + 2):
-            for v in variants:
+            for vt in variants:
+                v, skew, flags, epi_v, dbg = parse(vt)
+                os.environ["CH_GEMM_DBG"] = dbg
+                ep = epi if epi_v is None else epi_v
+                os.environ["CH_PPP_SKEW_NS"], os.environ["CH_PPP_FLAGS"] = skew, flags
                 if v in (2, 5, 21, 22, 23, 24, 25, 26, 27) and (N % 256 or K % 128):
                     continue
-                if v == 5 and epi > 2:
+                if v == 5 and ep > 2:
                     continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                _lib.check(lib.ch_debug_gemm(v, _lib.ptr(X), Mp, _lib.ptr(W), _lib.ptr(bias), M, N, K, epi, _lib.ptr(out), N,
-                                             _lib.ptr(resid), N, _lib.ptr(scale), None, _lib.stream_ptr()), "gemm")
+                if ep >= 6:
+                    _lib.check(lib.ch_debug_gemm_ln(v, _lib.ptr(X), Mp, _lib.ptr(W), _lib.ptr(bias), M, N, K, ep, _lib.ptr(out), N,
+                                                    _lib.ptr(resid), N, _lib.ptr(scale), _lib.ptr(addend), _lib.ptr(stats_in),
+                                                    _lib.ptr(fold_c), 1e-5, _lib.ptr(stats_out), _lib.ptr(hb),
+                                                    _lib.stream_ptr()), "gemm_ln")
+                else:
+                    _lib.check(lib.ch_debug_gemm(v, _lib.ptr(X), Mp, _lib.ptr(W), _lib.ptr(bias), M, N, K, ep, _lib.ptr(out), N,
+                                                 _lib.ptr(resid), N, _lib.ptr(scale), _lib.ptr(addend) if ep == 4 else None,
+                                                 _lib.stream_ptr()), "gemm")
                 e1.record()
                 torch.cuda.synchronize()
                 if r >= 2:
-                    times[v].append(e0.elapsed_time(e1))
+                    times[vt].append(e0.elapsed_time(e1))
         fl = 2.0 * M * N * K
         msg = f"{name:5s} M={M} N={N:5d} K={K:5d} epi={epi}:"
         for v in variants:
