@@ -70,7 +70,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
 
     const int tiles_n = p.N / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // blocks [0, split_full) own one tile each; the tiles of the last, partial round are cut along K into split_s slices
+    // (blocks split_full + tile * split_s + slice) whose fp32 partial tiles the last arriver sums -- see the split-K block
+    // after the K loop.  Without a split split_full = tiles and split_s = 1.
+    const bool split = (int)blockIdx.x >= p.split_full;  // workgroup-uniform
+    const int unit = (int)blockIdx.x - p.split_full;
+    const int split_tile = split ? unit / p.split_s : 0, slice = split ? unit - split_tile * p.split_s : 0;
+    const int wg = xcd_remap(split ? p.split_full + split_tile : (int)blockIdx.x, tiles_m * tiles_n);
     // tile order inside an XCD's contiguous chunk: n-tiles are taken in groups of p.group_n whose weight panels stay
     // L2-resident (<= ~2.4 MB) while the m-tiles sweep past; inside a group n is fastest so the co-resident workgroups of
     // an XCD share activation panels too.  (host: gemm_group_n)
@@ -159,18 +165,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     } while (0)
 
     const int nk = p.K / BK;  // even, >= 2
-    const int J = nk >> 1;
+    const int J = split ? (nk >> 1) / p.split_s : (nk >> 1);  // iterations (pairs of K-tiles) of this block
+    const int j0 = slice * J;
+    const int kb0 = 2 * j0;  // first K-tile (even, so the buffer parity of the schedule is unchanged)
 
     // ---- prologue: K-tile 0 complete (4 half-tiles) + 3 half-tiles of K-tile 1; retire K-tile 0 with vmcnt(6)
     f32x4 fold_v[5];
     if constexpr (ch_epi::traits<EPI>::fold) if (!(p.dbg & 1)) ch_epi::fold_stats_issue(p, m0, tid, fold_v);  // older than every DMA below
-    issue(0, 0);
-    issue(2, 0);
-    issue(3, 0);
-    issue(1, 0);
-    issue(0, 1);
-    issue(2, 1);
-    issue(3, 1);
+    issue(0, kb0);
+    issue(2, kb0);
+    issue(3, kb0);
+    issue(1, kb0);
+    issue(0, kb0 + 1);
+    issue(2, kb0 + 1);
+    issue(3, kb0 + 1);
     PP_WAIT_VM(6);
     if constexpr (ch_epi::traits<EPI>::fold) if (!(p.dbg & 1)) {  // per-row (mean, rstd) of the LN-folded input
         ch_epi::fold_stats_finish(p, tid, fold_v, (float *)(smem + 2 * BUF_BYTES));
@@ -179,9 +187,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     PP_BARRIER();
     if (wr == 1) PP_BARRIER();  // stagger: waves 4-7 run one barrier behind waves 0-3
 
-    for (int j = 0; j < J; ++j) {
-        const bool more = (j + 1 < J);  // K-tiles 2j+2 / 2j+3 exist
-        const int ke = 2 * j, ko = 2 * j + 1;
+    for (int jj = 0; jj < J; ++jj) {
+        const bool more = (jj + 1 < J);  // K-tiles ke+2 / ke+3 belong to this block
+        const int ke = 2 * (j0 + jj), ko = ke + 1;
         // ================= even buffer, K-tile ke =================
         // phase 1
         read_w(Wa, 0, 0);
@@ -249,6 +257,49 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     }
     if (wr == 0) PP_BARRIER();  // balance the stagger barrier
 
+    // ---- split-K tail: publish this slice's partial tile; the LAST arriver (agent-scope ticket) sums all slices in slice
+    // order -- its own included, read back from memory, so the result does not depend on who arrives last -- and runs the
+    // epilogue.  No workgroup ever waits for another one.  Visibility without cache-wide fences (an agent-scope release /
+    // acquire pair writes back and invalidates the whole XCD L2 under the other workgroups' feet: measured +25..40 us per
+    // launch): every slab byte is stored write-through (sc1) and drained by the storing wave before the barrier that
+    // precedes the ticket, and every slab load is an sc1 load.
+    if (split) {
+        if (p.dbg & 8) return;   // timing experiment: no fix-up at all
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        constexpr unsigned SLAB_BYTES = BM * BN * 4;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(p.splitk_ws, 0, (int)CH_SPLITK_WS_BYTES, 0x00020000);
+        const unsigned tile_off = (unsigned)(split_tile * p.split_s) * SLAB_BYTES;
+        const unsigned lane_off = (unsigned)tid * 16;
+        {
+            const unsigned base = tile_off + (unsigned)slice * SLAB_BYTES + lane_off;
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, acc[i >> 3][i & 7]), rsrc, base + i * (NTHREADS * 16), 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned *ticket_lds = (unsigned *)(smem + 2 * BUF_BYTES + CH_FOLD_LDS_BYTES);
+        if (tid == 0)
+            *ticket_lds = __hip_atomic_fetch_add(p.splitk_cnt + split_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ticket = *ticket_lds;
+        if (ticket != (unsigned)(p.split_s - 1)) return;
+        if (p.dbg & 16) { if (tid == 0) __hip_atomic_store(p.splitk_cnt + split_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        if (tid == 0)  // ready for the next launch
+            __hip_atomic_store(p.splitk_cnt + split_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the slab loads below the ticket
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < p.split_s; ++sl) {
+            const unsigned base = tile_off + (unsigned)sl * SLAB_BYTES + lane_off;
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                acc[i >> 3][i & 7] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + i * (NTHREADS * 16), 0, 16));
+        }
+    }
+
     if constexpr (DBG & 4) {  // keep the accumulators alive with one store per lane
         f32x4 t = acc[0][0];
 #pragma unroll
@@ -264,18 +315,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
                                (const float *)(smem + 2 * BUF_BYTES) + 2 * (wr * 128));
 }
 
+// Tail split: with G compute units, tiles = full rounds * G + R.  The R tiles of the last round would keep R units busy for
+// a whole tile time; cut along K into S slices they keep R * S <= G units busy for 1/S of it.  S must divide the K-loop's
+// iteration count.
+// OPT-IN (CH_GEMM_SPLITK=1, or the debug tap): measured on MI355X at M = 51456 the fix-up costs more than the shorter tail
+// saves -- one workgroup moves its 256 KB fp32 slab at only ~25-30 GB/s (write-through stores 3-11 us per slice, sc1 loads
+// 9.5 us per slab), against 8 us (K = 768) to 24 us (K = 3072) saved: qkv 206 -> 223 us (S = 2) / 252 us (S = 6),
+// fc2 223 -> 229 us.  With agent-scope release/acquire fences instead of sc1 accesses it is another 5-20 us slower (the
+// fences write back / invalidate the XCD's whole L2 under the other workgroups).  DESIGN.md section 3.7.
+void ch_pp_choose_split(GemmParams &p, int tiles) {
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    static const int enabled = getenv("CH_GEMM_SPLITK") ? atoi(getenv("CH_GEMM_SPLITK")) : 0;
+    p.split_full = tiles;
+    p.split_s = 1;
+    if (!(enabled || p.force_split) || !p.splitk_ws || !p.splitk_cnt) return;
+    const int R = tiles % ncu, J = p.K / (2 * BK);
+    if (R == 0) return;
+    int S = 1;
+    for (int c = 2; c <= 8; ++c)
+        if (J % c == 0 && R * c <= ncu && R * c <= 256) S = c;
+    if (const char *e = getenv("CH_GEMM_SPLITK_S")) S = (J % atoi(e) == 0 && R * atoi(e) <= ncu) ? atoi(e) : S;
+    if (S < 2 || J / S < 1) return;
+    p.split_full = tiles - R;
+    p.split_s = S;
+}
+
 template <int EPI>
 int launch_pp(const GemmParams &p0, hipStream_t s) {
     GemmParams p = p0;
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-    constexpr int lds = 2 * BUF_BYTES + (ch_epi::traits<EPI>::fold ? CH_FOLD_LDS_BYTES : 0);
+    constexpr int lds = 2 * BUF_BYTES + CH_FOLD_LDS_BYTES + 16;  // operands + (mean, rstd) table + split-K ticket
+    ch_pp_choose_split(p, tiles);
     static bool attr_set = false;
     if (!attr_set) {
         CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_pp_kernel<EPI>, dim3(tiles), dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL(gemm_pp_kernel<EPI>, dim3(p.split_full + (tiles - p.split_full) * p.split_s), dim3(NTHREADS), lds, s, p);
     CH_LAUNCH_CHECK();
     return 0;
 }
@@ -292,6 +373,8 @@ int ch_gemm_bf16_pp_dbg(const GemmParams &p0, int dbg, hipStream_t s) {
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (!ch_gemm_pp_supported(p)) return 2;
+    p.split_full = tiles;
+    p.split_s = 1;
 #define PP_DBG_CASE(D)                                                                                                   \
     case D:                                                                                                              \
         (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI_BIAS, D>, hipFuncAttributeMaxDynamicSharedMemorySize,   \

@@ -47,7 +47,15 @@ struct GemmParams {
     const float *fold_c;     // [N]
     float ln_eps;
     int dbg;                 // timing experiments only (CH_GEMM_DBG through ch_debug_gemm_ln)
+    // split-K tail of the 256x256 kernel (gemm_pp.hip): fp32 slabs [<= 256 units][256*256] + one counter per split tile;
+    // nullptr = every tile is computed by one workgroup.  split_full / split_s are set by the launcher.
+    float *splitk_ws;
+    unsigned *splitk_cnt;
+    int split_full, split_s;
+    int force_split;         // debug taps: split even though CH_GEMM_SPLITK is off
 };
+constexpr size_t CH_SPLITK_WS_BYTES = (size_t)256 * 256 * 256 * 4;  // 64 MiB: at most 256 tail units of one 256x256 fp32 slab
+constexpr size_t CH_SPLITK_CNT_BYTES = 256 * sizeof(unsigned);
 constexpr int CH_FOLD_LDS_BYTES = 2048;  // per-row (mean, rstd) table of a <= 256-row block tile
 int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);      // dispatcher
 int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s);   // gemm_bf16.hip: 128x128x64, two-phase

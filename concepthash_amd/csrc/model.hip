@@ -71,6 +71,8 @@ struct ch_model {
     // workspace
     int64_t rows_alloc = 0, prow_alloc = 0;
     float *H = nullptr;
+    float *splitk_ws[2] = {nullptr, nullptr};      // split-K tail slabs + tickets of the 256x256 GEMM, one set per chain
+    unsigned *splitk_cnt[2] = {nullptr, nullptr};
     float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn
     bf16_t *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *A = nullptr, *AD = nullptr, *F1 = nullptr, *PATCH = nullptr;
 };
@@ -371,6 +373,13 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
     m->prow_alloc = prows;
     m->H = (float *)B.alloc(sizeof(float) * rows * D);
     m->Xn = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * D);
+    const bool want_splitk = getenv("CH_GEMM_SPLITK") && atoi(getenv("CH_GEMM_SPLITK")) != 0;  // opt-in, see gemm_pp.hip
+    for (int i = 0; want_splitk && i < (m->nstreams >= 2 ? 2 : 1); ++i) {
+        m->splitk_ws[i] = (float *)B.alloc(CH_SPLITK_WS_BYTES);
+        m->splitk_cnt[i] = (unsigned *)B.alloc(CH_SPLITK_CNT_BYTES);
+        if (!B.ok) return 4;
+        CH_CHECK_HIP(hipMemset(m->splitk_cnt[i], 0, CH_SPLITK_CNT_BYTES));
+    }
     m->statsA = (float *)B.alloc(sizeof(float) * rows * (D / 64) * 2);
     m->statsH = (float *)B.alloc(sizeof(float) * rows * (D / 64) * 2);
     m->QKV = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * 3 * D);
@@ -454,6 +463,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
                     int epi, bf16_t *out, int ldo, const float *scale, const bf16_t *addend = nullptr, const Fold &f = Fold()) {
         mark(mm, pi, cat, 2.0 * rows * (double)n_true * k_true, s);
         GemmParams p{};
+        p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi];
         p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
         p.X = X; p.W = W; p.M = rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
@@ -721,6 +731,24 @@ extern "C" int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *la
     return 0;
 }
 
+// split-K workspace of the debug taps (off by default so that the 256x256 kernel stays bit-identical to the 128x128 one)
+static bool g_debug_splitk = false;
+static float *g_debug_ws = nullptr;
+static unsigned *g_debug_cnt = nullptr;
+static int debug_attach_splitk(GemmParams &p) {
+    if (!g_debug_splitk) return 0;
+    if (!g_debug_ws) {
+        CH_CHECK_HIP(hipMalloc((void **)&g_debug_ws, CH_SPLITK_WS_BYTES));
+        CH_CHECK_HIP(hipMalloc((void **)&g_debug_cnt, CH_SPLITK_CNT_BYTES));
+        CH_CHECK_HIP(hipMemset(g_debug_cnt, 0, CH_SPLITK_CNT_BYTES));
+    }
+    p.splitk_ws = g_debug_ws;
+    p.splitk_cnt = g_debug_cnt;
+    p.force_split = 1;
+    return 0;
+}
+extern "C" void ch_debug_set_gemm_splitk(int32_t on) { g_debug_splitk = on != 0; }
+
 // ---- test / bench tap: one GEMM launch on caller buffers (tests/test_gemm_gpu.py, tools/gemm_bench.py) -----------------
 extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_alloc, const void *W, const float *bias,
                              int32_t M, int32_t N, int32_t K, int32_t epi, void *out_bf16, int32_t ldo, float *resid,
@@ -731,6 +759,8 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
     p.X = (const bf16_t *)X; p.W = (const bf16_t *)W; p.M = M; p.N = N; p.K = K; p.X_rows_alloc = X_rows_alloc;
     p.bias = bias; p.out_bf16 = (bf16_t *)out_bf16; p.ldo = ldo; p.resid = resid; p.ldr = ldr; p.scale_ptr = scale_ptr; p.addend = (const bf16_t *)addend; p.ld_addend = N;
     hipStream_t s = (hipStream_t)stream;
+    if (int e = debug_attach_splitk(p)) return e;
+    if (const char *e = getenv("CH_GEMM_DBG")) p.dbg = atoi(e);
     if (variant == 1) return ch_gemm_bf16_v1(p, epi, s);
     if (variant == 2) return ch_gemm_bf16_pp(p, epi, s);
     if (variant == 3) return ch_gemm_bf16_dp(p, epi, s);
@@ -751,6 +781,7 @@ extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_a
     p.stats_in = stats_in; p.fold_c = fold_c; p.ln_eps = ln_eps; p.stats_out = stats_out; p.hb_out = (bf16_t *)hb_out; p.ld_hb = N;
     if (const char *e = getenv("CH_GEMM_DBG")) p.dbg = atoi(e);
     hipStream_t s = (hipStream_t)stream;
+    if (int e = debug_attach_splitk(p)) return e;
     if (variant == 1 || variant == 2) ch_gemm_set_variant(variant);
     const int rc = ch_gemm_bf16(p, epi, s);
     if (variant == 1 || variant == 2) ch_gemm_set_variant(0);

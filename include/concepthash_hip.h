@@ -122,6 +122,9 @@ int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_alloc, const
                      const float *scale_ptr, const void *addend, const float *stats_in, const float *fold_c, float ln_eps,
                      float *stats_out, void *hb_out, void *stream);
 void ch_debug_set_gemm_variant(int32_t variant);
+/* Let the debug GEMM taps use the split-K tail of the 256x256 kernel (off by default: a split tile sums its K slices in a
+ * different order, so it is no longer bit-identical to the 128x128 kernel). */
+void ch_debug_set_gemm_splitk(int32_t on);
 /* One fused adapter call H += a + scale * (GELU(LN(a) Wd^T + bd) Wu^T + bu) on caller buffers (a [M,D] bf16, H [M,D] fp32,
  * Wd [b,D] fp32, Wu [D, roundup(b,128)] bf16 zero-padded); work_* are caller scratch for the LayerNorm-folded weights. */
 int ch_debug_adapter(const void *A, float *H, int32_t M, int32_t D, int32_t b, const float *Wd, const float *bd,

@@ -29,8 +29,8 @@ def main():
     variants = a.variants.split(",")
 
     def parse(tok):
-        m = re.fullmatch(r"(\d+)(?:s(\d+))?(?:f(\d+))?(?:e(\d+))?(?:d(\d+))?", tok)
-        return int(m.group(1)), m.group(2) or "0", m.group(3) or "0", int(m.group(4)) if m.group(4) else None, m.group(5) or "0"
+        m = re.fullmatch(r"(\d+)(?:s(\d+))?(?:f(\d+))?(?:e(\d+))?(?:d(\d+))?(?:k(\d))?", tok)
+        return int(m.group(1)), m.group(2) or "0", m.group(3) or "0", int(m.group(4)) if m.group(4) else None, m.group(5) or "0", int(m.group(6) or 0)
     scale = torch.tensor([0.5], device="cuda")
     for name, N, K, epi in SHAPES:
         if a.shapes and name not in a.shapes.split(","):
@@ -51,7 +51,8 @@ def main():
         times = {v: [] for v in variants}
         for r in range(a.rounds + 2):
             for vt in variants:
-                v, skew, flags, epi_v, dbg = parse(vt)
+                v, skew, flags, epi_v, dbg, sk = parse(vt)
+                lib.ch_debug_set_gemm_splitk(sk)
                 os.environ["CH_GEMM_DBG"] = dbg
                 ep = epi if epi_v is None else epi_v
                 os.environ["CH_PPP_SKEW_NS"], os.environ["CH_PPP_FLAGS"] = skew, flags
