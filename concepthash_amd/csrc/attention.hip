@@ -5,7 +5,7 @@
 // materialises every layer's (B,heads,N,N) probability map (output_attentions=True, models/arch/coop.py:474-479); retrieval
 // never reads it, so this kernel keeps scores in registers and never writes them.
 //
-// One workgroup (4 waves) per (image, head).  The head's whole K and V are staged ROW-MAJOR into LDS by LDS-DMA
+// One workgroup (8 waves) per (image, head).  The head's whole K and V are staged ROW-MAJOR into LDS by LDS-DMA
 // (global_load_lds_dwordx4: no VGPR round trip, all 14 requests of a wave in flight at once); rows are 128 B with the
 // 16-B chunk index XOR (row & 7) applied on the per-lane source address.  Each wave takes 16-query tiles round robin:
 //   S^T = K Q^T      v_mfma_f32_16x16x32_bf16 with A = K tile (ds_read_b128, conflict free), B = Q^T fragment straight
@@ -22,13 +22,14 @@
 namespace {
 
 constexpr int HD = 64;
+constexpr int NW = 8;  // waves per workgroup: 13 query tiles (201 tokens) take two rounds instead of four with 4 waves; K/V staged once
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s lds_v4s;
 
-template <int KB>  // number of 32-key blocks (keys padded to KB*32)
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ qkv, int ntok, int heads, float scale_log2e,
+template <int KB, bool TAP>  // KB: number of 32-key blocks (keys padded to KB*32); TAP: write the concept-token attention rows
+__global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__restrict__ qkv, int ntok, int heads, float scale_log2e,
                                                         bf16_t *__restrict__ out, float *__restrict__ cattn, int ncon) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = KB * 2;   // 16-key tiles
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
     {
         const int lrow = lane >> 3;
         const int src_chunk = (lane & 7) ^ lrow;
-        for (int i = wid; i < KP / 8; i += 4) {
+        for (int i = wid; i < KP / 8; i += NW) {
             int row = i * 8 + lrow;
             row = row < ntok ? row : ntok - 1;
             const bf16_t *src = base + (size_t)row * ld + src_chunk * 8;
@@ -78,22 +79,39 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         voff[dt] = (fq * 4 + tq) * 128 + (((dt * 2 + (tp >> 1)) ^ trow7) << 4) + (tp & 1) * 8;
     const int koff0 = fr * 128 + ((fq ^ (fr & 7)) << 4), koff1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
 
-    for (int qt = wid; qt < QT; qt += 4) {
+    for (int qt = wid; qt < QT; qt += NW) {
+        // S^T in chunks of two key tiles, fragment reads of chunk c+1 issued before the MFMAs of chunk c; the scheduling fences
+        // keep the compiler from hoisting all 28 reads (112 VGPRs) above the first MFMA, which costs the third wave per SIMD
         f32x4 st[KT];
+        bf16x8 kf[2][4];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const bf16x8 k0 = *(const bf16x8 *)(Ks + kt * 2048 + koff0);
-            const bf16x8 k1 = *(const bf16x8 *)(Ks + kt * 2048 + koff1);
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
-            st[kt] = a;
+        for (int t = 0; t < 2; ++t) {
+            kf[0][2 * t] = *(const bf16x8 *)(Ks + t * 2048 + koff0);
+            kf[0][2 * t + 1] = *(const bf16x8 *)(Ks + t * 2048 + koff1);
+        }
+#pragma unroll
+        for (int c = 0; c < KB; ++c) {
+            if (c + 1 < KB) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    kf[(c + 1) & 1][2 * t] = *(const bf16x8 *)(Ks + (2 * c + 2 + t) * 2048 + koff0);
+                    kf[(c + 1) & 1][2 * t + 1] = *(const bf16x8 *)(Ks + (2 * c + 2 + t) * 2048 + koff1);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c & 1][2 * t], qf0, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[c & 1][2 * t + 1], qf1, a, 0, 0, 0);
+                st[2 * c + t] = a;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const bool cur_valid = qvalid;
         const int cur_q = q;
         // prefetch the next tile's Q fragments
-        if (qt + 4 < QT) {
-            q = (qt + 4) * 16 + fr;
+        if (qt + NW < QT) {
+            q = (qt + NW) * 16 + fr;
             qvalid = q < ntok;
             if (!qvalid) q = ntok - 1;
             qf0 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8);
@@ -130,7 +148,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         const float inv = 1.0f / sum;
         // optional interpretability tap (last layer only): softmax rows of the `ncon` concept tokens over the patch tokens,
         // = attn_cache[-1][:, :, -Q:, 1:-Q] of the reference (models/arch/coop.py:481-482, models/loss/coop.py:164-176)
-        if (cattn != nullptr && cur_valid && cur_q >= ntok - ncon) {
+        if (TAP && cur_valid && cur_q >= ntok - ncon) {
             const int np = ntok - ncon - 1;
             float *dst = cattn + (((size_t)b * heads + h) * ncon + (cur_q - (ntok - ncon))) * np;
 #pragma unroll
@@ -146,8 +164,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        union VF {
+            bf16x8 v;
+            v4s h[2];
+        };
+        VF vf[2][4];
+        // keys 32kb + 4fq + 0..3 (elements 0..3) and + 16 (elements 4..7): immediate offsets off one lane base
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            vf[0][dt].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Vs + voff[dt]));
+            vf[0][dt].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Vs + 2048 + voff[dt]));
+        }
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
+            if (kb + 1 < KB) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    vf[(kb + 1) & 1][dt].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Vs + (kb + 1) * 4096 + voff[dt]));
+                    vf[(kb + 1) & 1][dt].h[1] =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Vs + (kb + 1) * 4096 + 2048 + voff[dt]));
+                }
+            }
             union {
                 bf16x8 v;
                 uint32_t u[4];
@@ -157,16 +194,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             pf.u[2] = pack_bf16x2(st[2 * kb + 1][0], st[2 * kb + 1][1]);
             pf.u[3] = pack_bf16x2(st[2 * kb + 1][2], st[2 * kb + 1][3]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                union {
-                    bf16x8 v;
-                    v4s h[2];
-                } vf;
-                // keys 32kb + 4fq + 0..3 (elements 0..3) and + 16 (elements 4..7): immediate offsets off one lane base
-                vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Vs + kb * 4096 + voff[dt]));
-                vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Vs + kb * 4096 + 2048 + voff[dt]));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
-            }
+            for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb & 1][dt].v, pf.v, o[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (cur_valid) {
             bf16_t *op = out + ((size_t)b * ntok + cur_q) * D + h * HD + fq * 4;
@@ -188,12 +217,19 @@ int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, floa
     CH_REQUIRE(lds <= 160 * 1024, "attention: sequence too long for the LDS-resident K/V kernel");
     static bool attr_set = false;
     if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        CH_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KB, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+        CH_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
         attr_set = true;
     }
     const float scale_log2e = 0.125f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e), head_dim = 64
-    hipLaunchKernelGGL(attention_kernel<KB>, dim3(B * heads), dim3(256), lds, s, qkv, ntok, heads, scale_log2e, out, cattn, ncon);
+    if (cattn)
+        hipLaunchKernelGGL((attention_kernel<KB, true>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, ntok, heads, scale_log2e, out,
+                           cattn, ncon);
+    else
+        hipLaunchKernelGGL((attention_kernel<KB, false>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, ntok, heads, scale_log2e, out,
+                           cattn, ncon);
     CH_LAUNCH_CHECK();
     return 0;
 }
