@@ -89,6 +89,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
     f32x4 fold_v[5];
     if constexpr (ch_epi::traits<EPI>::fold) ch_epi::fold_stats_issue(p, m0, tid, fold_v);
     stage(0, 0);
+    // read-modify-write epilogues: fetch the residual tile now, so that it arrives under the K loop
+    constexpr bool PREF = ch_epi::traits<EPI>::scale_resid;
+    ch_epi::ResidPrefetch rp;
+    if constexpr (PREF) ch_epi::resid_prefetch<EPI>(p, m0 + wm * 64, n0 + wn * 64, lane, rp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ch_epi::traits<EPI>::fold)  // per-row (mean, rstd) of the LN-folded input
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
 
     // ---- epilogue (gemm_epilogue.h): transpose through this wave's 16 KB of the idle staging LDS, full-line stores.
     // The loop's last __syncthreads() guarantees no wave still reads staged operands.
-    ch_epi::store_tile<EPI, 4>(p, acc, smem + wid * 16384, m0 + wm * 64, n0 + wn * 64, lane,
-                               (const float *)(smem + 2 * STAGE_BYTES) + 2 * (wm * 64));
+    ch_epi::store_tile<EPI, 4, PREF>(p, acc, smem + wid * 16384, m0 + wm * 64, n0 + wn * 64, lane,
+                                     (const float *)(smem + 2 * STAGE_BYTES) + 2 * (wm * 64), &rp);
 }
 
 template <int EPI>

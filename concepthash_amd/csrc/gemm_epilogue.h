@@ -104,11 +104,35 @@ __device__ __forceinline__ void fold_stats_finish(const GemmParams &p, int tid, 
     if (!(tid & 1)) *(ch_f32x2_t *)(row_ms + (tid & ~1)) = ch_f32x2_t{mean, rsqrtf(var + p.ln_eps)};
 }
 
+// Residual read-modify-write epilogues of a 64x64 wave tile (MT = 4): the fp32 residual values a lane will
+// update, in the lane mapping of store_tile's read-back loop.  Loaded BEFORE the K loop (64 VGPRs, free in the 128x128
+// kernel at two waves per SIMD) they arrive under the MFMA work, and the epilogue only stores.
+struct ResidPrefetch {
+    f32x4 hv[8];  // the first of the two read-back batches
+    uint2 av[8];
+};
+template <int EPI>
+__device__ __forceinline__ void resid_prefetch(const GemmParams &p, int m_base, int n_base, int lane, ResidPrefetch &r) {
+    const int lrow = lane >> 4, pos = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = j * 4 + lrow;
+        const int m = m_base + row;
+        const int mc = m < p.M ? m : p.M - 1;
+        const int n = n_base + (pos ^ (row & 15)) * 4;
+        r.hv[j] = *(const f32x4 *)(p.resid + (size_t)mc * p.ldr + n);
+        r.av[j] = make_uint2(0u, 0u);
+        if (p.addend) r.av[j] = *(const uint2 *)(p.addend + (size_t)mc * p.ld_addend + n);
+    }
+}
+
 // wave_lds: this wave's 16 KB staging region; m_base / n_base: global row / column of the wave's sub-tile origin;
-// row_ms: (EPI_FOLD_*) the block tile's (mean, rstd) table in LDS, already offset to this wave's first row.
-template <int EPI, int MT>
+// row_ms: (EPI_FOLD_*) the block tile's (mean, rstd) table in LDS, already offset to this wave's first row;
+// pf: (PREF) the residual / addend values loaded by resid_prefetch.
+template <int EPI, int MT, bool PREF = false>
 __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][MT], char *wave_lds, int m_base, int n_base,
-                                           int lane, const float *row_ms = nullptr) {
+                                           int lane, const float *row_ms = nullptr, const ResidPrefetch *pf = nullptr) {
+    static_assert(!PREF || (MT == 4 && traits<EPI>::scale_resid), "prefetched residual: 64-row wave tiles, scale+residual epilogues");
     const int fr = lane & 15, fq = lane >> 4;
     using T = traits<EPI>;
     constexpr bool BF16_ONLY = T::bf16_only;
@@ -217,10 +241,17 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                         hv[i] = *(const f32x4 *)(p.pos + (size_t)(1 + pp) * p.N + n);
                     } else {
                         off[i] = (size_t)mc * p.ldr + n;
-                        hv[i] = *(const f32x4 *)(p.resid + off[i]);
+                        if (PREF && batch == 0)
+                            hv[i] = pf->hv[i];
+                        else
+                            hv[i] = *(const f32x4 *)(p.resid + off[i]);
                         if constexpr (T::scale_resid) {
-                            av[i] = make_uint2(0u, 0u);
-                            if (p.addend) av[i] = *(const uint2 *)(p.addend + (size_t)mc * p.ld_addend + n);
+                            if (PREF && batch == 0) {
+                                av[i] = pf->av[i];
+                            } else {
+                                av[i] = make_uint2(0u, 0u);
+                                if (p.addend) av[i] = *(const uint2 *)(p.addend + (size_t)mc * p.ld_addend + n);
+                            }
                         }
                     }
                 }
