@@ -150,13 +150,13 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
         f32x4 fc[4];
         if constexpr (T::fold) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) fc[nt] = (p.dbg & 4) ? bias[nt] : *(const f32x4 *)(p.fold_c + n_base + nt * 16 + fq * 4);
+            for (int nt = 0; nt < 4; ++nt) fc[nt] = *(const f32x4 *)(p.fold_c + n_base + nt * 16 + fq * 4);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int row = mt * 16 + fr;
             float rs = 1.0f, nm = 0.f;
-            if constexpr (T::fold) if (!(p.dbg & 2)) {
+            if constexpr (T::fold) {
                 const ch_f32x2_t ms = *(const ch_f32x2_t *)(row_ms + 2 * row);
                 rs = ms[1];
                 nm = -ms[0] * ms[1];

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
 
     // ---- prologue: K-tile 0 complete (4 half-tiles) + 3 half-tiles of K-tile 1; retire K-tile 0 with vmcnt(6)
     f32x4 fold_v[5];
-    if constexpr (ch_epi::traits<EPI>::fold) if (!(p.dbg & 1)) ch_epi::fold_stats_issue(p, m0, tid, fold_v);  // older than every DMA below
+    if constexpr (ch_epi::traits<EPI>::fold) ch_epi::fold_stats_issue(p, m0, tid, fold_v);  // older than every DMA below
     issue(0, kb0);
     issue(2, kb0);
     issue(3, kb0);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     issue(2, kb0 + 1);
     issue(3, kb0 + 1);
     PP_WAIT_VM(6);
-    if constexpr (ch_epi::traits<EPI>::fold) if (!(p.dbg & 1)) {  // per-row (mean, rstd) of the LN-folded input
+    if constexpr (ch_epi::traits<EPI>::fold) {  // per-row (mean, rstd) of the LN-folded input
         ch_epi::fold_stats_finish(p, tid, fold_v, (float *)(smem + 2 * BUF_BYTES));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }

@@ -782,6 +782,7 @@ extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_a
     if (const char *e = getenv("CH_GEMM_DBG")) p.dbg = atoi(e);
     hipStream_t s = (hipStream_t)stream;
     if (int e = debug_attach_splitk(p)) return e;
+    if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 1 || variant == 2) ch_gemm_set_variant(variant);
     const int rc = ch_gemm_bf16(p, epi, s);
     if (variant == 1 || variant == 2) ch_gemm_set_variant(0);

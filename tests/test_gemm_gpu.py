@@ -264,3 +264,4 @@ def test_splitk_tail_of_the_pingpong_kernel(splitk, M, N, K):
     assert torch.allclose(r[:M], r_ref[:M], atol=2e-4, rtol=1e-5) and torch.equal(r[M:], r_ref[M:])
     want = _slice_stats(out, M)
     assert torch.allclose(stats[:M].double(), want, rtol=1e-5, atol=1e-4)
+
