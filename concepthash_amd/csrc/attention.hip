@@ -28,7 +28,9 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s lds_v4s;
 
-template <int KB, bool TAP>  // KB: number of 32-key blocks (keys padded to KB*32); TAP: write the concept-token attention rows
+// KB: number of 32-key blocks (keys padded to KB*32); TAP: write the concept-token attention rows; COMPACT: only the rows the
+// hashing head reads -- CLS and the `ncon` concept tokens -- are queries, and the output is [B * (1 + ncon), D] (final layer)
+template <int KB, bool TAP, bool COMPACT>
 __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__restrict__ qkv, int ntok, int heads, float scale_log2e,
                                                         bf16_t *__restrict__ out, float *__restrict__ cattn, int ncon) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,11 +60,22 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__r
         }
     }
     const int fr = lane & 15, fq = lane >> 4;
-    const int QT = (ntok + 15) >> 4;
+    const int nqc = 1 + ncon;  // COMPACT: queries per image
+    const int QT = COMPACT ? (nqc + 15) >> 4 : (ntok + 15) >> 4;
+    // query slot j of this image -> (token row, valid); COMPACT: slot 0 = CLS, slots 1.. = the concept tokens (the last ncon rows)
+    auto query_of = [&](int j, bool &valid) {
+        if constexpr (COMPACT) {
+            valid = j < nqc;
+            return !valid ? ntok - 1 : (j == 0 ? 0 : ntok - ncon + j - 1);
+        } else {
+            valid = j < ntok;
+            return valid ? j : ntok - 1;
+        }
+    };
     // first query tile's Q fragments overlap the staging latency
-    int q = wid * 16 + fr;
-    bool qvalid = q < ntok;
-    if (!qvalid) q = ntok - 1;
+    bool qvalid;
+    int qslot = wid * 16 + fr;
+    int q = query_of(qslot, qvalid);
     bf16x8 qf0 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8);
     bf16x8 qf1 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8 + 32);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -108,12 +121,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__r
             __builtin_amdgcn_sched_barrier(0);
         }
         const bool cur_valid = qvalid;
-        const int cur_q = q;
+        const int cur_q = q, cur_slot = qslot;
         // prefetch the next tile's Q fragments
         if (qt + NW < QT) {
-            q = (qt + NW) * 16 + fr;
-            qvalid = q < ntok;
-            if (!qvalid) q = ntok - 1;
+            qslot = (qt + NW) * 16 + fr;
+            q = query_of(qslot, qvalid);
             qf0 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8);
             qf1 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8 + 32);
         }
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__r
             __builtin_amdgcn_sched_barrier(0);
         }
         if (cur_valid) {
-            bf16_t *op = out + ((size_t)b * ntok + cur_q) * D + h * HD + fq * 4;
+            bf16_t *op = out + (COMPACT ? (size_t)b * nqc + cur_slot : (size_t)b * ntok + cur_q) * D + h * HD + fq * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 uint2 w;
@@ -210,45 +222,48 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__r
     }
 }
 
-template <int KB>
-int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, float *cattn, int ncon, hipStream_t s) {
+template <int KB, bool TAP, bool COMPACT>
+int launch_attn_inst(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, float *cattn, int ncon, hipStream_t s) {
     const int KP = KB * 32;
     const size_t lds = (size_t)KP * 128 * 2;
     CH_REQUIRE(lds <= 160 * 1024, "attention: sequence too long for the LDS-resident K/V kernel");
     static bool attr_set = false;
     if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KB, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KB, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
+        CH_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KB, TAP, COMPACT>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const float scale_log2e = 0.125f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e), head_dim = 64
-    if (cattn)
-        hipLaunchKernelGGL((attention_kernel<KB, true>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, ntok, heads, scale_log2e, out,
-                           cattn, ncon);
-    else
-        hipLaunchKernelGGL((attention_kernel<KB, false>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, ntok, heads, scale_log2e, out,
-                           cattn, ncon);
+    hipLaunchKernelGGL((attention_kernel<KB, TAP, COMPACT>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, ntok, heads, scale_log2e,
+                       out, cattn, ncon);
     CH_LAUNCH_CHECK();
     return 0;
+}
+template <int KB>
+int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, float *cattn, int ncon, bool compact, hipStream_t s) {
+    if (compact)
+        return cattn ? launch_attn_inst<KB, true, true>(qkv, B, ntok, heads, out, cattn, ncon, s)
+                     : launch_attn_inst<KB, false, true>(qkv, B, ntok, heads, out, cattn, ncon, s);
+    return cattn ? launch_attn_inst<KB, true, false>(qkv, B, ntok, heads, out, cattn, ncon, s)
+                 : launch_attn_inst<KB, false, false>(qkv, B, ntok, heads, out, cattn, ncon, s);
 }
 
 }  // namespace
 
-int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s, float *cattn, int ncon) {
+int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s, float *cattn, int ncon, bool compact) {
     CH_REQUIRE(B > 0 && ntok > 0 && heads > 0, "attention: empty problem");
+    CH_REQUIRE(!compact || (ncon >= 1 && ncon < ntok), "attention: compact mode needs 1 <= ncon < ntok");
     const int KB = (ntok + 31) / 32;
     switch (KB) {
-        case 1: return launch_attn<1>(qkv, B, ntok, heads, out, cattn, ncon, s);
-        case 2: return launch_attn<2>(qkv, B, ntok, heads, out, cattn, ncon, s);
-        case 3: return launch_attn<3>(qkv, B, ntok, heads, out, cattn, ncon, s);
-        case 4: return launch_attn<4>(qkv, B, ntok, heads, out, cattn, ncon, s);
-        case 5: return launch_attn<5>(qkv, B, ntok, heads, out, cattn, ncon, s);
-        case 6: return launch_attn<6>(qkv, B, ntok, heads, out, cattn, ncon, s);
-        case 7: return launch_attn<7>(qkv, B, ntok, heads, out, cattn, ncon, s);
-        case 8: return launch_attn<8>(qkv, B, ntok, heads, out, cattn, ncon, s);
-        case 9: return launch_attn<9>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        case 1: return launch_attn<1>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
+        case 2: return launch_attn<2>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
+        case 3: return launch_attn<3>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
+        case 4: return launch_attn<4>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
+        case 5: return launch_attn<5>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
+        case 6: return launch_attn<6>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
+        case 7: return launch_attn<7>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
+        case 8: return launch_attn<8>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
+        case 9: return launch_attn<9>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
     }
     ch_set_error("attention: more than 288 tokens per image is not supported");
     return 2;

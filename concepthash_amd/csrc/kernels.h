@@ -103,11 +103,15 @@ int ch_layernorm_f32(const float *x, int64_t rows, int D, const float *w, const 
 int ch_layernorm_bf16(const bf16_t *x, int64_t rows, int D, const float *w, const float *b, float eps, bf16_t *out,
                       hipStream_t s);
 
+// compact copy of the residual rows the hashing head reads: out[b*(1+ncon) + j] = H[b*ntok + (j == 0 ? 0 : ntok-ncon+j-1)]
+int ch_gather_head_rows(const float *H, int B, int ntok, int ncon, int D, float *out, hipStream_t s);
+
 // ---- attention.hip -------------------------------------------------------------------------------------------
 // qkv [B*ntok, 3D] bf16 (q | k | v, head h at columns h*64), out [B*ntok, D] bf16.  head_dim == 64.
 // cattn (optional): [B, heads, ncon, ntok - ncon - 1] fp32 softmax rows of the last `ncon` tokens over tokens 1 .. ntok-ncon-1
+// compact: queries are only CLS + the last `ncon` (concept) tokens of every image; out is [B * (1 + ncon), heads * 64]
 int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s, float *cattn = nullptr,
-                 int ncon = 0);
+                 int ncon = 0, bool compact = false);
 
 // ---- head.hip ------------------------------------------------------------------------------------------------
 struct HeadParams {

@@ -73,6 +73,9 @@ struct ch_model {
     float *H = nullptr;
     float *splitk_ws[2] = {nullptr, nullptr};      // split-K tail slabs + tickets of the 256x256 GEMM, one set per chain
     unsigned *splitk_cnt[2] = {nullptr, nullptr};
+    // final-layer row pruning: compact fp32 copy of the residual rows the head reads, [max_batch * (1 + Q) (+pad), D]
+    bool prune_last = true;
+    float *Hc = nullptr;
     float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn
     bf16_t *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *A = nullptr, *AD = nullptr, *F1 = nullptr, *PATCH = nullptr;
 };
@@ -380,6 +383,7 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
         if (!B.ok) return 4;
         CH_CHECK_HIP(hipMemset(m->splitk_cnt[i], 0, CH_SPLITK_CNT_BYTES));
     }
+    m->Hc = (float *)B.alloc(sizeof(float) * ((size_t)c.max_batch * (1 + c.ncontext) + 512) * D);
     m->statsA = (float *)B.alloc(sizeof(float) * rows * (D / 64) * 2);
     m->statsH = (float *)B.alloc(sizeof(float) * rows * (D / 64) * 2);
     m->QKV = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * 3 * D);
@@ -391,6 +395,7 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
     if (!B.ok) return 4;
     CH_CHECK_HIP(hipMemset(m->H, 0, sizeof(float) * rows * D));
     CH_CHECK_HIP(hipMemset(m->Xn, 0, sizeof(bf16_t) * rows * D));
+    CH_CHECK_HIP(hipMemset(m->Hc, 0, sizeof(float) * ((size_t)c.max_batch * (1 + c.ncontext) + 512) * D));
     CH_CHECK_HIP(hipMemset(m->statsA, 0, sizeof(float) * rows * (D / 64) * 2));
     CH_CHECK_HIP(hipMemset(m->statsH, 0, sizeof(float) * rows * (D / 64) * 2));
     CH_CHECK_HIP(hipMemset(m->QKV, 0, sizeof(bf16_t) * rows * 3 * D));
@@ -415,8 +420,10 @@ inline void mark(ch_model *m, int pi, int cat, double flops, hipStream_t s) {
 
 // one launch chain: images [img0, img0 + B) through `nlayers` layers on stream s; rows of every activation buffer are
 // independent, so a micro-batch simply works on its own row range of the shared workspace
+// prune: (ch_encode) in the final layer only the rows the hashing head reads -- CLS and the Q concept tokens of every image --
+// are carried past the attention (whose keys / values still cover all tokens); their residual lives in mm->Hc afterwards
 int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int img0, int B, int nlayers, hipStream_t s,
-              float *concept_attn) {
+              float *concept_attn, bool prune) {
     const ch_model_config &c = mm->cfg;
     const int D = c.dim, M = c.ffn, ntok = mm->ntok, np = mm->np;
     const int rows = B * ntok;
@@ -459,15 +466,17 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         bf16_t *hb_out = nullptr;
     };
     const bool fold = mm->ln_fold && c.adapter_dim > 0 && !mm->use_fused_adapter;
+    int cur_rows = rows;      // rows the GEMMs work on: all token rows, or the compact head rows in the pruned final layer
+    float *cur_H = m->H;      // ... and their residual stream
     auto gemm = [&](int cat, int n_true, int k_true, const bf16_t *X, const bf16_t *W, int N, int K, const float *bias,
                     int epi, bf16_t *out, int ldo, const float *scale, const bf16_t *addend = nullptr, const Fold &f = Fold()) {
-        mark(mm, pi, cat, 2.0 * rows * (double)n_true * k_true, s);
+        mark(mm, pi, cat, 2.0 * cur_rows * (double)n_true * k_true, s);
         GemmParams p{};
         p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi];
         p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
-        p.X = X; p.W = W; p.M = rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
-        p.out_bf16 = out; p.ldo = ldo; p.resid = m->H; p.ldr = D; p.scale_ptr = scale;
+        p.X = X; p.W = W; p.M = cur_rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
+        p.out_bf16 = out; p.ldo = ldo; p.resid = cur_H; p.ldr = D; p.scale_ptr = scale;
         return ch_gemm_bf16(p, epi, s);
     };
     // emit_h: (LN-fold chain) the up-projection also writes bf16(H) to Xn + its row statistics for the next folded GEMM
@@ -522,9 +531,18 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
             }
             if (int e = gemm(CH_CAT_GEMM_QKV, 3 * D, D, m->Xn, w.qkv_w, 3 * D, D, w.qkv_b, EPI_BIAS, m->QKV, 3 * D, nullptr)) return e;
         }
-        mark(mm, pi, CH_CAT_ATTENTION, 4.0 * B * (double)ntok * ntok * D, s);
-        if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, i == nlayers - 1 ? concept_attn : nullptr, c.ncontext))
+        const bool pruned = prune && fold && mm->prune_last && i == nlayers - 1 && nlayers == c.layers;
+        const int nq = 1 + c.ncontext;
+        mark(mm, pi, CH_CAT_ATTENTION, 4.0 * B * (double)(pruned ? nq : ntok) * ntok * D, s);
+        if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, i == nlayers - 1 ? concept_attn : nullptr, c.ncontext, pruned))
             return e;
+        if (pruned) {
+            // from here on every buffer holds B * (1 + Q) compact rows (image-major: CLS, then the concept tokens)
+            cur_rows = B * nq;
+            cur_H = mm->Hc + (size_t)img0 * nq * D;
+            mark(mm, pi, CH_CAT_ROWOPS, 0.0, s);
+            if (int e = ch_gather_head_rows(m->H, B, ntok, c.ncontext, D, cur_H, s)) return e;
+        }
         // h = r + a  (+ adapter_1(a) below);  a kept as bf16 in m->A for the adapter branch
         // with adapters the residual add of `a` is deferred to the adapter's up-projection epilogue (see adapter())
         const int sub_epi = fold ? EPI_BIAS_STATS : (w.ad[0].down_w ? EPI_BIAS : EPI_BIAS_RESID);
@@ -550,13 +568,13 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
 // encoder up to `nlayers` layers; leaves the residual stream in m->H.  With two streams the batch is split into two
 // micro-batches whose chains run concurrently (fork/join by events on the caller's stream).
 int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nlayers, hipStream_t s,
-                float *concept_attn = nullptr) {
-    if (m->nstreams < 2 || B < 2) return run_chain(m, 0, images, image_dtype, 0, B, nlayers, s, concept_attn);
+                float *concept_attn = nullptr, bool prune = false) {
+    if (m->nstreams < 2 || B < 2) return run_chain(m, 0, images, image_dtype, 0, B, nlayers, s, concept_attn, prune);
     const int B0 = (B + 1) / 2, B1 = B - B0;
     CH_CHECK_HIP(hipEventRecord(m->ev_fork, s));
     CH_CHECK_HIP(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
-    if (int e = run_chain(m, 0, images, image_dtype, 0, B0, nlayers, s, concept_attn)) return e;
-    if (int e = run_chain(m, 1, images, image_dtype, B0, B1, nlayers, m->aux_stream, concept_attn)) return e;
+    if (int e = run_chain(m, 0, images, image_dtype, 0, B0, nlayers, s, concept_attn, prune)) return e;
+    if (int e = run_chain(m, 1, images, image_dtype, B0, B1, nlayers, m->aux_stream, concept_attn, prune)) return e;
     CH_CHECK_HIP(hipEventRecord(m->ev_join, m->aux_stream));
     CH_CHECK_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
     return 0;
@@ -598,6 +616,7 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
     m->Kp = (int)round_up64(3 * cfg->patch * cfg->patch, 64);
     if (const char *e = getenv("CH_FUSED_ADAPTER")) m->use_fused_adapter = atoi(e) != 0;
     if (const char *e = getenv("CH_LN_FOLD")) m->ln_fold = atoi(e) != 0;
+    if (const char *e = getenv("CH_PRUNE_LAST")) m->prune_last = atoi(e) != 0;
     if (const char *e = getenv("CH_STREAMS")) m->nstreams = atoi(e) >= 2 ? 2 : 1;
     if (hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -639,7 +658,13 @@ extern "C" double ch_model_flops_per_image(const ch_model *m) {
     const double N = m->ntok, D = c.dim, M = c.ffn, b = c.adapter_dim, L = c.layers;
     const double patch = 2.0 * m->np * D * 3.0 * c.patch * c.patch;
     const double layer = 8.0 * N * D * D + 4.0 * N * D * M + 4.0 * N * N * D + 8.0 * N * D * b;
-    return patch + L * layer + 2.0 * D * c.nbit;
+    double total = patch + L * layer + 2.0 * D * c.nbit;
+    if (m->prune_last && m->ln_fold && c.adapter_dim > 0 && !m->use_fused_adapter) {
+        // final layer: qkv on all rows, everything after it on the 1 + Q rows the head reads
+        const double nq = 1 + c.ncontext;
+        total += -layer + 6.0 * N * D * D + 4.0 * nq * N * D + 2.0 * nq * D * D + 4.0 * nq * D * M + 8.0 * nq * D * b;
+    }
+    return total;
 }
 
 extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, float *out_codes,
@@ -651,10 +676,11 @@ extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, i
     CH_REQUIRE(!out_logits_concept || m->concept_cent_l2, "model has no concept classifier (concept_ce.centroids)");
     CH_REQUIRE(!out_image_features || m->vis_proj, "model has no post_layernorm / visual_projection");
     hipStream_t s = (hipStream_t)stream;
-    if (int e = run_encoder(m, images, image_dtype, B, m->cfg.layers, s, out_concept_attn)) return e;
+    if (int e = run_encoder(m, images, image_dtype, B, m->cfg.layers, s, out_concept_attn, true)) return e;
     const ch_model_config &c = m->cfg;
+    const bool pruned = m->prune_last && m->ln_fold && c.adapter_dim > 0 && !m->use_fused_adapter;  // as run_chain decides
     HeadParams p{};
-    p.H = m->H; p.B = B; p.ntok = m->ntok; p.D = c.dim; p.Q = c.ncontext; p.nbit = c.nbit; p.C = c.nclass; p.P = c.proj_dim;
+    p.H = pruned ? m->Hc : m->H; p.B = B; p.ntok = pruned ? 1 + c.ncontext : m->ntok; p.D = c.dim; p.Q = c.ncontext; p.nbit = c.nbit; p.C = c.nclass; p.P = c.proj_dim;
     p.hash_pe = m->hash_pe; p.hash_fc = m->hash_fc; p.bn_scale = m->bn_scale; p.bn_shift = m->bn_shift;
     p.center_l2 = m->center_l2; p.center_bin = m->center_bin; p.concept_pe = m->concept_pe;
     p.concept_cent_l2 = m->concept_cent_l2; p.post_w = m->post_w; p.post_b = m->post_b; p.vis_proj = m->vis_proj;

@@ -209,7 +209,23 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T *img, int B, int im
     *(uint4 *)(out + prow * Kp + ck * 8) = o;
 }
 
+// out[b * (1 + ncon) + j] = H[b * ntok + (j == 0 ? 0 : ntok - ncon + j - 1)]: the rows the hashing head reads (CLS + concept tokens)
+__global__ void gather_head_rows_kernel(const float *__restrict__ H, int ntok, int ncon, int D, float *__restrict__ out) {
+    const int r = blockIdx.x, nq = 1 + ncon;
+    const int b = r / nq, j = r - b * nq;
+    const float *src = H + ((size_t)b * ntok + (j == 0 ? 0 : ntok - ncon + j - 1)) * D;
+    float *dst = out + (size_t)r * D;
+    for (int i = threadIdx.x * 4; i < D; i += blockDim.x * 4) *(f32x4 *)(dst + i) = *(const f32x4 *)(src + i);
+}
+
 }  // namespace
+
+int ch_gather_head_rows(const float *H, int B, int ntok, int ncon, int D, float *out, hipStream_t s) {
+    CH_REQUIRE(B > 0 && ncon >= 1 && ncon < ntok && D % 4 == 0, "gather_head_rows: bad shape");
+    hipLaunchKernelGGL(gather_head_rows_kernel, dim3(B * (1 + ncon)), dim3(192), 0, s, H, ntok, ncon, D, out);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
 
 int ch_layernorm_f32(const float *x, int64_t rows, int D, const float *w, const float *b, float eps, bf16_t *out,
                      hipStream_t s) {

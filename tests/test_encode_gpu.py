@@ -217,3 +217,36 @@ def test_layernorm_fold_chain_matches_the_unfolded_chain(dev, monkeypatch):
     assert _rel_err(fold, ref) < 4e-2 and _rel_err(plain, ref) < 4e-2 and _rel_err(fold, plain) < 2e-2
     assert _rel_err(hid_fold, hid_plain) < 4e-2               # max-abs / RMS of the final residual stream
     assert float((hid_fold - hid_plain).pow(2).mean().sqrt() / hid_plain.pow(2).mean().sqrt()) < 5e-3
+
+
+def test_final_layer_row_pruning_is_bit_identical(dev, monkeypatch):
+    """Default: after the final layer's attention only the rows the hashing head reads (CLS + Q concept tokens per image) are
+    carried through out_proj / adapters / MLP.  Same kernels, same per-row arithmetic -> every output is bit-identical to the
+    unpruned chain (CH_PRUNE_LAST=0); the hidden-state tap always runs unpruned."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_b16"])
+    cfg["L"] = 3
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    x = eo.synthetic_images(7, cfg["image"]).to(dev)
+    want = ("codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features", "image_features", "concept_attn")
+    enc = _encoder(sd, cfg["heads"], max_batch=4)        # 7 images at max_batch 4: chunks of 4 and 3
+    pruned = enc.encode(x, want=want)
+    hid = enc.hidden_states(x[:3], cfg["L"])
+    assert enc.flops_per_image > 0
+    monkeypatch.setenv("CH_PRUNE_LAST", "0")
+    enc0 = _encoder(sd, cfg["heads"], max_batch=4)
+    full = enc0.encode(x, want=want)
+    hid0 = enc0.hidden_states(x[:3], cfg["L"])
+    monkeypatch.delenv("CH_PRUNE_LAST")
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(pruned[k], full[k]), k
+    assert torch.equal(hid, hid0)
+    assert enc.flops_per_image < enc0.flops_per_image
+    # two streams + pruning: each micro-batch owns its slice of the compact residual
+    monkeypatch.setenv("CH_STREAMS", "2")
+    enc2 = _encoder(sd, cfg["heads"], max_batch=8)
+    two = enc2.encode(x, want=want)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(two[k], full[k]), k
