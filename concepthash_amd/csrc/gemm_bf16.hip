@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
     const int tiles_m = (p.M + BM - 1) / BM;
     const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     // tile order inside an XCD's contiguous chunk: n-tiles are taken in groups of p.group_n whose weight panels stay
-    // L2-resident (<= ~2.4 MB) while the m-tiles sweep past; inside a group n is fastest so the co-resident workgroups of
+    // L2-resident (<= ~2.0 MB) while the m-tiles sweep past; inside a group n is fastest so the co-resident workgroups of
     // an XCD share activation panels too.  (host: gemm_group_n)
     const int per_group = tiles_m * p.group_n;
     const int g = wg / per_group, rem = wg - g * per_group;
@@ -173,7 +173,7 @@ int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s) {
 }
 
 // Estimated beyond-L2 read traffic for n-groups of gn tiles: every group re-streams X once; a group's weight panels are
-// fetched once per XCD if they fit in ~60 % of the 4 MB L2, otherwise once per round of co-resident tiles.
+// fetched once per XCD if they fit in half of the 4 MB L2, otherwise once per round of co-resident tiles.
 int ch_gemm_group_n(int M, int N, int K, int bm, int bn) {
     const int tiles_n = N / bn, tiles_m = (M + bm - 1) / bm;
     const double xbytes = 2.0 * M * K, wpanel = 2.0 * bn * K, wbytes = 2.0 * N * K;
@@ -184,7 +184,7 @@ int ch_gemm_group_n(int M, int N, int K, int bm, int bn) {
     double best_cost = 1e300;
     for (int gn = 1; gn <= tiles_n; ++gn) {
         const int ng = (tiles_n + gn - 1) / gn;
-        const bool fits = gn * wpanel <= 2.4e6;
+        const bool fits = gn * wpanel <= 2.0e6;  // measured (fc1, K = 768): 4-5 panels (1.6-2.0 MB) 270 us, 6 panels (2.4 MB) 286 us
         const double cost = xbytes * ng + wbytes * 8.0 * (fits ? 1.0 : rounds);
         if (cost < best_cost - 1.0) {
             best_cost = cost;

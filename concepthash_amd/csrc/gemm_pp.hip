@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const int split_tile = split ? unit / p.split_s : 0, slice = split ? unit - split_tile * p.split_s : 0;
     const int wg = xcd_remap(split ? p.split_full + split_tile : (int)blockIdx.x, tiles_m * tiles_n);
     // tile order inside an XCD's contiguous chunk: n-tiles are taken in groups of p.group_n whose weight panels stay
-    // L2-resident (<= ~2.4 MB) while the m-tiles sweep past; inside a group n is fastest so the co-resident workgroups of
+    // L2-resident (<= ~2.0 MB) while the m-tiles sweep past; inside a group n is fastest so the co-resident workgroups of
     // an XCD share activation panels too.  (host: gemm_group_n)
     const int per_group = tiles_m * p.group_n;
     const int g = wg / per_group, rem = wg - g * per_group;
