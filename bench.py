@@ -230,6 +230,30 @@ def main():
                                             f"({host.numel() * 2 / 2**20:.0f} MiB bf16, no overlap); never used for `value`"}
         del host, dev_in
 
+    # ---- optional two-stream mode (outside the timed region): same step, two micro-batches on two HIP streams ---------
+    if rank == 0 and world == 1 and args.streams == 1:
+        os.environ["CH_STREAMS"] = "2"
+        enc2 = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=B, device=dev)
+        os.environ["CH_STREAMS"] = "1"
+        c1 = enc.encode(images, want=("codes", "packed"))
+        c2 = enc2.encode(images, want=("codes", "packed"))
+        same = bool(torch.equal(c1["codes"], c2["codes"]) and torch.equal(c1["packed"], c2["packed"]))
+        for _ in range(2):
+            enc2.encode(images, want=("codes", "packed"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            o2 = enc2.encode(images, want=("codes", "packed"))
+            rt.hamming_topk(o2["packed"], gallery, TOPK)
+        torch.cuda.synchronize()
+        s2 = (time.perf_counter() - t0) / 10
+        result["two_streams"] = {"images_per_s": round(B / s2, 1), "ms_per_step": round(s2 * 1e3, 3), "codes_identical": same,
+                                 "note": "CH_STREAMS=2 / --streams 2: the tile-quantisation tails of one micro-batch's launches are "
+                                         "filled by the other's; not the default because per-launch durations (the roofline above) "
+                                         "stop describing single kernels once launches overlap; never used for `value`"}
+        enc2.close()
+        del enc2
+
     # ---- Hamming scan at BASELINE config-5 size (outside the timed region; per rank, reported by rank 0) -----------
     if rank == 0 and not args.no_hamming_scan:
         G5, Q5, NB5 = 1_000_000, 16384, 128
