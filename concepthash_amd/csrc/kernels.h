@@ -61,6 +61,8 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);      // dispatche
 int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s);   // gemm_bf16.hip: 128x128x64, two-phase
 int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s);   // gemm_pp.hip: 256x256x64, ping-pong 8-phase
 bool ch_gemm_pp_supported(const GemmParams &p);
+int ch_gemm_bf16_pq(const GemmParams &p, int epi, hipStream_t s);   // gemm_pq.hip: 256x128x64, ping-pong, two phases per K-tile
+bool ch_gemm_pq_supported(const GemmParams &p);
 int ch_gemm_bf16_ppp(const GemmParams &p, int epi, hipStream_t s);  // gemm_ppp.hip: persistent ping-pong (bf16-output epilogues)
 bool ch_gemm_ppp_supported(const GemmParams &p, int epi);
 int ch_gemm_bf16_dp(const GemmParams &p, int epi, hipStream_t s);   // gemm_dp.hip: 256x128x32, 3-stage ring, 2 workgroups/CU

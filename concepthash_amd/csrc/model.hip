@@ -791,6 +791,7 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
     if (variant == 2) return ch_gemm_bf16_pp(p, epi, s);
     if (variant == 3) return ch_gemm_bf16_dp(p, epi, s);
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
+    if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
     if (variant >= 21 && variant <= 27) return ch_gemm_bf16_pp_dbg(p, variant - 20, s);  // timing-only builds
     return ch_gemm_bf16(p, epi, s);
 }
@@ -809,6 +810,7 @@ extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_a
     hipStream_t s = (hipStream_t)stream;
     if (int e = debug_attach_splitk(p)) return e;
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
+    if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
     if (variant == 1 || variant == 2) ch_gemm_set_variant(variant);
     const int rc = ch_gemm_bf16(p, epi, s);
     if (variant == 1 || variant == 2) ch_gemm_set_variant(0);

@@ -265,3 +265,44 @@ def test_splitk_tail_of_the_pingpong_kernel(splitk, M, N, K):
     want = _slice_stats(out, M)
     assert torch.allclose(stats[:M].double(), want, rtol=1e-5, atol=1e-4)
 
+
+
+@pytest.mark.parametrize("M,N,K", [(51456, 768, 768), (4096, 2304, 768), (3000, 384, 768), (2500, 768, 3072), (300, 128, 128),
+                                   (70000, 256, 256), (700, 640, 1280)])
+def test_256x128_pingpong_equals_two_phase_bitwise_and_is_race_free(M, N, K):
+    """gemm_pq.hip (variant 6): 256x128 tile, two phases per K-tile, three 16 KB units per K-tile.  Same MFMA and the same k
+    order per output element as the 128x128 kernel -> bit-identical for every epilogue; repeated with cold and warm caches."""
+    X, W, bias, resid0 = _inputs(M, N, K, seed=9)
+    scale = torch.tensor([0.7], device="cuda")
+    addend = torch.randn(X.shape[0], N, device="cuda").to(torch.bfloat16)
+    junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    for epi in (EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_BIAS_RESID, EPI_SCALE_RESID):
+        ref = torch.zeros(X.shape[0], N, dtype=torch.bfloat16, device="cuda")
+        r_ref = resid0.clone()
+        _gemm(1, X, W, bias, M, epi, out=ref if epi != EPI_SCALE_RESID else None, resid=r_ref if epi >= EPI_BIAS_RESID else None,
+              scale=scale, addend=addend if epi == EPI_SCALE_RESID else None)
+        for it in range(3):
+            out = torch.zeros_like(ref)
+            r = resid0.clone()
+            if it % 2:
+                junk.fill_(float(it))
+            _gemm(6, X, W, bias, M, epi, out=out if epi != EPI_SCALE_RESID else None, resid=r if epi >= EPI_BIAS_RESID else None,
+                  scale=scale, addend=addend if epi == EPI_SCALE_RESID else None)
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), (epi, it)
+            assert torch.equal(r, r_ref), (epi, it)
+    if K <= 1280:   # LayerNorm-fold consumers and the statistics producers through the same kernel
+        stats_in = torch.zeros(X.shape[0], K // 64, 2, device="cuda")
+        stats_in[:M] = _slice_stats(X, M).float()
+        fold_c = torch.randn(N, device="cuda")
+        for epi in (EPI_BIAS_STATS, EPI_FOLD_BIAS, EPI_FOLD_QGELU, EPI_FOLD_GELU):
+            kw = dict(stats_in=stats_in, fold_c=fold_c) if epi != EPI_BIAS_STATS else {}
+            ref = torch.zeros(X.shape[0], N, dtype=torch.bfloat16, device="cuda")
+            out = torch.zeros_like(ref)
+            st_ref = torch.zeros(X.shape[0], N // 64, 2, device="cuda")
+            st = torch.zeros_like(st_ref)
+            _gemm_ln(1, X, W, bias, M, epi, out=ref, stats_out=st_ref if epi == EPI_BIAS_STATS else None, **kw)
+            _gemm_ln(6, X, W, bias, M, epi, out=out, stats_out=st if epi == EPI_BIAS_STATS else None, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), epi
+            assert torch.equal(st, st_ref), epi

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--variants", default="1,2", help="comma list; '5s12000' = variant 5 with CH_PPP_SKEW_NS=12000, '5f1' = CH_PPP_FLAGS=1")
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--custom", default="", help="extra shape name:N:K:epi, e.g. d512:512:768:2")
     ap.add_argument("--epi", type=int, default=-1, help="override the epilogue of every shape")
     a = ap.parse_args()
     lib = _lib.load()
@@ -32,7 +33,11 @@ def main():
         m = re.fullmatch(r"(\d+)(?:s(\d+))?(?:f(\d+))?(?:e(\d+))?(?:d(\d+))?(?:k(\d))?", tok)
         return int(m.group(1)), m.group(2) or "0", m.group(3) or "0", int(m.group(4)) if m.group(4) else None, m.group(5) or "0", int(m.group(6) or 0)
     scale = torch.tensor([0.5], device="cuda")
-    for name, N, K, epi in SHAPES:
+    shapes = list(SHAPES)
+    if a.custom:
+        nm, n_, k_, e_ = a.custom.split(":")
+        shapes.append((nm, int(n_), int(k_), int(e_)))
+    for name, N, K, epi in shapes:
         if a.shapes and name not in a.shapes.split(","):
             continue
         if a.epi >= 0:
@@ -56,6 +61,8 @@ def main():
                 os.environ["CH_GEMM_DBG"] = dbg
                 ep = epi if epi_v is None else epi_v
                 os.environ["CH_PPP_SKEW_NS"], os.environ["CH_PPP_FLAGS"] = skew, flags
+                if v == 6 and (N % 128 or K % 128):
+                    continue
                 if v in (2, 5, 21, 22, 23, 24, 25, 26, 27) and (N % 256 or K % 128):
                     continue
                 if v == 5 and ep not in (0, 1, 2, 6, 8, 9, 10):
