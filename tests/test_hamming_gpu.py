@@ -181,3 +181,23 @@ def test_full_size_properties_1m_gallery(dev):
     p1 = rt.hamming_topk(gq, gg[half:], k, half)
     midx, mdst = rt.topk_merge(torch.stack([p0[0], p1[0]]), torch.stack([p0[1], p1[1]]))
     assert torch.equal(midx, idx) and torch.equal(mdst, dst)
+
+
+@pytest.mark.parametrize("nbit,k", [(64, 10), (128, 33), (64, 1)])
+def test_topk_large_gallery_with_heavy_ties(dev, nbit, k):
+    """300,000 rows of clustered codes (few centres, low noise): thousands of rows sit at the k-th distance, exact duplicates of
+    a query lie at the very end of the gallery; the lists must equal the CPU oracle's stable (distance, index) ranking."""
+    from concepthash_amd import retrieval as rt
+    from oracle import hamming_oracle as ho
+    G, Qn = 300_000, 48
+    g, _ = ho.synthetic_codes(G, nbit, seed=51, nclass=20, flip=0.02)
+    q, _ = ho.synthetic_codes(Qn, nbit, seed=52, nclass=20, flip=0.02)
+    g = g.copy()
+    g[G - 5] = q[0]                      # exact duplicates of query 0 at the very end: distance 0, beyond the sample
+    g[G - 1] = q[0]
+    g[40_000] = q[1]                     # ... and just outside the sampled prefix
+    idx, dst = rt.hamming_topk(_t(q, dev), _t(g, dev), k)
+    torch.cuda.synchronize()
+    ridx, rdst = ho.topk(q, g, k)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(dst.cpu().numpy(), rdst)
