@@ -264,7 +264,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     // launch): every slab byte is stored write-through (sc1) and drained by the storing wave before the barrier that
     // precedes the ticket, and every slab load is an sc1 load.
     if (split) {
-        if (p.dbg & 8) return;   // timing experiment: no fix-up at all
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         constexpr unsigned SLAB_BYTES = BM * BN * 4;
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(p.splitk_ws, 0, (int)CH_SPLITK_WS_BYTES, 0x00020000);
@@ -284,7 +283,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
         __syncthreads();
         const unsigned ticket = *ticket_lds;
         if (ticket != (unsigned)(p.split_s - 1)) return;
-        if (p.dbg & 16) { if (tid == 0) __hip_atomic_store(p.splitk_cnt + split_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
         if (tid == 0)  // ready for the next launch
             __hip_atomic_store(p.splitk_cnt + split_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the slab loads below the ticket
@@ -338,7 +336,6 @@ void ch_pp_choose_split(GemmParams &p, int tiles) {
     int S = 1;
     for (int c = 2; c <= 8; ++c)
         if (J % c == 0 && R * c <= ncu && R * c <= 256) S = c;
-    if (const char *e = getenv("CH_GEMM_SPLITK_S")) S = (J % atoi(e) == 0 && R * atoi(e) <= ncu) ? atoi(e) : S;
     if (S < 2 || J / S < 1) return;
     p.split_full = tiles - R;
     p.split_s = S;

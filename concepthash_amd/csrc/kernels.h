@@ -46,7 +46,6 @@ struct GemmParams {
     const float *stats_in;   // [rows, K/64, 2] partials of this GEMM's input rows (written by the producer)
     const float *fold_c;     // [N]
     float ln_eps;
-    int dbg;                 // timing experiments only (CH_GEMM_DBG through ch_debug_gemm_ln)
     // split-K tail of the 256x256 kernel (gemm_pp.hip): fp32 slabs [<= 256 units][256*256] + one counter per split tile;
     // nullptr = every tile is computed by one workgroup.  split_full / split_s are set by the launcher.
     float *splitk_ws;

@@ -786,7 +786,6 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
     p.bias = bias; p.out_bf16 = (bf16_t *)out_bf16; p.ldo = ldo; p.resid = resid; p.ldr = ldr; p.scale_ptr = scale_ptr; p.addend = (const bf16_t *)addend; p.ld_addend = N;
     hipStream_t s = (hipStream_t)stream;
     if (int e = debug_attach_splitk(p)) return e;
-    if (const char *e = getenv("CH_GEMM_DBG")) p.dbg = atoi(e);
     if (variant == 1) return ch_gemm_bf16_v1(p, epi, s);
     if (variant == 2) return ch_gemm_bf16_pp(p, epi, s);
     if (variant == 3) return ch_gemm_bf16_dp(p, epi, s);
@@ -806,7 +805,6 @@ extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_a
     p.bias = bias; p.out_bf16 = (bf16_t *)out_bf16; p.ldo = ldo; p.resid = resid; p.ldr = ldr; p.scale_ptr = scale_ptr;
     p.addend = (const bf16_t *)addend; p.ld_addend = N;
     p.stats_in = stats_in; p.fold_c = fold_c; p.ln_eps = ln_eps; p.stats_out = stats_out; p.hb_out = (bf16_t *)hb_out; p.ld_hb = N;
-    if (const char *e = getenv("CH_GEMM_DBG")) p.dbg = atoi(e);
     hipStream_t s = (hipStream_t)stream;
     if (int e = debug_attach_splitk(p)) return e;
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);

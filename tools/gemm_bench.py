@@ -58,7 +58,6 @@ def main():
             for vt in variants:
                 v, skew, flags, epi_v, dbg, sk = parse(vt)
                 lib.ch_debug_set_gemm_splitk(sk)
-                os.environ["CH_GEMM_DBG"] = dbg
                 ep = epi if epi_v is None else epi_v
                 os.environ["CH_PPP_SKEW_NS"], os.environ["CH_PPP_FLAGS"] = skew, flags
                 if v == 6 and (N % 128 or K % 128):
