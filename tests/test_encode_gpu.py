@@ -250,3 +250,25 @@ def test_final_layer_row_pruning_is_bit_identical(dev, monkeypatch):
     torch.cuda.synchronize()
     for k in want:
         assert torch.equal(two[k], full[k]), k
+
+
+@pytest.mark.parametrize("batch", [1, 2, 9])
+def test_small_and_odd_batches_through_the_default_chain(dev, batch):
+    """Batch sizes whose row counts are far from any tile multiple (201 .. 1809 token rows; 5 .. 45 compact head rows in the
+    pruned final layer) through LayerNorm fold + final-layer pruning, against the fp32 oracle and against a larger batch that
+    contains the same images (rows are independent: bit-identical)."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_s16"])
+    cfg["L"] = 3
+    sd = eo.synthetic_state_dict(cfg, nbit=32, nclass=10)
+    x = eo.synthetic_images(12, cfg["image"])
+    enc = _encoder(sd, cfg["heads"], max_batch=16)
+    want = ("codes", "packed", "logits_cont", "hash_features", "image_features")
+    small = enc.encode(x[:batch].to(dev), want=want)
+    big = enc.encode(x.to(dev), want=want)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(small[k], big[k][:batch]), k
+    ref = eo.encode(sd, x[:batch], heads=cfg["heads"], with_pooled=True)
+    assert _rel_err(small["codes"].cpu(), ref["codes"]) < 4e-2
+    assert _rel_err(small["image_features"].cpu(), ref["image_features"]) < 4e-2
