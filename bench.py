@@ -313,9 +313,9 @@ def main():
                          "frac": round(alg_bytes / sec / 1e9 / PEAK_HBM_GBS, 5), "traffic": None,
                          "note": "algorithmic bytes = ceil(Qn/256)*G*W*8 + Qn*(W+k)*8; the scan is VALU-bound "
                                  "(xor+popcount+select), see DESIGN.md"},
-            # the bound that applies (PMC-backed): 11.5 integer VALU instructions per 128-bit pair at
+            # the bound that applies (PMC-backed): 9.75 integer VALU instructions per 128-bit pair at
             # 4 cycles per wave64 instruction on 1024 SIMDs at 2.4 GHz, insertion passes not counted
-            "valu_ceiling_comparisons_per_s": 3.4e12, "valu_frac": round(Q5 * G5 / sec / 3.4e12, 4),
+            "valu_ceiling_comparisons_per_s": 4.0e12, "valu_frac": round(Q5 * G5 / sec / 4.0e12, 4),
         }
         del g5, q5
         # mAP@all + P@k/R@k at the CUB-200 size (5,794 queries x 5,994 gallery rows x 64 bit, real class-count statistics)

@@ -26,16 +26,31 @@ namespace {
 constexpr int KEY_SHIFT = 23;
 constexpr uint32_t KEY_MASK = (1u << KEY_SHIFT) - 1;
 
+// The scan is VALU-issue bound, so its inner loop is written down to the instruction:
+// v_bcnt_u32_b32 d, x, acc = popcount(x) + acc: chaining the accumulate operand keeps a distance at 2 instructions per 32-bit
+// word (left to itself the compiler re-associates into separate counts + v_add3: one more instruction per row);
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
+// key = dist << KEY_SHIFT | row with the (wave-uniform) row number taken from an SGPR: one v_lshl_or_b32 (the compiler's own
+// form is a shift plus v_or3 with the row's low bits as a literal).
+__device__ __forceinline__ uint32_t make_key(uint32_t d, uint32_t row_uniform) {
+    uint32_t key;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(d), "n"(KEY_SHIFT), "s"(row_uniform));
+    return key;
+}
 template <int W>
 __device__ __forceinline__ int hamming(const uint32_t (&q)[2 * W], const uint64_t *__restrict__ g) {
-    int d = 0;
+    uint32_t d = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
         const uint64_t gw = g[w];
-        d += __builtin_popcount(q[2 * w] ^ (uint32_t)gw);
-        d += __builtin_popcount(q[2 * w + 1] ^ (uint32_t)(gw >> 32));
+        d = bcnt_acc(q[2 * w] ^ (uint32_t)gw, d);
+        d = bcnt_acc(q[2 * w + 1] ^ (uint32_t)(gw >> 32), d);
     }
-    return d;
+    return (int)d;
 }
 
 template <int W>
@@ -90,30 +105,33 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(const uint64_t *__res
     // four gallery rows per trip: one wide scalar load (the next block is requested before this one is consumed), four
     // XOR/popcount keys, ONE threshold test on their minimum; the insertion network runs only if some lane beats its list.
     constexpr int UB = 4;
-    uint64_t cur[UB * W], nxt[UB * W];
-    int j = 0;
-    if (n >= UB) {
+    uint64_t bufA[UB * W], bufB[UB * W];
+    auto load_block = [&](uint64_t (&dst)[UB * W], int row) {
 #pragma unroll
-        for (int t = 0; t < UB * W; ++t) cur[t] = gp[t];
-    }
-    for (; j + UB <= n; j += UB) {
-        const bool more = j + 2 * UB <= n;
-        if (more) {
-#pragma unroll
-            for (int t = 0; t < UB * W; ++t) nxt[t] = gp[(size_t)(j + UB) * W + t];
-        }
+        for (int t = 0; t < UB * W; ++t) dst[t] = gp[(size_t)row * W + t];
+    };
+    auto scan_block = [&](const uint64_t (&blk)[UB * W], int row) {
         uint32_t key[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) key[u] = ((uint32_t)hamming<W>(qw, cur + u * W) << KEY_SHIFT) | (uint32_t)(j + u);
+        for (int u = 0; u < UB; ++u) key[u] = make_key((uint32_t)hamming<W>(qw, blk + u * W), (uint32_t)(row + u));
         const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
         if (__builtin_amdgcn_ballot_w64(kmin < list[KREG - 1]) != 0ull) {
 #pragma unroll
             for (int u = 0; u < UB; ++u) insert(key[u]);
         }
-        if (more) {
-#pragma unroll
-            for (int t = 0; t < UB * W; ++t) cur[t] = nxt[t];
-        }
+    };
+    // two blocks per iteration with the two SGPR buffers taking turns: no register copies between trips
+    int j = 0;
+    if (n >= UB) load_block(bufA, 0);
+    for (; j + 2 * UB <= n; j += 2 * UB) {
+        load_block(bufB, j + UB);
+        scan_block(bufA, j);
+        if (j + 3 * UB <= n) load_block(bufA, j + 2 * UB);
+        scan_block(bufB, j + UB);
+    }
+    if (j + UB <= n) {  // an odd number of whole blocks: the last one is already in bufA
+        scan_block(bufA, j);
+        j += UB;
     }
     for (; j < n; ++j) insert(((uint32_t)hamming<W>(qw, gp + (size_t)j * W) << KEY_SHIFT) | (uint32_t)j);
     if (qi < Qn) {
@@ -390,6 +408,8 @@ int launch_topk_partial(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_
 template <int W>
 int topk_dispatch_k(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int seg_rows, int k, uint32_t *part,
                     hipStream_t s) {
+    if (k <= 10) return launch_topk_partial<W, 10>(q, Qn, g, G, seg_rows, k, part, s);  // PRs = [1, 5, 10]: exactly k entries, so the
+                                                                                         // insertion threshold is the k-th key
     if (k <= 16) return launch_topk_partial<W, 16>(q, Qn, g, G, seg_rows, k, part, s);
     if (k <= 32) return launch_topk_partial<W, 32>(q, Qn, g, G, seg_rows, k, part, s);
     if (k <= 64) return launch_topk_partial<W, 64>(q, Qn, g, G, seg_rows, k, part, s);
