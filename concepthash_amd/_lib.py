@@ -41,6 +41,7 @@ SIGNATURES = {
                                  c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                  c_void_p]),
     "ch_debug_set_gemm_variant": (None, [c_int32]),
+    "ch_debug_gemm_dispatch_count": (c_int64, [c_int32]),
     "ch_debug_set_gemm_splitk": (None, [c_int32]),
     "ch_debug_adapter": (c_int, [c_void_p] * 2 + [c_int32] * 3 + [c_void_p] * 10 + [c_int32, c_void_p]),
     "ch_debug_attention": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
@@ -57,6 +58,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "ch_hamming_ap": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_hamming_ap_multi": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                                    c_void_p, POINTER(c_int64), c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_hamming_hist_prefix": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
 }
 

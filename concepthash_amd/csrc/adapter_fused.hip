@@ -312,12 +312,8 @@ __global__ __launch_bounds__(BM * 4, 2) void adapter_fused_kernel(AdapterParams 
 template <int BPAD, int BM, int NST>
 int launch_adapter_cfg(const AdapterParams &p, hipStream_t s) {
     constexpr int LDS_BYTES = BM == 64 ? 80 * 1024 : 160 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)adapter_fused_kernel<BPAD, BM, NST>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
-    }
+    static ch_once_per_device lds_once;
+    if (int e = ch_func_max_lds((const void *)adapter_fused_kernel<BPAD, BM, NST>, LDS_BYTES, lds_once)) return e;
     const int blocks = (p.M + BM - 1) / BM;
     hipLaunchKernelGGL((adapter_fused_kernel<BPAD, BM, NST>), dim3(blocks), dim3(BM * 4), LDS_BYTES, s, p);
     CH_LAUNCH_CHECK();

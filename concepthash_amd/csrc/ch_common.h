@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 typedef uint16_t bf16_t;  // raw bf16 bits
@@ -61,6 +62,22 @@ void ch_set_error(const std::string &msg);
             return 3;                                                                                        \
         }                                                                                                    \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set it once per (kernel, device), thread-safely
+// (two racing threads both set it -- idempotent).  One CH_LDS_ONCE object per kernel instantiation.
+struct ch_once_per_device {
+    std::atomic<uint64_t> done[4] = {};
+};
+static inline int ch_func_max_lds(const void *fn, int bytes, ch_once_per_device &once) {
+    int dev = 0;
+    CH_CHECK_HIP(hipGetDevice(&dev));
+    std::atomic<uint64_t> &word = once.done[(dev >> 6) & 3];
+    const uint64_t bit = 1ull << (dev & 63);
+    if (word.load(std::memory_order_acquire) & bit) return 0;
+    CH_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    word.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up64(int64_t a, int64_t b) { return ceil_div64(a, b) * b; }

@@ -137,11 +137,8 @@ int launch(const GemmParams &p0, hipStream_t s) {
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     constexpr int lds = 2 * STAGE_BYTES + (ch_epi::traits<EPI>::fold ? CH_FOLD_LDS_BYTES : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static ch_once_per_device lds_once;
+    if (int e = ch_func_max_lds((const void *)gemm_bf16_kernel<EPI>, lds, lds_once)) return e;
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(NTHREADS), lds, s, p);
     CH_LAUNCH_CHECK();
     return 0;
@@ -195,6 +192,7 @@ int ch_gemm_group_n(int M, int N, int K, int bm, int bn) {
 }
 
 // ---- dispatcher: the 256x256 ping-pong kernel when the shape allows it, this file's 128x128 kernel otherwise ---------
+static std::atomic<int64_t> g_dispatch_count[2];
 static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128 two-phase), 2 force pp (256x256 ping-pong), 3 force dp
 void ch_gemm_set_variant(int v) { g_gemm_variant = v; }
 int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
@@ -209,6 +207,12 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
     // Short-K GEMMs (the adapter up-projection, K = 384) are epilogue/HBM bound: two 128x128 workgroups per CU overlap one's
     // read-modify-write epilogue with the other's K loop and win there (measured: 152 -> 97 us per launch in the pipeline);
     // the 256x256 ping-pong kernel wins from K = 512 up.
-    static const int min_k = getenv("CH_GEMM_PP_MIN_K") ? atoi(getenv("CH_GEMM_PP_MIN_K")) : 512;
-    return (ch_gemm_pp_supported(p) && p.K >= min_k) ? ch_gemm_bf16_pp(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
+    const int min_k = p.pp_min_k > 0 ? p.pp_min_k : 512;  // per model (CH_GEMM_PP_MIN_K at ch_model_create), not per process
+    const bool pp = ch_gemm_pp_supported(p) && p.K >= min_k;
+    g_dispatch_count[pp ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
+    return pp ? ch_gemm_bf16_pp(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
+}
+// test tap: how many GEMMs the dispatcher has sent to the 128x128 (which = 0) / 256x256 ping-pong (which = 1) kernel
+extern "C" int64_t ch_debug_gemm_dispatch_count(int32_t which) {
+    return g_dispatch_count[which != 0].load(std::memory_order_relaxed);
 }

@@ -136,12 +136,8 @@ int launch_dp(const GemmParams &p0, hipStream_t s) {
     GemmParams p = p0;
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_dp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         LDS_BYTES));
-        attr_set = true;
-    }
+    static ch_once_per_device lds_once;
+    if (int e = ch_func_max_lds((const void *)gemm_dp_kernel<EPI>, LDS_BYTES, lds_once)) return e;
     hipLaunchKernelGGL(gemm_dp_kernel<EPI>, dim3(tiles), dim3(NTHREADS), LDS_BYTES, s, p);
     CH_LAUNCH_CHECK();
     return 0;

@@ -348,11 +348,8 @@ int launch_pp(const GemmParams &p0, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     constexpr int lds = 2 * BUF_BYTES + CH_FOLD_LDS_BYTES + 16;  // operands + (mean, rstd) table + split-K ticket
     ch_pp_choose_split(p, tiles);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static ch_once_per_device lds_once;
+    if (int e = ch_func_max_lds((const void *)gemm_pp_kernel<EPI>, lds, lds_once)) return e;
     hipLaunchKernelGGL(gemm_pp_kernel<EPI>, dim3(p.split_full + (tiles - p.split_full) * p.split_s), dim3(NTHREADS), lds, s, p);
     CH_LAUNCH_CHECK();
     return 0;

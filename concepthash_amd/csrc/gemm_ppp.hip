@@ -296,12 +296,8 @@ int launch_ppp(const GemmParams &p0, hipStream_t s) {
     GemmParams p = p0;
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_ppp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         LDS_BYTES));
-        attr_set = true;
-    }
+    static ch_once_per_device lds_once;
+    if (int e = ch_func_max_lds((const void *)gemm_ppp_kernel<EPI>, LDS_BYTES, lds_once)) return e;
     const int grid = tiles < 256 ? tiles : 256;  // one workgroup per CU (160 KB of LDS each)
     const char *e1 = getenv("CH_PPP_SKEW_NS"), *e2 = getenv("CH_PPP_FLAGS");
     const int skew_ticks = e1 ? atoi(e1) / 10 : 0, flags = e2 ? atoi(e2) : 0;   // wall_clock64: 100 MHz

@@ -223,11 +223,8 @@ int launch_pq(const GemmParams &p0, hipStream_t s) {
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     constexpr int lds = STAGE_BYTES + CH_FOLD_LDS_BYTES;  // staging (>= the two operand buffers) + (mean, rstd) table
-    static bool attr_set = false;
-    if (!attr_set) {
-        CH_CHECK_HIP(hipFuncSetAttribute((const void *)gemm_pq_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static ch_once_per_device lds_once;
+    if (int e = ch_func_max_lds((const void *)gemm_pq_kernel<EPI>, lds, lds_once)) return e;
     hipLaunchKernelGGL(gemm_pq_kernel<EPI>, dim3(tiles), dim3(NTHREADS), lds, s, p);
     CH_LAUNCH_CHECK();
     return 0;

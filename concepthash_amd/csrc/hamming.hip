@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void topk_merge_lists_kernel(const int64_t *__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// mAP passes.  MODE 0 = histogram, MODE 1 = AP accumulation
+// mAP passes.  MODE 0 = histogram, MODE 1 = AP accumulation (NR rank limits in one pass)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool relevant_multi(const uint64_t *qm, const uint64_t *gm, int LW) {
     bool r = false;
@@ -229,30 +229,55 @@ __device__ __forceinline__ bool relevant_multi(const uint64_t *qm, const uint64_
     return r;
 }
 
-// floor(a * 2^32 / b) for 1 <= a <= b < 2^32, exact: double estimate + integer correction
+// floor(a * 2^32 / b) for 1 <= a <= b < 2^32, exact: double estimate (hardware reciprocal + one Newton step, relative error
+// ~2^-51, i.e. < 2^-18 absolute on a quotient <= 2^32) + integer correction.  No IEEE division sequence.
 __device__ __forceinline__ unsigned long long fixdiv32(uint32_t a, uint32_t b) {
     const unsigned long long num = (unsigned long long)a << 32;
-    unsigned long long qq = (unsigned long long)((double)a * 4294967296.0 / (double)b);
+    const double bd = (double)b;
+    double r = __builtin_amdgcn_rcp(bd);
+    r = __builtin_fma(r, __builtin_fma(-bd, r, 1.0), r);
+    unsigned long long qq = (unsigned long long)((double)a * 4294967296.0 * r);
     long long rem = (long long)(num - qq * (unsigned long long)b);
-    if (rem < 0) {
-        qq -= 1;
-        rem += b;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (rem < 0) {
+            qq -= 1;
+            rem += b;
+        }
+        if (rem >= (long long)b) {
+            qq += 1;
+            rem -= b;
+        }
     }
-    if (rem >= (long long)b) qq += 1;
     return qq;
 }
 
-template <int W, int BLK, int MODE>
+constexpr int MAX_LIMITS = 16;
+struct RankLimits {
+    uint32_t lim[MAX_LIMITS];  // mAP@R cut-offs of one AP pass; 0xFFFFFFFF = the whole ranking
+};
+
+// One lane per query; the gallery segment is wave-uniform and walked four rows per trip: codes and labels of a trip come
+// through ONE scalar load each (the next trip's block is requested before this one is consumed), distances are chained
+// v_bcnt, every row is one LDS counter update in the lane's own column (conflict free).
+//   MODE 0: ds_add (no return); at the end the [bucket][lane] counters leave through a coalesced transposed write.
+//   MODE 1: ds_add_rtn: the returned value is the row's position inside its (query, distance) bucket in gallery order; only
+//           when some lane of the wave holds a relevant row in the trip are the four "ranked before" bases gathered (four
+//           independent 8-byte loads in flight) and the AP terms of the relevant rows added -- to NR accumulators, one per
+//           rank limit, so that mAP@R for a list of R, P@k and R@k all come out of a single pass.
+template <int W, int BLK, int MODE, int NR>
 __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restrict__ q, int64_t Qn,
                                                        const uint64_t *__restrict__ g, int64_t G, const void *q_labels,
                                                        const void *g_labels, int LW, int seg_rows,
                                                        uint32_t *__restrict__ out_hist, const uint32_t *__restrict__ base,
-                                                       int64_t rank_limit, const int32_t *__restrict__ first_rel,
+                                                       RankLimits lims, int nlim, const int32_t *__restrict__ first_rel,
                                                        unsigned long long *out_S, uint32_t *out_nrel) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // [nb][BLK]
     constexpr int NB = 64 * W + 1;
+    constexpr int UB = 4;
     const int tid = threadIdx.x;
-    const int64_t qi = (int64_t)blockIdx.x * BLK + tid;
+    const int64_t q0 = (int64_t)blockIdx.x * BLK;
+    const int64_t qi = q0 + tid;
     const int seg = blockIdx.y;
     const int64_t g0 = (int64_t)seg * seg_rows;
     const int n = (int)min((int64_t)seg_rows, G - g0);
@@ -262,114 +287,214 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
     const bool valid = qi < Qn;
     const int32_t qlab = (LW == 0 && valid) ? ((const int32_t *)q_labels)[qi] : -1;
     const uint64_t *qm = (LW > 0 && valid) ? (const uint64_t *)q_labels + qi * LW : nullptr;
-    const int32_t *gl32 = (const int32_t *)g_labels + g0;
+    const int32_t *__restrict__ gl32 = (const int32_t *)g_labels + g0;
     const uint64_t *glm = (const uint64_t *)g_labels + g0 * (LW > 0 ? LW : 0);
     __syncthreads();  // counters zeroed (each lane only touches its own column afterwards)
 
-    unsigned long long S = 0ull;
-    uint32_t nrel = 0;
+    unsigned long long S[NR];
+    uint32_t nrel[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        S[r] = 0ull;
+        nrel[r] = 0;
+    }
     int skip = 0, frel = 0;
     if (MODE == 1 && first_rel != nullptr) {
         skip = 1;
         frel = valid ? first_rel[qi] : 0;
     }
-    const uint64_t *gp = g + g0 * W;
+    const uint64_t *__restrict__ gp = g + g0 * W;
     const size_t brow = ((size_t)seg * Qn + (valid ? qi : 0)) * NB * 2;
-    for (int j = 0; j < n; ++j) {
-        const int d = hamming<W>(qw, gp + (size_t)j * W);
-        bool rel;
-        if (LW == 0)
-            rel = valid && (gl32[j] == qlab);
-        else
-            rel = valid && relevant_multi(qm, glm + (size_t)j * LW, LW);
+    uint32_t *col = cnt + tid;
+
+    // one relevant row: exact global rank / relevant-rank from (base, position in bucket), AP term into every limit it is inside
+    auto account = [&](uint2 b, uint32_t old) {
+        uint32_t rank = b.x + (old & 0xFFFFu) + 1u;     // 1-based global rank
+        uint32_t relrank = b.y + (old >> 16) + 1u;      // 1-based rank among relevant rows
+        if (skip) {
+            if (rank == 1u) return;
+            rank -= 1u;
+            relrank -= (uint32_t)frel;
+        }
+        if (rank > lims.lim[NR - 1]) return;            // limits ascend: outside the largest = outside all
+        const unsigned long long term = fixdiv32(relrank, rank);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool in = rank <= lims.lim[r];
+            S[r] += in ? term : 0ull;
+            nrel[r] += in ? 1u : 0u;
+        }
+    };
+    auto row = [&](const uint64_t *gw, bool rel) {   // single-row form (segment tail, multi-hot labels)
+        const uint32_t d = (uint32_t)hamming<W>(qw, gw);
         const uint32_t inc = 1u | ((uint32_t)rel << 16);
         if (MODE == 0) {
-            atomicAdd(&cnt[d * BLK + tid], inc);
+            atomicAdd(col + d * BLK, inc);
         } else {
-            const uint32_t old = atomicAdd(&cnt[d * BLK + tid], inc);
-            if (rel) {
-                uint32_t rank = base[brow + 2 * d] + (old & 0xFFFFu) + 1u;      // 1-based global rank
-                uint32_t relrank = base[brow + 2 * d + 1] + (old >> 16) + 1u;  // 1-based rank among relevant rows
-                bool counts = true;
-                if (skip) {
-                    if (rank == 1u) counts = false;
-                    rank -= 1u;
-                    relrank -= (uint32_t)frel;
-                }
-                if (rank_limit > 0 && (int64_t)rank > rank_limit) counts = false;
-                if (counts) {
-                    S += fixdiv32(relrank, rank);
-                    nrel += 1;
-                }
-            }
+            const uint32_t old = atomicAdd(col + d * BLK, inc);
+            if (rel) account(*(const uint2 *)(base + brow + 2 * d), old);
         }
-    }
-    if (MODE == 0) {
-        if (valid) {
-            uint32_t *o = out_hist + brow;
-            for (int d = 0; d < NB; ++d) {
-                const uint32_t v = cnt[d * BLK + tid];
-                *(uint2 *)(o + 2 * d) = make_uint2(v & 0xFFFFu, v >> 16);
+    };
+
+    int j = 0;
+    if (LW == 0) {
+        uint64_t bufA[UB * W], bufB[UB * W];
+        int32_t labA[UB], labB[UB];
+        auto load_block = [&](uint64_t (&dst)[UB * W], int32_t (&lab)[UB], int r0) {
+#pragma unroll
+            for (int t = 0; t < UB * W; ++t) dst[t] = gp[(size_t)r0 * W + t];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) lab[u] = gl32[r0 + u];
+        };
+        auto scan_block = [&](const uint64_t (&blk)[UB * W], const int32_t (&lab)[UB]) {
+            uint32_t d[UB], old[UB];
+            bool rel[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                d[u] = (uint32_t)hamming<W>(qw, blk + u * W);
+                rel[u] = valid && (lab[u] == qlab);
             }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {  // in row order: two rows of a trip may share a bucket
+                const uint32_t inc = 1u | ((uint32_t)rel[u] << 16);
+                if (MODE == 0)
+                    atomicAdd(col + d[u] * BLK, inc);
+                else
+                    old[u] = atomicAdd(col + d[u] * BLK, inc);
+            }
+            if (MODE == 1) {
+                if (__builtin_amdgcn_ballot_w64(rel[0] | rel[1] | rel[2] | rel[3]) != 0ull) {
+                    uint2 b[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) b[u] = *(const uint2 *)(base + brow + 2 * d[u]);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+                        if (rel[u]) account(b[u], old[u]);
+                }
+            }
+        };
+        if (n >= UB) load_block(bufA, labA, 0);
+        for (; j + 2 * UB <= n; j += 2 * UB) {
+            load_block(bufB, labB, j + UB);
+            scan_block(bufA, labA);
+            if (j + 3 * UB <= n) load_block(bufA, labA, j + 2 * UB);
+            scan_block(bufB, labB);
+        }
+        if (j + UB <= n) {  // an odd number of whole blocks: the last one is already in bufA
+            scan_block(bufA, labA);
+            j += UB;
+        }
+        for (; j < n; ++j) row(gp + (size_t)j * W, valid && (gl32[j] == qlab));
+    } else {
+        for (; j < n; ++j) row(gp + (size_t)j * W, valid && relevant_multi(qm, glm + (size_t)j * LW, LW));
+    }
+
+    if (MODE == 0) {
+        // out_hist[seg][q][bucket] = (count, relevant count): element e of this tile's [BLK][NB] block is written by thread
+        // e % BLK -> consecutive lanes write consecutive 8-byte elements
+        __syncthreads();
+        const int nq = (int)min((int64_t)BLK, Qn - q0);
+        uint2 *o = (uint2 *)(out_hist + ((size_t)seg * Qn + q0) * NB * 2);
+        for (int e = tid; e < nq * NB; e += BLK) {
+            const int ql = e / NB, d = e - ql * NB;
+            const uint32_t v = cnt[d * BLK + ql];
+            o[e] = make_uint2(v & 0xFFFFu, v >> 16);
         }
     } else {
-        if (valid && nrel) {
-            atomicAdd(out_S + qi, S);
-            atomicAdd(out_nrel + qi, nrel);
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (r < nlim && nrel[r]) {  // out_S / out_nrel are [nlim, Qn]; limits past nlim are padding
+                    atomicAdd(out_S + (size_t)r * Qn + qi, S[r]);
+                    atomicAdd(out_nrel + (size_t)r * Qn + qi, nrel[r]);
+                }
         }
     }
 }
 
-// hist [nseg,Qn,nb,2] -> base: exclusive prefix in ranking order (bucket ascending, then segment ascending)
-__global__ void hist_prefix_kernel(const uint32_t *__restrict__ hist, int nseg, int64_t Qn, int nb, uint32_t *__restrict__ base,
-                                   uint32_t *__restrict__ totals) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= Qn * 2) return;
-    const int64_t qi = gid >> 1;
-    const int comp = (int)(gid & 1);
-    uint32_t run = 0;
-    for (int d = 0; d < nb; ++d)
-        for (int s = 0; s < nseg; ++s) {
-            const size_t off = (((size_t)s * Qn + qi) * nb + d) * 2 + comp;
-            base[off] = run;
-            run += hist[off];
-        }
-    if (totals) totals[qi * 2 + comp] = run;
+// hist [nseg,Qn,nb,2] -> base: exclusive prefix in ranking order (bucket ascending, then segment ascending).
+// One wave per query, a lane per bucket (coalesced 8-byte accesses): per-bucket totals over the segments, a wave scan across
+// buckets, then the per-segment bases.
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t &total) {
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+__global__ __launch_bounds__(256) void hist_prefix_kernel(const uint32_t *__restrict__ hist, int nseg, int64_t Qn, int nb,
+                                                          uint32_t *__restrict__ base, uint32_t *__restrict__ totals) {
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (qi >= Qn) return;  // wave-uniform
+    const uint2 *h = (const uint2 *)hist;
+    uint2 *b = (uint2 *)base;
+    uint32_t carry_a = 0, carry_r = 0;
+    for (int d0 = 0; d0 < nb; d0 += 64) {
+        const int d = d0 + lane;
+        const bool act = d < nb;
+        uint32_t ta = 0, tr = 0;
+        for (int s = 0; s < nseg; ++s)
+            if (act) {
+                const uint2 v = h[((size_t)s * Qn + qi) * nb + d];
+                ta += v.x;
+                tr += v.y;
+            }
+        uint32_t sum_a, sum_r;
+        uint32_t ba = carry_a + wave_excl_scan(ta, lane, sum_a), br = carry_r + wave_excl_scan(tr, lane, sum_r);
+        for (int s = 0; s < nseg; ++s)
+            if (act) {
+                const size_t off = ((size_t)s * Qn + qi) * nb + d;
+                const uint2 v = h[off];
+                b[off] = make_uint2(ba, br);
+                ba += v.x;
+                br += v.y;
+            }
+        carry_a += sum_a;
+        carry_r += sum_r;
+    }
+    if (totals && lane == 0) {
+        totals[qi * 2] = carry_a;
+        totals[qi * 2 + 1] = carry_r;
+    }
 }
 
-template <int W, int BLK>
-int launch_scan(int mode, const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql, const void *gl,
-                int LW, int seg_rows, uint32_t *out_hist, const uint32_t *base, int64_t rank_limit, const int32_t *first_rel,
-                unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
+template <int W, int BLK, int MODE, int NR>
+int launch_scan_nr(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql, const void *gl, int LW,
+                   int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims, int nlim,
+                   const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
     const int nseg = (int)ceil_div64(G, seg_rows);
     const size_t lds = sizeof(uint32_t) * (64 * W + 1) * BLK;
     dim3 grid((unsigned)ceil_div64(Qn, BLK), (unsigned)nseg);
-    if (mode == 0) {
-        static bool set0 = false;
-        if (!set0) {
-            CH_CHECK_HIP(hipFuncSetAttribute((const void *)map_scan_kernel<W, BLK, 0>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            set0 = true;
-        }
-        hipLaunchKernelGGL((map_scan_kernel<W, BLK, 0>), grid, dim3(BLK), lds, s, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist,
-                           base, rank_limit, first_rel, out_S, out_nrel);
-    } else {
-        static bool set1 = false;
-        if (!set1) {
-            CH_CHECK_HIP(hipFuncSetAttribute((const void *)map_scan_kernel<W, BLK, 1>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            set1 = true;
-        }
-        hipLaunchKernelGGL((map_scan_kernel<W, BLK, 1>), grid, dim3(BLK), lds, s, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist,
-                           base, rank_limit, first_rel, out_S, out_nrel);
-    }
+    static ch_once_per_device lds_once;
+    if (int e = ch_func_max_lds((const void *)map_scan_kernel<W, BLK, MODE, NR>, (int)lds, lds_once)) return e;
+    hipLaunchKernelGGL((map_scan_kernel<W, BLK, MODE, NR>), grid, dim3(BLK), lds, s, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist,
+                       base, lims, nlim, first_rel, out_S, out_nrel);
     CH_LAUNCH_CHECK();
     return 0;
 }
 
+template <int W, int BLK>
+int launch_scan(int mode, int nlim, const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql,
+                const void *gl, int LW, int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims,
+                const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
+    if (mode == 0)
+        return launch_scan_nr<W, BLK, 0, 1>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
+    if (nlim == 1)
+        return launch_scan_nr<W, BLK, 1, 1>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
+    if (nlim <= 4)
+        return launch_scan_nr<W, BLK, 1, 4>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
+    return launch_scan_nr<W, BLK, 1, MAX_LIMITS>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
+}
+
+// lims: nlim ascending rank limits, padded to MAX_LIMITS with copies of the last one (the kernel instance accumulates
+// NR = 1 / 4 / 16 of them and stores rows [0, nlim) of out_S / out_nrel)
 int scan_dispatch(int mode, const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int W, const void *ql,
-                  const void *gl, int LW, int seg_rows, uint32_t *out_hist, const uint32_t *base, int64_t rank_limit,
-                  const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
+                  const void *gl, int LW, int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims,
+                  int nlim, const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
     CH_REQUIRE(W >= 1 && W <= 4, "hamming: 1 <= W <= 4 (nbit <= 256)");
     CH_REQUIRE(seg_rows >= 1 && seg_rows <= 65535, "hamming: seg_rows must be in [1, 65535]");
     CH_REQUIRE(LW >= 0, "hamming: LW must be >= 0");
@@ -378,10 +503,10 @@ int scan_dispatch(int mode, const uint64_t *q, int64_t Qn, const uint64_t *g, in
     CH_REQUIRE(q && g && ql && gl, "hamming: null pointer");
     CH_REQUIRE(ceil_div64(G, seg_rows) <= 65535, "hamming: too many gallery segments (raise seg_rows)");
     switch (W) {
-        case 1: return launch_scan<1, 256>(mode, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, rank_limit, first_rel, out_S, out_nrel, s);
-        case 2: return launch_scan<2, 256>(mode, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, rank_limit, first_rel, out_S, out_nrel, s);
-        case 3: return launch_scan<3, 128>(mode, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, rank_limit, first_rel, out_S, out_nrel, s);
-        default: return launch_scan<4, 128>(mode, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, rank_limit, first_rel, out_S, out_nrel, s);
+        case 1: return launch_scan<1, 256>(mode, nlim, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, first_rel, out_S, out_nrel, s);
+        case 2: return launch_scan<2, 256>(mode, nlim, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, first_rel, out_S, out_nrel, s);
+        case 3: return launch_scan<3, 128>(mode, nlim, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, first_rel, out_S, out_nrel, s);
+        default: return launch_scan<4, 128>(mode, nlim, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, first_rel, out_S, out_nrel, s);
     }
 }
 
@@ -485,16 +610,32 @@ extern "C" int ch_topk_merge(const int64_t *idx_lists, const int32_t *dist_lists
 extern "C" int ch_hamming_hist(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
                                const void *g_labels, int32_t LW, int32_t seg_rows, uint32_t *out_hist, void *stream) {
     CH_REQUIRE(Qn == 0 || G == 0 || out_hist != nullptr, "hamming_hist: null output");
-    return scan_dispatch(0, q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, out_hist, nullptr, 0, nullptr, nullptr, nullptr,
+    RankLimits lims{};
+    return scan_dispatch(0, q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, out_hist, nullptr, lims, 1, nullptr, nullptr, nullptr,
+                         (hipStream_t)stream);
+}
+
+extern "C" int ch_hamming_ap_multi(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                                   const void *g_labels, int32_t LW, int32_t seg_rows, const uint32_t *base,
+                                   const int64_t *rank_limits, int32_t nlimits, const int32_t *first_rel,
+                                   unsigned long long *out_S, uint32_t *out_nrel, void *stream) {
+    CH_REQUIRE(nlimits >= 1 && nlimits <= MAX_LIMITS && rank_limits != nullptr, "hamming_ap_multi: 1 <= nlimits <= 16");
+    CH_REQUIRE(Qn == 0 || G == 0 || (base && out_S && out_nrel), "hamming_ap_multi: null pointer");
+    RankLimits lims;
+    for (int i = 0; i < MAX_LIMITS; ++i) {
+        const int64_t r = rank_limits[i < nlimits ? i : nlimits - 1];
+        lims.lim[i] = (r <= 0 || r >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (uint32_t)r;
+        CH_REQUIRE(i == 0 || lims.lim[i] >= lims.lim[i - 1], "hamming_ap_multi: rank limits must ascend (<= 0 = unlimited, last)");
+    }
+    return scan_dispatch(1, q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, nullptr, base, lims, nlimits, first_rel, out_S, out_nrel,
                          (hipStream_t)stream);
 }
 
 extern "C" int ch_hamming_ap(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
                              const void *g_labels, int32_t LW, int32_t seg_rows, const uint32_t *base, int64_t rank_limit,
                              const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, void *stream) {
-    CH_REQUIRE(Qn == 0 || G == 0 || (base && out_S && out_nrel), "hamming_ap: null pointer");
-    return scan_dispatch(1, q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, nullptr, base, rank_limit, first_rel, out_S,
-                         out_nrel, (hipStream_t)stream);
+    return ch_hamming_ap_multi(q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, base, &rank_limit, 1, first_rel, out_S, out_nrel,
+                               stream);
 }
 
 extern "C" int ch_hamming_hist_prefix(const uint32_t *hist, int32_t nseg, int64_t Qn, int32_t nb, uint32_t *out_base,
@@ -502,8 +643,8 @@ extern "C" int ch_hamming_hist_prefix(const uint32_t *hist, int32_t nseg, int64_
     CH_REQUIRE(nseg >= 1 && nb >= 1 && Qn >= 0, "hist_prefix: bad sizes");
     if (Qn == 0) return 0;
     CH_REQUIRE(hist && out_base, "hist_prefix: null pointer");
-    hipLaunchKernelGGL(hist_prefix_kernel, dim3((unsigned)ceil_div64(Qn * 2, 256)), dim3(256), 0, (hipStream_t)stream, hist, nseg,
-                       Qn, nb, out_base, out_totals);
+    hipLaunchKernelGGL(hist_prefix_kernel, dim3((unsigned)ceil_div64(Qn, 4)), dim3(256), 0, (hipStream_t)stream, hist, nseg, Qn, nb,
+                       out_base, out_totals);
     CH_LAUNCH_CHECK();
     return 0;
 }

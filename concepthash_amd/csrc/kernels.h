@@ -52,6 +52,7 @@ struct GemmParams {
     unsigned *splitk_cnt;
     int split_full, split_s;
     int force_split;         // debug taps: split even though CH_GEMM_SPLITK is off
+    int pp_min_k;            // dispatcher: smallest K that goes to the 256x256 ping-pong kernel (0 = default 512)
 };
 constexpr size_t CH_SPLITK_WS_BYTES = (size_t)256 * 256 * 256 * 4;  // 64 MiB: at most 256 tail units of one 256x256 fp32 slab
 constexpr size_t CH_SPLITK_CNT_BYTES = 256 * sizeof(unsigned);

@@ -1,6 +1,7 @@
 // ch_model: weights + workspace + the per-batch launch sequence of the ConceptHash encoder (C-ABI in
 // include/concepthash_hip.h).  Restates LGHWithFixedPrompt.forward (models/arch/coop.py:524-598) as a fixed chain of
 // HIP launches on one stream; see DESIGN.md for the kernel list and data layout.
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <string>
@@ -14,6 +15,8 @@ static thread_local std::string g_last_error;
 void ch_set_error(const std::string &msg) { g_last_error = msg; }
 extern "C" const char *ch_last_error(void) { return g_last_error.c_str(); }
 extern "C" int ch_abi_version(void) { return CH_ABI_VERSION; }
+
+constexpr int CH_MAX_STREAMS = 4;  // micro-batch chains that may run concurrently (CH_STREAMS)
 
 namespace {
 struct AdapterW {
@@ -60,21 +63,22 @@ struct ch_model {
         std::vector<int> cat;
         std::vector<double> flops;
         size_t n = 0;
-    } prof[2];  // one per micro-batch stream
+    } prof[CH_MAX_STREAMS];  // one per micro-batch stream
     // optional (CH_STREAMS=2): two micro-batches on two HIP streams, so memory-bound launches of one chain (LayerNorm,
     // epilogue-heavy GEMMs) co-run with MFMA-bound launches of the other.  Measured +8.8 % images/s at B = 256 (16.0k -> 17.5k);
     // only LDS-free kernels can share a CU with the 128 KB ping-pong GEMM, so the overlap is partial.  Not the default:
     // per-launch durations (and the roofline computed from them) stop describing the kernels once launches overlap.
     int nstreams = 1;
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux_stream[CH_MAX_STREAMS - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[CH_MAX_STREAMS - 1] = {};
     // workspace
     int64_t rows_alloc = 0, prow_alloc = 0;
     float *H = nullptr;
-    float *splitk_ws[2] = {nullptr, nullptr};      // split-K tail slabs + tickets of the 256x256 GEMM, one set per chain
-    unsigned *splitk_cnt[2] = {nullptr, nullptr};
+    float *splitk_ws[CH_MAX_STREAMS] = {};      // split-K tail slabs + tickets of the 256x256 GEMM, one set per chain
+    unsigned *splitk_cnt[CH_MAX_STREAMS] = {};
     // final-layer row pruning: compact fp32 copy of the residual rows the head reads, [max_batch * (1 + Q) (+pad), D]
     bool prune_last = true;
+    int pp_min_k = 0;  // CH_GEMM_PP_MIN_K at creation (tests: sends small-K GEMMs of a small fixture to the 256x256 kernel)
     float *Hc = nullptr;
     float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn
     bf16_t *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *A = nullptr, *AD = nullptr, *F1 = nullptr, *PATCH = nullptr;
@@ -377,7 +381,7 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
     m->H = (float *)B.alloc(sizeof(float) * rows * D);
     m->Xn = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * D);
     const bool want_splitk = getenv("CH_GEMM_SPLITK") && atoi(getenv("CH_GEMM_SPLITK")) != 0;  // opt-in, see gemm_pp.hip
-    for (int i = 0; want_splitk && i < (m->nstreams >= 2 ? 2 : 1); ++i) {
+    for (int i = 0; want_splitk && i < m->nstreams; ++i) {
         m->splitk_ws[i] = (float *)B.alloc(CH_SPLITK_WS_BYTES);
         m->splitk_cnt[i] = (unsigned *)B.alloc(CH_SPLITK_CNT_BYTES);
         if (!B.ok) return 4;
@@ -449,6 +453,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         GemmParams p{};
         p.X = m->PATCH; p.W = mm->patch_w; p.M = B * np; p.N = D; p.K = mm->Kp; p.X_rows_alloc = m->prow_alloc;
         p.bias = nullptr; p.resid = m->H; p.ldr = D; p.pos = mm->pos; p.tokens_per_img = ntok; p.patches_per_img = np;
+        p.pp_min_k = mm->pp_min_k;
         if (int e = ch_gemm_bf16(p, EPI_PATCH, s)) return e;
     }
     const LayerW &w0 = mm->layers[0];
@@ -472,7 +477,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
                     int epi, bf16_t *out, int ldo, const float *scale, const bf16_t *addend = nullptr, const Fold &f = Fold()) {
         mark(mm, pi, cat, 2.0 * cur_rows * (double)n_true * k_true, s);
         GemmParams p{};
-        p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi];
+        p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi]; p.pp_min_k = mm->pp_min_k;
         p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
         p.X = X; p.W = W; p.M = cur_rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
@@ -569,14 +574,20 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
 // micro-batches whose chains run concurrently (fork/join by events on the caller's stream).
 int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nlayers, hipStream_t s,
                 float *concept_attn = nullptr, bool prune = false) {
-    if (m->nstreams < 2 || B < 2) return run_chain(m, 0, images, image_dtype, 0, B, nlayers, s, concept_attn, prune);
-    const int B0 = (B + 1) / 2, B1 = B - B0;
+    const int ns = std::min(m->nstreams, B);
+    if (ns < 2) return run_chain(m, 0, images, image_dtype, 0, B, nlayers, s, concept_attn, prune);
+    // micro-batch i = images [i*B/ns, (i+1)*B/ns); chain 0 on the caller's stream, the others fork from / join it
     CH_CHECK_HIP(hipEventRecord(m->ev_fork, s));
-    CH_CHECK_HIP(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
-    if (int e = run_chain(m, 0, images, image_dtype, 0, B0, nlayers, s, concept_attn, prune)) return e;
-    if (int e = run_chain(m, 1, images, image_dtype, B0, B1, nlayers, m->aux_stream, concept_attn, prune)) return e;
-    CH_CHECK_HIP(hipEventRecord(m->ev_join, m->aux_stream));
-    CH_CHECK_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
+    for (int i = 0; i < ns; ++i) {
+        const int b0 = (int)((int64_t)B * i / ns), b1 = (int)((int64_t)B * (i + 1) / ns);
+        hipStream_t si = i == 0 ? s : m->aux_stream[i - 1];
+        if (i > 0) CH_CHECK_HIP(hipStreamWaitEvent(si, m->ev_fork, 0));
+        if (int e = run_chain(m, i, images, image_dtype, b0, b1 - b0, nlayers, si, concept_attn, prune)) return e;
+        if (i > 0) {
+            CH_CHECK_HIP(hipEventRecord(m->ev_join[i - 1], si));
+            CH_CHECK_HIP(hipStreamWaitEvent(s, m->ev_join[i - 1], 0));
+        }
+    }
     return 0;
 }
 
@@ -617,11 +628,14 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
     if (const char *e = getenv("CH_FUSED_ADAPTER")) m->use_fused_adapter = atoi(e) != 0;
     if (const char *e = getenv("CH_LN_FOLD")) m->ln_fold = atoi(e) != 0;
     if (const char *e = getenv("CH_PRUNE_LAST")) m->prune_last = atoi(e) != 0;
-    if (const char *e = getenv("CH_STREAMS")) m->nstreams = atoi(e) >= 2 ? 2 : 1;
-    if (hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
-        ch_set_error("cannot create the auxiliary stream / events");
+    if (const char *e = getenv("CH_GEMM_PP_MIN_K")) m->pp_min_k = atoi(e);
+    if (const char *e = getenv("CH_STREAMS")) m->nstreams = std::max(1, std::min(atoi(e), CH_MAX_STREAMS));
+    bool aux_ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; aux_ok && i < CH_MAX_STREAMS - 1; ++i)
+        aux_ok = hipStreamCreateWithFlags(&m->aux_stream[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    if (!aux_ok) {
+        ch_set_error("cannot create the auxiliary streams / events");
         ch_model_destroy(m);
         return 4;
     }
@@ -643,9 +657,11 @@ extern "C" void ch_model_destroy(ch_model *m) {
     if (!m) return;
     for (auto &P : m->prof)
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
-    if (m->aux_stream) (void)hipStreamDestroy(m->aux_stream);
+    for (hipStream_t a : m->aux_stream)
+        if (a) (void)hipStreamDestroy(a);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    for (hipEvent_t e : m->ev_join)
+        if (e) (void)hipEventDestroy(e);
     for (void *p : m->allocs) (void)hipFree(p);
     delete m;
 }

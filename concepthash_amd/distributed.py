@@ -57,7 +57,7 @@ class ShardedRetrieval:
     gallery:  packed codes of THIS rank's rows, int64 [G_local, W]
     labels:   labels of this rank's rows (1-D class ids or 2-D indicator matrix), optional
     ops:      module/object providing hamming_topk, topk_merge, prepare_labels, hamming_hist, hist_prefix,
-              hamming_ap, map_seg_rows, ap_from_fixed  (default: concepthash_amd.retrieval)
+              hamming_ap_multi, normalize_limits, summarize, map_seg_rows  (default: concepthash_amd.retrieval)
     """
 
     def __init__(self, gallery: torch.Tensor, labels: Optional[torch.Tensor] = None, group=None, ops=None):
@@ -96,8 +96,11 @@ class ShardedRetrieval:
         return self.ops.topk_merge(li, ld)
 
     # ---- mAP / P@k / R@k -----------------------------------------------------------------------------------------
-    def evaluate(self, q_all: torch.Tensor, q_labels: torch.Tensor, R: int = -1, ks: Sequence[int] = (1, 5, 10),
+    def evaluate(self, q_all: torch.Tensor, q_labels: torch.Tensor, R=-1, ks: Sequence[int] = (1, 5, 10),
                  remove_first: bool = False, seg_rows: Optional[int] = None) -> dict:
+        """Same statistics as ``retrieval.evaluate`` (R an int or a list), gallery sharded by rows: per-shard histograms are
+        all-gathered, every rank builds the same global bases, ONE local AP pass accumulates every rank limit (each R and each
+        k), and the integer sums are all-reduced -- bit-identical to the single-GPU result for any shard count."""
         if self.labels is None:
             raise ValueError("gallery labels are required for evaluate()")
         ops = self.ops
@@ -105,19 +108,20 @@ class ShardedRetrieval:
         Qn, W = q_all.shape
         q_lab, g_lab, LW = ops.prepare_labels(q_labels.to(dev), self.labels.to(dev))
         ks = [int(k) for k in ks]
-        kmax = (max(ks) if ks else 0) + (1 if remove_first else 0)
-        first_rel = rel_top = None
-        if kmax > 0:
-            idx, _ = self.topk(q_all, min(kmax, 128))
+        if any(k <= 0 for k in ks):
+            raise ValueError("P@k / R@k need k >= 1")
+        many = isinstance(R, (list, tuple))
+        Rs = [int(r) for r in R] if many else [int(R)]
+        first_rel = None
+        if remove_first:      # relevance of the global rank-1 row of every query
+            idx, _ = self.topk(q_all, 1)
             g_lab_all, _ = _all_gather_ragged(g_lab, self.group) if self.world > 1 else (g_lab, None)
             safe = idx.clamp_min(0)
             if LW == 0:
-                rel_top = (g_lab_all[safe] == q_lab[:, None]) & (idx >= 0)
+                rel = (g_lab_all[safe] == q_lab[:, None]) & (idx >= 0)
             else:
-                rel_top = (g_lab_all[safe] & q_lab[:, None, :]).ne(0).any(-1) & (idx >= 0)
-            if remove_first:
-                first_rel = rel_top[:, 0].to(torch.int32)
-                rel_top = rel_top[:, 1:]
+                rel = (g_lab_all[safe] & q_lab[:, None, :]).ne(0).any(-1) & (idx >= 0)
+            first_rel = rel[:, 0].to(torch.int32)
         # one segment size for all ranks, so the gathered histogram stack has one shape
         gmax = max(self.counts) if self.counts else 0
         seg = seg_rows or ops.map_seg_rows(Qn, max(gmax, 1), W)
@@ -129,21 +133,19 @@ class ShardedRetrieval:
         hist_all = _all_gather_rows(hist, self.group) if self.world > 1 else hist      # [world*nseg, Qn, nb, 2], rank-major
         base_all, totals = ops.hist_prefix(hist_all)
         base = base_all[self.rank * nseg:(self.rank + 1) * nseg].contiguous()
-        S, nrel = ops.hamming_ap(q_all, self.gallery, q_lab, g_lab, LW, seg, base, rank_limit=R, first_rel=first_rel)
+        limits, idx_of = ops.normalize_limits(Rs + ks)
+        S, nrel = ops.hamming_ap_multi(q_all, self.gallery, q_lab, g_lab, LW, seg, base, limits, first_rel=first_rel)
         if self.world > 1:
             dist.all_reduce(S, op=dist.ReduceOp.SUM, group=self.group)       # int64 wrap-around sum == uint64 sum
             dist.all_reduce(nrel, op=dist.ReduceOp.SUM, group=self.group)
         total = totals[:, 1].clone()
         if remove_first:
             total = total - first_rel
-        ap = ops.ap_from_fixed(S, nrel)
-        hits = torch.zeros(Qn, len(ks), dtype=torch.int32, device=dev)
-        precisions, recalls = [], []
-        for t, k in enumerate(ks):
-            h = rel_top[:, :k].sum(1).to(torch.int32)
-            hits[:, t] = h
-            precisions.append(float((h.double() / k).mean().item()) if Qn else 0.0)
-            recalls.append(float(torch.where(total > 0, h.double() / total.clamp_min(1).double(),
-                                             torch.zeros_like(h, dtype=torch.float64)).mean().item()) if Qn else 0.0)
-        return dict(mAP=float(ap.mean().item()) if Qn else 0.0, precisions=precisions, recalls=recalls, S=S, nrel=nrel,
-                    hits=hits, total=total, ap=ap)
+        sm = ops.summarize(S, nrel, total, idx_of, Rs, ks)
+        out = dict(precisions=sm["precisions"], recalls=sm["recalls"], hits=sm["hits"], total=total)
+        if many:
+            out.update(mAP=sm["mAPs"], S=[S[idx_of[i]] for i in range(len(Rs))], nrel=[nrel[idx_of[i]] for i in range(len(Rs))],
+                       ap=sm["aps"])
+        else:
+            out.update(mAP=sm["mAPs"][0], S=S[idx_of[0]], nrel=nrel[idx_of[0]], ap=sm["aps"][0])
+        return out

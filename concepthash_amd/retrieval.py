@@ -178,6 +178,42 @@ def _relevance_of(idx: torch.Tensor, q_lab: torch.Tensor, g_lab_all: torch.Tenso
     return rel & (idx >= 0)
 
 
+MAX_LIMITS = 16   # rank limits one AP pass accumulates (csrc/hamming.hip)
+
+
+def normalize_limits(limits: Sequence[int]):
+    """-> (ascending unique limits with "unlimited" (<= 0) last as 0, index of every input limit in that list)"""
+    norm = [int(r) if int(r) > 0 else 0 for r in limits]
+    uniq = sorted({r for r in norm if r > 0}) + ([0] if 0 in norm else [])
+    pos = {r: i for i, r in enumerate(uniq)}
+    return uniq, [pos[r] for r in norm]
+
+
+def hamming_ap_multi(q, g, q_lab, g_lab, LW: int, seg_rows: int, base: torch.Tensor, rank_limits: Sequence[int],
+                     first_rel: Optional[torch.Tensor] = None, stream=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """mAP pass 2 for a list of ascending rank limits (<= 0 = unlimited, last) in ONE gallery scan per 16 limits
+    -> (S int64 [n, Qn], nrel int32 [n, Qn]); nrel[i] = number of relevant rows inside limit i."""
+    lib = _lib.load()
+    q, g = _check_packed(q, g)
+    Qn, W = q.shape
+    G = g.shape[0]
+    lim = [int(r) for r in rank_limits]
+    n = len(lim)
+    S = torch.zeros(n, Qn, dtype=torch.int64, device=q.device)
+    nrel = torch.zeros(n, Qn, dtype=torch.int32, device=q.device)
+    if first_rel is not None:
+        first_rel = first_rel.to(torch.int32).contiguous()
+    base = base.contiguous()
+    with _dev_guard(q):
+        for c0 in range(0, n, MAX_LIMITS):
+            chunk = lim[c0:c0 + MAX_LIMITS]
+            arr = (ctypes.c_int64 * len(chunk))(*chunk)
+            _lib.check(lib.ch_hamming_ap_multi(_lib.ptr(q), Qn, _lib.ptr(g), G, W, _lib.ptr(q_lab), _lib.ptr(g_lab), LW, seg_rows,
+                                               _lib.ptr(base), arr, len(chunk), _lib.ptr(first_rel), _lib.ptr(S[c0:c0 + len(chunk)]),
+                                               _lib.ptr(nrel[c0:c0 + len(chunk)]), _lib.stream_ptr(stream)), "ch_hamming_ap_multi")
+    return S, nrel
+
+
 def ap_from_fixed(S: torch.Tensor, nrel: torch.Tensor) -> torch.Tensor:
     """AP[q] = S / (nrel * 2^32) in float64 (0 where nrel == 0); S holds uint64 bit patterns."""
     Sf = S.to(torch.float64)
@@ -186,46 +222,66 @@ def ap_from_fixed(S: torch.Tensor, nrel: torch.Tensor) -> torch.Tensor:
     return torch.where(nrel > 0, Sf / (n.clamp_min(1.0) * TWO32), torch.zeros_like(Sf))
 
 
-def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels: torch.Tensor, R: int = -1,
+def summarize(S, nrel, total, idx_of, Rs: Sequence[int], ks: Sequence[int]) -> dict:
+    """Host-side statistics from the per-limit integers of one multi-limit AP pass: limits were Rs + ks (idx_of maps each to
+    its row of S / nrel).  mAP per R; P@k = hits / k and R@k = hits / total with hits = nrel under limit k."""
+    Qn = total.shape[0]
+    dev = total.device
+    nR = len(Rs)
+    aps = [ap_from_fixed(S[idx_of[i]], nrel[idx_of[i]]) for i in range(nR)]
+    hits = torch.zeros(Qn, len(ks), dtype=torch.int32, device=dev)
+    precisions, recalls = [], []
+    for t, k in enumerate(ks):
+        h = nrel[idx_of[nR + t]]
+        hits[:, t] = h
+        precisions.append(float((h.double() / k).mean().item()) if Qn else 0.0)
+        recalls.append(float(torch.where(total > 0, h.double() / total.clamp_min(1).double(),
+                                         torch.zeros_like(h, dtype=torch.float64)).mean().item()) if Qn else 0.0)
+    return dict(mAPs=[float(a.mean().item()) if Qn else 0.0 for a in aps], aps=aps, hits=hits, precisions=precisions,
+                recalls=recalls)
+
+
+def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels: torch.Tensor, R=-1,
              ks: Sequence[int] = (1, 5, 10), remove_first: bool = False, seg_rows: Optional[int] = None) -> dict:
-    """Single-GPU mAP@R + P@k + R@k on packed codes.  Returns python floats/lists plus the raw integer statistics
-    (S, nrel, hits, total) that the parity tests compare bit-for-bit with the oracle."""
+    """Single-GPU mAP@R + P@k + R@k on packed codes: histogram pass, prefix, ONE AP pass whose rank limits are R (an int or
+    a list) and every k -- the number of relevant rows inside limit k is exactly hits@k, for any k.  Returns python
+    floats/lists plus the raw integer statistics (S, nrel, hits, total) that the parity tests compare bit-for-bit with the
+    oracle.  With a list R: mAP, S, nrel, ap are lists (one entry per R)."""
     q, g = _check_packed(q, g)
     Qn, W = q.shape
     G = g.shape[0]
     q_lab, g_lab, LW = prepare_labels(q_labels.to(q.device), g_labels.to(q.device))
     seg = seg_rows or map_seg_rows(Qn, G, W)
     ks = [int(k) for k in ks]
-    kmax = (max(ks) if ks else 0) + (1 if remove_first else 0)
+    if any(k <= 0 for k in ks):
+        raise ValueError("P@k / R@k need k >= 1")
+    many = isinstance(R, (list, tuple))
+    Rs = [int(r) for r in R] if many else [int(R)]
     dev = q.device
     if Qn == 0 or G == 0:
         z64 = torch.zeros(Qn, dtype=torch.int64, device=dev)
         z32 = torch.zeros(Qn, dtype=torch.int32, device=dev)
-        return dict(mAP=0.0, precisions=[0.0] * len(ks), recalls=[0.0] * len(ks), S=z64, nrel=z32,
-                    hits=torch.zeros(Qn, len(ks), dtype=torch.int32, device=dev), total=z32, ap=z64.double())
+        out = dict(mAP=0.0, precisions=[0.0] * len(ks), recalls=[0.0] * len(ks), S=z64, nrel=z32,
+                   hits=torch.zeros(Qn, len(ks), dtype=torch.int32, device=dev), total=z32, ap=z64.double())
+        if many:
+            out.update(mAP=[0.0] * len(Rs), S=[z64] * len(Rs), nrel=[z32] * len(Rs), ap=[z64.double()] * len(Rs))
+        return out
     first_rel = None
-    rel_top = None
-    if kmax > 0:
-        kk = min(kmax, 128)
-        idx, _ = hamming_topk(q, g, kk)
-        rel_top = _relevance_of(idx, q_lab, g_lab, LW)
-        if remove_first:
-            first_rel = rel_top[:, 0].to(torch.int32)
-            rel_top = rel_top[:, 1:]
+    if remove_first:   # relevance of every query's rank-1 row (the self-match when the test set is the database)
+        idx, _ = hamming_topk(q, g, 1)
+        first_rel = _relevance_of(idx, q_lab, g_lab, LW)[:, 0].to(torch.int32)
+    limits, idx_of = normalize_limits(Rs + ks)
     hist = hamming_hist(q, g, q_lab, g_lab, LW, seg)
     base, totals = hist_prefix(hist)
-    S, nrel = hamming_ap(q, g, q_lab, g_lab, LW, seg, base, rank_limit=R, first_rel=first_rel)
+    S, nrel = hamming_ap_multi(q, g, q_lab, g_lab, LW, seg, base, limits, first_rel=first_rel)
     total = totals[:, 1].clone()
     if remove_first:
         total = total - first_rel
-    ap = ap_from_fixed(S, nrel)
-    hits = torch.zeros(Qn, len(ks), dtype=torch.int32, device=dev)
-    precisions, recalls = [], []
-    for t, k in enumerate(ks):
-        h = rel_top[:, :k].sum(1).to(torch.int32) if rel_top is not None and rel_top.shape[1] > 0 else torch.zeros_like(total)
-        hits[:, t] = h
-        precisions.append(float((h.double() / k).mean().item()))
-        recalls.append(float(torch.where(total > 0, h.double() / total.clamp_min(1).double(),
-                                         torch.zeros_like(h, dtype=torch.float64)).mean().item()))
-    return dict(mAP=float(ap.mean().item()), precisions=precisions, recalls=recalls, S=S, nrel=nrel, hits=hits,
-                total=total, ap=ap)
+    sm = summarize(S, nrel, total, idx_of, Rs, ks)
+    out = dict(precisions=sm["precisions"], recalls=sm["recalls"], hits=sm["hits"], total=total)
+    if many:
+        out.update(mAP=sm["mAPs"], S=[S[idx_of[i]] for i in range(len(Rs))], nrel=[nrel[idx_of[i]] for i in range(len(Rs))],
+                   ap=sm["aps"])
+    else:
+        out.update(mAP=sm["mAPs"][0], S=S[idx_of[0]], nrel=nrel[idx_of[0]], ap=sm["aps"][0])
+    return out

@@ -122,6 +122,9 @@ int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_alloc, const
                      const float *scale_ptr, const void *addend, const float *stats_in, const float *fold_c, float ln_eps,
                      float *stats_out, void *hb_out, void *stream);
 void ch_debug_set_gemm_variant(int32_t variant);
+/* How many GEMMs the dispatcher has sent to the 128x128 (which = 0) / 256x256 ping-pong (which = 1) kernel since the
+ * library was loaded: lets a parity test prove which kernel produced the output it compared. */
+int64_t ch_debug_gemm_dispatch_count(int32_t which);
 /* Let the debug GEMM taps use the split-K tail of the 256x256 kernel (off by default: a split tile sums its K slices in a
  * different order, so it is no longer bit-identical to the 128x128 kernel). */
 void ch_debug_set_gemm_splitk(int32_t on);
@@ -182,6 +185,16 @@ int ch_hamming_hist(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G,
 int ch_hamming_ap(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
                   const void *g_labels, int32_t LW, int32_t seg_rows, const uint32_t *base, int64_t rank_limit,
                   const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, void *stream);
+
+/* The same pass for up to 16 rank limits at once (one gallery scan instead of one per limit): rank_limits[nlimits] is a
+ * HOST array, ascending, entries <= 0 meaning "no limit" (they sort last); out_S [nlimits, Qn] uint64 and out_nrel
+ * [nlimits, Qn] uint32 are accumulated row r under limit r.  With limits = the list R of calculate_mAP, the depths of
+ * calculate_pr_curve (experiments/test_hashing.py:124-128,153-167) or the k of P@k / R@k -- out_nrel under limit k IS
+ * the number of relevant rows in the top k -- every depth-dependent statistic of the evaluator comes out of one pass. */
+int ch_hamming_ap_multi(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                        const void *g_labels, int32_t LW, int32_t seg_rows, const uint32_t *base,
+                        const int64_t *rank_limits, int32_t nlimits, const int32_t *first_rel, unsigned long long *out_S,
+                        uint32_t *out_nrel, void *stream);
 
 /* Single-GPU helper: hist [nseg,Qn,nb,2] -> base (same shape) + totals[Qn,2] (rows, relevant rows overall). */
 int ch_hamming_hist_prefix(const uint32_t *hist, int32_t nseg, int64_t Qn, int32_t nb, uint32_t *out_base,

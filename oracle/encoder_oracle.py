@@ -192,6 +192,57 @@ def encoder_layer(sd, i: int, h: torch.Tensor, heads: int, R: _R, act: str = "qu
     return h, probs
 
 
+def _fold_linear(xb, W, bias, gamma, beta, eps=1e-5):
+    """LayerNorm folded into the consumer Linear, with the HIP path's rounding points (DESIGN.md section 3.6,
+    fold_ln_kernel + the EPI_FOLD_* epilogues): xb = bf16-rounded RAW rows; W' = bf16(W * gamma); c = row sums of W';
+    d = bias + W beta; single-pass statistics of the rounded rows; y = rstd * (xb W'^T) + (c * (-mean * rstd) + d)."""
+    K = xb.shape[-1]
+    Wf = _bf16(W * gamma)
+    c = Wf.sum(dim=1)
+    d = bias + W @ beta
+    mean = xb.sum(dim=-1, keepdim=True) / K
+    var = (xb.pow(2).sum(dim=-1, keepdim=True) / K - mean * mean).clamp_min(0.0)
+    rstd = torch.rsqrt(var + eps)
+    return (xb @ Wf.t()) * rstd + (c * (-mean * rstd) + d)
+
+
+def _adapter_fold(sd, pre: str, a_b: torch.Tensor) -> torch.Tensor:
+    """adapter on the bf16 copy of the sub-block output, adapter LayerNorm folded into down_proj; returns scale * up(...)"""
+    down = _fold_linear(a_b, sd[pre + "down_proj.weight"].float(), sd[pre + "down_proj.bias"].float(),
+                        sd[pre + "adapter_layer_norm.weight"].float(), sd[pre + "adapter_layer_norm.bias"].float())
+    ad = _bf16(F.gelu(down))
+    up = ad @ _bf16(sd[pre + "up_proj.weight"].float()).t() + sd[pre + "up_proj.bias"].float()
+    return up * sd[pre + "scale"].float()
+
+
+def encoder_layer_fold(sd, i: int, h: torch.Tensor, heads: int, act: str = "quick_gelu"):
+    """The same layer with the rounding points of the HIP path's DEFAULT chain (LayerNorm folded into the consumer GEMMs,
+    the sub-block output entering the residual as its bf16 copy): used only to separate "kernel bug" from "bf16 rounding"."""
+    pre = VM + f"encoder.layers.{i}."
+    B, N, D = h.shape
+    hd = D // heads
+    R = _R(True)
+    if i == 0:   # layer 0: LN1 is computed in fp32 by assemble_preln and rounded afterwards
+        xin = _bf16(layer_norm(h, sd[pre + "layer_norm1.weight"].float(), sd[pre + "layer_norm1.bias"].float()))
+        qkv = [xin @ _bf16(sd[pre + f"self_attn.{n}.weight"].float()).t() + sd[pre + f"self_attn.{n}.bias"].float()
+               for n in ("q_proj", "k_proj", "v_proj")]
+    else:
+        qkv = [_fold_linear(_bf16(h), sd[pre + f"self_attn.{n}.weight"].float(), sd[pre + f"self_attn.{n}.bias"].float(),
+                            sd[pre + "layer_norm1.weight"].float(), sd[pre + "layer_norm1.bias"].float())
+               for n in ("q_proj", "k_proj", "v_proj")]
+    q, k, v = [_bf16(t).reshape(B, N, heads, hd).transpose(1, 2) for t in qkv]
+    s = (q @ k.transpose(-1, -2)) * (hd ** -0.5)
+    e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
+    o = _bf16(((_bf16(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, D))
+    a_b = _bf16(o @ _bf16(sd[pre + "self_attn.out_proj.weight"].float()).t() + sd[pre + "self_attn.out_proj.bias"].float())
+    h = h + a_b + _adapter_fold(sd, pre + "adapt_mlp_1.", a_b)
+    m = _fold_linear(_bf16(h), sd[pre + "mlp.fc1.weight"].float(), sd[pre + "mlp.fc1.bias"].float(),
+                     sd[pre + "layer_norm2.weight"].float(), sd[pre + "layer_norm2.bias"].float())
+    m = _bf16(quick_gelu(m) if act == "quick_gelu" else F.gelu(m))
+    m_b = _bf16(m @ _bf16(sd[pre + "mlp.fc2.weight"].float()).t() + sd[pre + "mlp.fc2.bias"].float())
+    return h + m_b + _adapter_fold(sd, pre + "adapt_mlp_2.", m_b)
+
+
 def hash_head(sd, hash_features: torch.Tensor) -> torch.Tensor:
     """models/arch/coop.py:544-559: (hf + hash_pe) @ hash_fc.W^T -> (B, Q*sub) concept-major -> BatchNorm1d eval."""
     B = hash_features.shape[0]
@@ -224,7 +275,7 @@ def concept_logits(sd, hash_features: torch.Tensor) -> torch.Tensor:
 @torch.no_grad()
 def encode(sd: Dict[str, torch.Tensor], images: torch.Tensor, heads: int, upt_heads: int = 8,
            act: str = "quick_gelu", emulate_bf16: bool = False, stages: Optional[dict] = None,
-           with_pooled: bool = True) -> dict:
+           with_pooled: bool = True, emulate_fold: bool = False) -> dict:
     """LGHWithFixedPrompt.forward (models/arch/coop.py:524-598), eval mode.
 
     Returns dict(codes (B,nbit) fp32 pre-sign, hash_features (B,Q,D), logits_cont, logits_bin (B,C),
@@ -240,7 +291,14 @@ def encode(sd: Dict[str, torch.Tensor], images: torch.Tensor, heads: int, upt_he
     if stages is not None:
         stages["concept_tokens"] = ctx.clone()
         stages["h0"] = h.clone()
+    if emulate_fold and not (emulate_bf16 and dims["b"] > 0):
+        raise ValueError("emulate_fold restates the default HIP chain: needs emulate_bf16=True and a model with adapters")
     for i in range(dims["L"]):
+        if emulate_fold:
+            h = encoder_layer_fold(sd, i, h, heads, act)
+            if stages is not None:
+                stages[f"h{i + 1}"] = h.clone()
+            continue
         h, probs = encoder_layer(sd, i, h, heads, R, act, want_probs=stages is not None)
         if stages is not None:
             stages[f"h{i + 1}"] = h.clone()

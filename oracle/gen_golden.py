@@ -28,11 +28,78 @@ FIXTURES = {
     "encode_hd64": (dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
                          image_size=64, patch_size=16, projection_dim=64), 64, 20, 64, 48, 4, "quick_gelu"),
 }
+# Fixtures whose weights and images are rounded to bf16-representable values BEFORE the reference runs (stored as the
+# uint16 bit patterns, "sdbf/..." / "inbf/...": half the bytes, and the HIP path's weight conversion is exact).
+# encode_n201: image 224 / patch 16 -> 196 patches + CLS + 4 concept tokens = 201 tokens, D = 256 (4 heads x 64), so that
+# the dispatched kernels of the real configs -- the 256x256 ping-pong GEMM (with CH_GEMM_PP_MIN_K=256), the KB = 7
+# attention with its masked 201 -> 224 tail, the LN-fold chain and final-layer pruning -- meet REFERENCE output.
+FIXTURES_BF16 = {
+    "encode_n201": (dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                         image_size=224, patch_size=16, projection_dim=128), 64, 20, 256, 64, 2, "quick_gelu"),
+}
+
+
+def _to_bf16_bits(t: torch.Tensor) -> np.ndarray:
+    return t.detach().to(torch.bfloat16).view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def gen_bf16_fixture(name):
+    vd, nbit, nclass, b, cdim, batch, act = FIXTURES_BF16[name]
+    model = shim.build_reference_model(vd, nbit=nbit, nclass=nclass, adapter_bottleneck_dim=b, seed=7,
+                                       center_dim=cdim, hidden_act=act)
+    cfg = dict(D=vd["hidden_size"], L=vd["num_hidden_layers"], heads=vd["num_attention_heads"],
+               M=vd["intermediate_size"], patch=vd["patch_size"], image=vd["image_size"],
+               P=vd["projection_dim"], b=b)
+    syn = eo.synthetic_state_dict(cfg, nbit=nbit, nclass=nclass, seed=13, center_dim=cdim)
+    missing, unexpected = model.load_state_dict(syn, strict=False)
+    assert not unexpected, unexpected
+    model.eval()
+    with torch.no_grad():
+        for v in model.state_dict().values():          # shares storage with the parameters / buffers (aliases included)
+            if v.is_floating_point():
+                v.copy_(v.to(torch.bfloat16).float())
+    x = eo.synthetic_images(batch, vd["image_size"], seed=5).to(torch.bfloat16).float()
+    with torch.no_grad():
+        feats, out = model(x)
+    sd = model.state_dict()
+    payload = {}
+    for k, v in sd.items():
+        if (k.startswith("adapter_params.") or k.startswith("trainable_params.") or k.startswith("backbone.text_projection")
+                or k.startswith("backbone.text_model.") or k in ("backbone.logit_scale", "hash_bn.num_batches_tracked")):
+            continue
+        if v.is_floating_point():
+            assert torch.equal(v.to(torch.bfloat16).float(), v.float()), k
+            payload["sdbf/" + k] = _to_bf16_bits(v)
+        else:
+            payload["sd/" + k] = v.cpu().numpy()
+    payload["meta/heads"] = np.int64(vd["num_attention_heads"])
+    payload["meta/upt_heads"] = np.int64(8)
+    payload["meta/act"] = np.array(act)
+    payload["inbf/images"] = _to_bf16_bits(x)
+    for key in ("codes", "hash_features", "logits_cont", "logits_bin", "logits_concept"):
+        payload["out/" + key] = out[key].numpy()
+    payload["out/image_features"] = feats.numpy()
+    hs = out["image_hidden_states"]
+    payload["out/h0"] = hs[0].numpy()
+    payload["out/h1"] = hs[1].numpy()
+    payload["out/h_last"] = hs[-1].numpy()
+    Q = 4
+    payload["out/concept_attn_last"] = out["attn_cache"][-1][:, :, -Q:, 1:-Q].numpy()
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **payload)
+    print(name, "->", path, f"{os.path.getsize(path) / 1e6:.2f} MB", "codes", out["codes"].shape,
+          "|codes| mean", float(out["codes"].abs().mean()))
 
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
+    only = set(sys.argv[1:])          # optional: fixture names to (re)generate; default = all
+    for name in FIXTURES_BF16:
+        if not only or name in only:
+            gen_bf16_fixture(name)
     for name, (vd, nbit, nclass, b, cdim, batch, act) in FIXTURES.items():
+        if only and name not in only:
+            continue
         model = shim.build_reference_model(vd, nbit=nbit, nclass=nclass, adapter_bottleneck_dim=b, seed=7,
                                            center_dim=cdim, hidden_act=act)
         cfg = dict(D=vd["hidden_size"], L=vd["num_hidden_layers"], heads=vd["num_attention_heads"],
@@ -75,6 +142,8 @@ def main():
         print(name, "->", path, f"{os.path.getsize(path) / 1e6:.2f} MB",
               "codes", out["codes"].shape, "|codes| mean", float(out["codes"].abs().mean()))
 
+    if only and "cossim" not in only:
+        return
     # directly importable reference module (no shim needed): CosSim
     shim.install()
     from models.layers.cossim import CosSim  # unmodified reference source

@@ -25,4 +25,20 @@ def load_fixture(name):
     import torch
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    # "sdbf/..." = bf16 bit patterns (uint16) of tensors that are exactly bf16-representable (oracle/gen_golden.py)
+    sd.update({k[5:]: bf16_bits_to_f32(z[k]) for k in z.files if k.startswith("sdbf/")})
     return sd, z
+
+
+def bf16_bits_to_f32(a):
+    import numpy as np
+    import torch
+    return torch.from_numpy((a.astype(np.uint32) << 16).view(np.float32).copy())
+
+
+def fixture_images(z):
+    """input images of a fixture: fp32 ("in/images") or bf16 bit patterns ("inbf/images")"""
+    import torch
+    if "in/images" in z.files:
+        return torch.from_numpy(z["in/images"])
+    return bf16_bits_to_f32(z["inbf/images"])

@@ -3,11 +3,12 @@
 import numpy as np
 import torch
 
-from concepthash_amd.retrieval import ap_from_fixed, map_seg_rows, prepare_labels  # pure-torch host helpers
+from concepthash_amd.retrieval import (ap_from_fixed, map_seg_rows, normalize_limits, prepare_labels,  # pure-torch host helpers
+                                       summarize)
 from oracle import hamming_oracle as ho
 
-__all__ = ["hamming_topk", "topk_merge", "prepare_labels", "hamming_hist", "hist_prefix", "hamming_ap", "map_seg_rows",
-           "ap_from_fixed"]
+__all__ = ["hamming_topk", "topk_merge", "prepare_labels", "hamming_hist", "hist_prefix", "hamming_ap", "hamming_ap_multi",
+           "map_seg_rows", "ap_from_fixed", "normalize_limits", "summarize"]
 
 
 def _u(t):
@@ -94,3 +95,8 @@ def hamming_ap(q, g, q_lab, g_lab, LW, seg_rows, base, rank_limit=-1, first_rel=
                 S[i] += np.uint64((rr << 32) // rank)
                 nrel[i] += 1
     return torch.from_numpy(S.view(np.int64).copy()), torch.from_numpy(nrel)
+
+
+def hamming_ap_multi(q, g, q_lab, g_lab, LW, seg_rows, base, rank_limits, first_rel=None, stream=None):
+    outs = [hamming_ap(q, g, q_lab, g_lab, LW, seg_rows, base, rank_limit=int(r), first_rel=first_rel) for r in rank_limits]
+    return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])

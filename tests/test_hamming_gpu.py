@@ -201,3 +201,140 @@ def test_topk_large_gallery_with_heavy_ties(dev, nbit, k):
     ridx, rdst = ho.topk(q, g, k)
     assert np.array_equal(idx.cpu().numpy(), ridx)
     assert np.array_equal(dst.cpu().numpy(), rdst)
+
+
+# ---- round 2: NABirds size, reference-pinned distance / arg-min, one-pass multi-limit evaluation ----------------------------
+def _clustered(labels, centres, nbit, seed, flip=0.2):
+    rng = np.random.default_rng(seed)
+    bits = centres[labels] ^ (rng.random((len(labels), nbit)) < flip).astype(np.uint8)
+    return np.ascontiguousarray(np.packbits(bits, axis=1, bitorder="little")).view("<u8")
+
+
+def test_nabirds_sized_map_single_call_and_eight_way_shards(dev):
+    """BASELINE.json config 4: NABirds, 64-bit, 24,633 queries x 23,929 gallery rows, C = 555 (real label vectors,
+    tests/golden/labels_nabirds.npz).  mAP@all + P@k / R@k bit-exact vs the C oracle in a single call, and again with the
+    gallery split 8 ways (ragged shards) through per-shard histograms -> one global hist_prefix -> per-shard AP pass ->
+    integer sum, and per-shard top-k -> topk_merge -- the single-GPU data path of the 8-GPU layout."""
+    from concepthash_amd import retrieval as rt
+    from concepthash_amd.distributed import shard_bounds
+    from oracle import hamming_oracle as ho
+    z = np.load(os.path.join(GOLDEN, "labels_nabirds.npz"))
+    gl, ql = z["db"].astype(np.int32), z["test"].astype(np.int32)
+    assert (len(ql), len(gl)) == (24633, 23929)
+    C = int(max(gl.max(), ql.max())) + 1
+    assert C >= 555
+    centres = np.random.default_rng(17).integers(0, 2, size=(C, 64), dtype=np.uint8)
+    q, g = _clustered(ql, centres, 64, 1), _clustered(gl, centres, 64, 2)
+    ks = (1, 5, 10)
+    ref = ho.mean_ap(q, g, ql, gl, R=-1, ks=ks)
+    gq, gg, gql, ggl = _t(q, dev), _t(g, dev), _t(ql, dev), _t(gl, dev)
+    got = rt.evaluate(gq, gg, gql, ggl, R=-1, ks=ks)
+    assert np.array_equal(got["S"].cpu().numpy().view(np.uint64), ref["S"])
+    assert np.array_equal(got["nrel"].cpu().numpy().astype(np.uint32), ref["nrel"])
+    assert np.array_equal(got["hits"].cpu().numpy().astype(np.uint32), ref["hits"])
+    assert np.array_equal(got["total"].cpu().numpy().astype(np.uint32), ref["total"])
+    assert abs(got["mAP"] - ref["mAP"]) < 1e-12
+    print(f"nabirds: mAP@all {got['mAP']:.6f}, P@1/5/10 {got['precisions']}")
+    # ---- 8 ragged shards on one GPU
+    b = shard_bounds(len(gl), 8)
+    qlab, glab, LW = rt.prepare_labels(gql, ggl)
+    seg = rt.map_seg_rows(len(ql), max(b[i + 1] - b[i] for i in range(8)), 1)
+    nseg = max(1, -(-max(b[i + 1] - b[i] for i in range(8)) // seg))
+    hists = []
+    for r in range(8):
+        h = rt.hamming_hist(gq, gg[b[r]:b[r + 1]], qlab, glab[b[r]:b[r + 1]], LW, seg)
+        if h.shape[0] < nseg:
+            h = torch.cat([h, torch.zeros((nseg - h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype, device=dev)])
+        hists.append(h)
+    base_all, totals = rt.hist_prefix(torch.cat(hists))
+    limits, idx_of = rt.normalize_limits([-1] + list(ks))
+    S = torch.zeros(len(limits), len(ql), dtype=torch.int64, device=dev)
+    nrel = torch.zeros(len(limits), len(ql), dtype=torch.int32, device=dev)
+    for r in range(8):
+        s_r, n_r = rt.hamming_ap_multi(gq, gg[b[r]:b[r + 1]], qlab, glab[b[r]:b[r + 1]], LW, seg,
+                                       base_all[r * nseg:(r + 1) * nseg].contiguous(), limits)
+        S += s_r
+        nrel += n_r
+    assert np.array_equal(S[idx_of[0]].cpu().numpy().view(np.uint64), ref["S"])
+    assert np.array_equal(nrel[idx_of[0]].cpu().numpy().astype(np.uint32), ref["nrel"])
+    for t in range(len(ks)):
+        assert np.array_equal(nrel[idx_of[1 + t]].cpu().numpy().astype(np.uint32), ref["hits"][:, t])
+    assert np.array_equal(totals[:, 1].cpu().numpy().astype(np.uint32), ref["total"])
+    parts = [rt.hamming_topk(gq, gg[b[r]:b[r + 1]], 10, g_index_base=b[r]) for r in range(8)]
+    midx, mdst = rt.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    idx, dst = rt.hamming_topk(gq, gg, 10)
+    assert torch.equal(midx, idx) and torch.equal(mdst, dst)
+    ridx, rdst = ho.topk(q[:64], g, 10)
+    assert np.array_equal(idx[:64].cpu().numpy(), ridx.astype(np.int64)) and np.array_equal(dst[:64].cpu().numpy(), rdst)
+
+
+@pytest.mark.parametrize("nbit", [64, 128])
+def test_distance_argmin_top5_equal_the_reference_fixture(dev, nbit):
+    """tests/golden/get_hd.npz holds OUTPUTS OF THE REFERENCE: get_hd (trainers/orthohash.py:263-264) pair by pair, and the
+    arg-min / 5-smallest that calculate_accuracy_hamm_dist (utils/metrics.py:18-29) ranks by, on +-1 codes with engineered ties
+    (oracle/gen_retrieval_golden.py).  ch_hamming_dist / utils.hashing.get_hamm_dist reproduce the matrix exactly; arg-min and
+    the 5 smallest come out of ch_hamming_topk."""
+    from concepthash_amd import retrieval as rt
+    from utils import hashing
+    z = np.load(os.path.join(GOLDEN, "get_hd.npz"))
+    tag = f"b{nbit}/"
+    codes, cb = z[tag + "codes"].astype(np.float32), z[tag + "codebook"].astype(np.float32)
+    ref = z[tag + "get_hd"]
+    got = hashing.get_hamm_dist(torch.from_numpy(codes), torch.from_numpy(cb), normalize=True).cpu().numpy()
+    assert got.dtype == np.float32 and np.array_equal(got, ref)                     # k / nbit is exact in fp32
+    a, b = rt.pack_sign(torch.from_numpy(codes).to(dev)), rt.pack_sign(torch.from_numpy(cb).to(dev))
+    d = rt.hamming_dist(a, b).cpu().numpy()
+    assert np.array_equal(d, np.rint(ref * nbit).astype(np.int32))
+    idx, dst = rt.hamming_topk(a, b, 5)
+    idx, dst = idx.cpu().numpy(), dst.cpu().numpy()
+    assert np.array_equal(idx[:, 0], z[tag + "argmin"])                             # ties -> lowest index, as torch.argmin
+    assert ref[0, 0] == ref[0, 1] and idx[0, 0] == 0                                # the engineered tie is really there
+    ref5 = z[tag + "top5_smallest"]
+    assert np.array_equal(dst, np.rint(np.take_along_axis(ref, ref5, 1) * nbit).astype(np.int32))   # same 5 distances
+    for i in range(len(idx)):      # same 5 classes wherever no tie straddles the 5th place (torch.topk leaves tie order open)
+        kth = np.sort(d[i])[4]
+        if (d[i] == kth).sum() == (dst[i] == kth).sum():
+            assert set(idx[i]) == set(ref5[i]), i
+    labels = z[tag + "labels"]
+    assert np.float32((idx[:, 0] == labels).mean()) == z[tag + "acc_argmin"] == z[tag + "acc_argmin_onehot"]
+    assert np.float32((idx == labels[:, None]).any(1).mean()) == z[tag + "acc_top5"]
+
+
+def test_one_pass_multi_limit_evaluation(dev):
+    """mAP@R for a list of R, P@k / R@k for any k (also k > 128, the top-k kernel's list limit) and the P/R curve come out of
+    ONE histogram pass + ONE AP pass (16 rank limits per gallery scan).  Every entry equals the oracle run per limit."""
+    from concepthash_amd import retrieval as rt
+    from oracle import hamming_oracle as ho
+    from utils import hashing
+    q, ql = ho.synthetic_codes(333, 64, seed=61, nclass=7)
+    g, gl = ho.synthetic_codes(4000, 64, seed=62, nclass=7)
+    Rs = [1, 10, 100, 1000, -1]
+    ks = (1, 5, 10, 200, 1500, 5000)                         # 5000 > G
+    for remove_first in (False, True):
+        got = rt.evaluate(_t(q, dev), _t(g, dev), _t(ql, dev), _t(gl, dev), R=Rs, ks=ks, remove_first=remove_first)
+        for i, R in enumerate(Rs):
+            ref = ho.mean_ap(q, g, ql, gl, R=R, ks=ks, remove_first=remove_first)
+            assert np.array_equal(got["S"][i].cpu().numpy().view(np.uint64), ref["S"]), (R, remove_first)
+            assert np.array_equal(got["nrel"][i].cpu().numpy().astype(np.uint32), ref["nrel"])
+            assert abs(got["mAP"][i] - ref["mAP"]) < 1e-12
+        assert np.array_equal(got["hits"].cpu().numpy().astype(np.uint32), ref["hits"])
+        assert np.allclose(got["precisions"], ref["precisions"], atol=1e-12) and np.allclose(got["recalls"], ref["recalls"], atol=1e-12)
+    # 20 limits -> two AP passes of <= 16; the public wrappers
+    codes_q = np.where(np.unpackbits(q.view(np.uint8), axis=1, bitorder="little") > 0, 1.0, -1.0).astype(np.float32)
+    codes_g = np.where(np.unpackbits(g.view(np.uint8), axis=1, bitorder="little") > 0, 1.0, -1.0).astype(np.float32)
+    many = list(range(1, 4000, 211)) + [-1]
+    assert len(many) > 16
+    m, rec, prec = hashing.calculate_mAP(torch.from_numpy(codes_g), torch.from_numpy(gl), torch.from_numpy(codes_q),
+                                         torch.from_numpy(ql), many, PRs=[1, 300])
+    for R, v in zip(many, m):
+        assert abs(v - ho.mean_ap(q, g, ql, gl, R=R)["mAP"]) < 1e-12
+    refk = ho.mean_ap(q, g, ql, gl, R=-1, ks=(1, 300))
+    assert np.allclose(prec, refk["precisions"], atol=1e-12) and np.allclose(rec, refk["recalls"], atol=1e-12)
+    rc, pc, depths = hashing.calculate_pr_curve(torch.from_numpy(codes_g), torch.from_numpy(gl), torch.from_numpy(codes_q),
+                                                torch.from_numpy(ql))
+    assert depths[0] == 1 and depths[-1] == 4000
+    for R, r_, p_ in zip(depths, rc, pc):
+        refR = ho.mean_ap(q, g, ql, gl, R=R)
+        nr, tot = refR["nrel"].astype(np.float64), refR["total"].astype(np.float64)
+        assert abs(p_ - float((nr / R).mean())) < 1e-12
+        assert abs(r_ - float(np.where(tot > 0, nr / np.maximum(tot, 1), 0).mean())) < 1e-12

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_fixture
+from conftest import fixture_images, load_fixture
 from oracle import encoder_oracle as eo
 
 ATOL = 2e-5
@@ -25,6 +25,27 @@ def test_encode_matches_reference_outputs(name):
         ref = torch.from_numpy(z["out/" + key])
         assert torch.allclose(stages[st], ref, atol=ATOL, rtol=0), (key, float((stages[st] - ref).abs().max()))
     # the bits the retrieval path consumes are identical
+    assert bool(((out["codes"] > 0) == (torch.from_numpy(z["out/codes"]) > 0)).all())
+
+
+def test_encode_matches_reference_outputs_at_201_tokens():
+    """encode_n201: the reference model at image 224 / patch 16 (201 tokens), D = 256, bf16-representable weights and images
+    (models/arch/coop.py:524-598 run by oracle/gen_golden.py).  Same atol as the small fixtures."""
+    sd, z = load_fixture("encode_n201")
+    stages = {}
+    x = fixture_images(z)
+    assert x.shape == (2, 3, 224, 224)
+    out = eo.encode(sd, x, heads=int(z["meta/heads"]), upt_heads=int(z["meta/upt_heads"]), act=str(z["meta/act"]), stages=stages)
+    for key in ("codes", "hash_features", "logits_cont", "logits_bin", "logits_concept", "image_features"):
+        ref = torch.from_numpy(z["out/" + key])
+        assert out[key].shape == ref.shape, key
+        assert torch.allclose(out[key], ref, atol=ATOL, rtol=0), (key, float((out[key] - ref).abs().max()))
+    for key, st in (("h0", "h0"), ("h1", "h1"), ("h_last", "h2")):
+        ref = torch.from_numpy(z["out/" + key])
+        assert ref.shape == (2, 201, 256)
+        assert torch.allclose(stages[st], ref, atol=ATOL, rtol=0), (key, float((stages[st] - ref).abs().max()))
+    ca = stages["attn1"][:, :, -4:, 1:-4]
+    assert torch.allclose(ca, torch.from_numpy(z["out/concept_attn_last"]), atol=ATOL, rtol=0)
     assert bool(((out["codes"] > 0) == (torch.from_numpy(z["out/codes"]) > 0)).all())
 
 

@@ -1,0 +1,260 @@
+"""GPU parity, second tier: the evidence VERDICT.md (round 1) found missing.
+
+  (a) reference-generated fixture at 201 tokens that reaches the DISPATCHED kernels of the real configs (256x256 ping-pong
+      GEMM, KB = 7 attention with its masked tail, LN-fold chain, final-layer pruning);
+  (c) full depth: ViT-L/14 x 24 layers and ViT-S/16 x 12 layers against the fp32 oracle;
+  (d) batch-256 ViT-B/16 ch_encode: images of the big batch are bit-equal to an oracle-checked small batch;
+  (e) north-star number: |mAP@all(HIP codes) - mAP@all(fp32-oracle codes)| < 1e-3 on a labelled, class-structured set;
+  (f) outlier-heavy residual channels (x100, LayerNorm gamma to match) through 12 layers;
+  (g) the bound against the rounding-emulating oracle: measured against an oracle that rounds at the SAME points as the
+      default chain (emulate_fold) and against the one that rounds after the LayerNorm -- both sit at the same distance from
+      the HIP path as from each other (error-growth table): what is left is not the placement of the
+      rounding points but bf16 roundings that flip on 1e-6 differences in accumulation order, summed over ~9 rounded GEMM
+      outputs per layer.
+Errors are max-abs / RMS of the compared tensor unless stated; every measured value is printed.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import fixture_images, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a.double() - b.double()).abs().max() / b.double().pow(2).mean().sqrt().clamp_min(1e-12))
+
+
+def _rms_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a.double() - b.double()).pow(2).mean().sqrt() / b.double().pow(2).mean().sqrt().clamp_min(1e-12))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _encoder(sd, heads, **kw):
+    from concepthash_amd.encoder import ConceptHashEncoder
+    return ConceptHashEncoder(sd, heads=heads, **kw)
+
+
+# ---- (a) ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pp_min_k", [None, 256])
+def test_reference_golden_at_201_tokens(dev, monkeypatch, pp_min_k):
+    """tests/golden/encode_n201.npz = the reference's LGHWithFixedPrompt (models/arch/coop.py:524-598) at image 224 /
+    patch 16, D = 256, 4 heads, 2 layers, bf16-representable weights and images.  Default dispatch: patch-embed and fc2 on
+    the 256x256 ping-pong kernel, the K = 256 GEMMs on the 128x128 kernel; CH_GEMM_PP_MIN_K=256: every GEMM of the chain on
+    the ping-pong kernel (qkv / fc1 / down with the LN-fold epilogues, up with the residual + statistics epilogue)."""
+    from concepthash_amd import _lib
+    sd, z = load_fixture("encode_n201")
+    heads = int(z["meta/heads"])
+    if pp_min_k:
+        monkeypatch.setenv("CH_GEMM_PP_MIN_K", str(pp_min_k))
+    enc = _encoder(sd, heads, max_batch=2)
+    lib = _lib.load()
+    n_small0, n_pp0 = lib.ch_debug_gemm_dispatch_count(0), lib.ch_debug_gemm_dispatch_count(1)
+    x = fixture_images(z).to(dev)
+    want = ("codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features", "image_features", "concept_attn")
+    out = enc.encode(x, want=want)
+    torch.cuda.synchronize()
+    n_small, n_pp = lib.ch_debug_gemm_dispatch_count(0) - n_small0, lib.ch_debug_gemm_dispatch_count(1) - n_pp0
+    print(f"pp_min_k={pp_min_k}: {n_pp} GEMMs on the 256x256 ping-pong kernel, {n_small} on the 128x128 kernel")
+    assert n_pp + n_small == 1 + 2 * 8           # patch + 8 GEMMs per layer
+    if pp_min_k:
+        assert n_small == 0                      # the whole chain ran on the ping-pong kernel
+    else:
+        assert n_pp == 1 + 2 and n_small == 14   # patch (K = 768) + fc2 (K = 512) of both layers
+    for key, tol in (("codes", 2e-2), ("hash_features", 2e-2), ("logits_cont", 2e-2), ("logits_bin", 3e-2),
+                     ("logits_concept", 2e-2), ("image_features", 2e-2)):
+        got, ref = out[key].cpu(), torch.from_numpy(z["out/" + key])
+        e = _rel_err(got, ref)
+        print(f"n201 {key}: rel err vs reference golden {e:.2e}")
+        assert got.shape == ref.shape and e < tol, key
+    for layer, key, tol in ((0, "h0", 1e-2), (1, "h1", 2e-2), (2, "h_last", 2e-2)):
+        h = enc.hidden_states(x, layer).cpu()
+        e = _rel_err(h, torch.from_numpy(z["out/" + key]))
+        print(f"n201 hidden state after {layer} layers: {e:.2e}")
+        assert e < tol, key
+    # KB = 7 attention (201 keys padded to 224, boundary masking): the concept tokens' last-layer attention rows
+    ca, ref = out["concept_attn"].cpu(), torch.from_numpy(z["out/concept_attn_last"])
+    assert ca.shape == ref.shape == (2, heads, 4, 196)
+    assert float((ca - ref).abs().max()) < 2e-3 and torch.allclose(ca.sum(-1), ref.sum(-1), atol=2e-3)
+    from oracle import hamming_oracle as ho
+    assert np.array_equal(out["packed"].cpu().numpy().view(np.uint64), ho.pack(out["codes"].cpu().numpy()))
+    refc = torch.from_numpy(z["out/codes"])
+    flips = (out["codes"].cpu() > 0) != (refc > 0)
+    print(f"n201: {int(flips.sum())} / {flips.numel()} bits differ from the reference")
+    assert bool((refc[flips].abs() < 2e-2 * refc.pow(2).mean().sqrt()).all())
+
+
+# ---- (c) + (g) ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg_name,batch,nbit,nclass", [("vit_l14", 1, 128, 555), ("vit_s16", 2, 16, 200), ("vit_b16", 2, 64, 200)])
+def test_full_depth_against_fp32_and_fold_emulating_oracle(dev, cfg_name, batch, nbit, nclass):
+    """All layers of the BASELINE.json model sizes (L/14: 24, S/16: 12, B/16: 12).  Against the fp32 oracle: bf16 operand
+    rounding through every layer (bound 4e-2 max-abs / RMS, 1e-2 RMS / RMS).  Against the oracle that rounds at the SAME
+    points as the default chain (emulate_fold): 2.5e-2 max-abs / RMS and 6e-3 RMS / RMS -- measured 1.4e-2 / 3e-3 at 24
+    layers, the same as the distance between the two rounding-emulating oracles themselves (tools/error_growth.py)."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS[cfg_name])
+    sd = eo.synthetic_state_dict(cfg, nbit=nbit, nclass=nclass)
+    x = eo.synthetic_images(batch, cfg["image"])
+    enc = _encoder(sd, cfg["heads"], max_batch=2)
+    out = enc.encode(x.to(dev), want=("codes", "hash_features", "logits_cont"))
+    torch.cuda.synchronize()
+    ref = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False)
+    emu = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False, emulate_bf16=True, emulate_fold=True)
+    for key in ("codes", "hash_features", "logits_cont"):
+        got = out[key].cpu()
+        e_ref, e_emu, r_ref = _rel_err(got, ref[key]), _rel_err(got, emu[key]), _rms_err(got, ref[key])
+        print(f"{cfg_name} x {cfg['L']} layers, {key}: vs fp32 oracle {e_ref:.2e} (rms {r_ref:.2e}), "
+              f"vs fold-emulating oracle {e_emu:.2e}; emulating vs fp32 {_rel_err(emu[key], ref[key]):.2e}")
+        assert e_ref < 4e-2 and r_ref < 1e-2, key
+        assert e_emu < 2.5e-2 and _rms_err(got, emu[key]) < 6e-3, key
+    flips = (out["codes"].cpu() > 0) != (ref["codes"] > 0)
+    assert bool((ref["codes"][flips].abs() < 4e-2 * ref["codes"].pow(2).mean().sqrt()).all())
+
+
+# ---- (d) ---------------------------------------------------------------------------------------------------------
+def test_batch_256_rows_are_bit_equal_to_an_oracle_checked_small_batch(dev):
+    """ch_encode at the bench shape (ViT-B/16 x 12, batch 256: 201 row tiles, n-grouped tile order, 113 launches): the first,
+    middle and last image of the big batch equal, bit for bit, the same three images encoded as a batch of 3, and that small
+    batch is checked against the fp32 oracle."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_b16"])
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=200)
+    x = eo.synthetic_images(256, cfg["image"], seed=42)
+    pick = [0, 127, 255]
+    enc = _encoder(sd, cfg["heads"], max_batch=256)
+    want = ("codes", "packed", "logits_cont", "hash_features")
+    big = enc.encode(x.to(dev).to(torch.bfloat16), want=want)
+    small = enc.encode(x[pick].to(dev).to(torch.bfloat16), want=want)
+    torch.cuda.synchronize()
+    assert torch.isfinite(big["codes"]).all()
+    for k in want:
+        assert torch.equal(big[k][pick], small[k]), k
+    ref = eo.encode(sd, x[pick].to(torch.bfloat16).float(), heads=cfg["heads"], with_pooled=False)
+    e = _rel_err(small["codes"].cpu(), ref["codes"])
+    print(f"batch 256 vs batch 3: bit-equal; batch 3 vs fp32 oracle {e:.2e}")
+    assert e < 4e-2
+    # the batch is not 256 copies of one answer (seeded noise images through random weights still give many distinct codes)
+    assert len({tuple(r) for r in big["packed"].cpu().numpy().tolist()}) > 32
+
+
+# ---- (e) ---------------------------------------------------------------------------------------------------------
+def test_map_delta_and_bit_flip_rate_against_fp32_oracle_codes(dev):
+    """North-star tolerance (BASELINE.json): mAP@all of the HIP path's codes within 1e-3 of the fp32 reference restatement's
+    on identical inputs.  512 class-structured synthetic images (16 classes x 32: class prototype + noise), ViT-B/16 x 12
+    layers, 64-bit codes; first 128 images = queries, the other 384 = gallery; mAP from the integer oracle on both code sets.
+
+    Two heads on the same backbone, because what bf16 does to mAP is decided by how much pre-sign code mass sits at zero:
+      * "fitted": hash_fc + BatchNorm fitted (closed-form ridge regression on the GALLERY's fp32 hash features) so that each
+        concept's bits spell its class codeword -- what training does to the head (models/loss/coop.py quantisation terms push
+        |code| to 1).  This is the model the north-star number is about: |delta mAP@all| < 1e-3 is asserted.
+      * "random": the untrained head.  Its pre-sign codes are unimodal around zero -- the worst case for any reduced-precision
+        path (a bit flips wherever |code| < error) -- and its ranking is near chance level, so one flipped query bit reorders
+        half the gallery.  Reported, and bounded by what the measured flip rate explains."""
+    from oracle import encoder_oracle as eo
+    from oracle import hamming_oracle as ho
+    cfg = dict(eo.CONFIGS["vit_b16"])
+    ncls, per, nbit, Q = 16, 32, 64, 4
+    sd = eo.synthetic_state_dict(cfg, nbit=nbit, nclass=ncls)
+    g = torch.Generator().manual_seed(2024)
+    proto = torch.randn(ncls, 3, cfg["image"], cfg["image"], generator=g)
+    labels = torch.arange(ncls).repeat_interleave(per)
+    noise = torch.randn(ncls * per, 3, cfg["image"], cfg["image"], generator=g)
+    x = (0.8 * proto[labels] + 0.6 * noise).to(torch.bfloat16).float()
+    perm = torch.randperm(ncls * per, generator=g)
+    x, labels = x[perm], labels[perm]
+    lab = labels.numpy().astype(np.int32)
+    nq = 128
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    hf = torch.cat([eo.encode(sd, x[i:i + 32], heads=cfg["heads"], with_pooled=False)["hash_features"]
+                    for i in range(0, x.shape[0], 32)])                                   # fp32 oracle, [512, Q, D]
+
+    def measure(tag, sd_head):
+        enc = _encoder(sd_head, cfg["heads"], max_batch=256)
+        hip = enc.encode(x.to(dev), want=("codes",))["codes"].cpu()
+        torch.cuda.synchronize()
+        enc.close()
+        ref = eo.hash_head(sd_head, hf)            # the head of the fp32 oracle on its own hash features (coop.py:544-559)
+        flips = (hip > 0) != (ref > 0)
+        res = {}
+        for name, codes in (("hip", hip), ("fp32", ref)):
+            pk = ho.pack(codes.numpy())
+            res[name] = ho.mean_ap(pk[:nq], pk[nq:], lab[:nq], lab[nq:])["mAP"]
+        d = abs(res["hip"] - res["fp32"])
+        near0 = float((ref.abs() < 0.02 * ref.pow(2).mean().sqrt()).float().mean())
+        print(f"[{tag} head] mAP@all hip {res['hip']:.6f} vs fp32 oracle {res['fp32']:.6f}: |delta| {d:.2e}; bit-flip rate "
+              f"{float(flips.float().mean()):.3e} ({int(flips.sum())} / {flips.numel()}); codes rel err {_rel_err(hip, ref):.2e}; "
+              f"fraction of fp32 codes within 2 % of zero {near0:.2e}")
+        assert bool((ref[flips].abs() < 4e-2 * ref.pow(2).mean().sqrt()).all())   # only bits inside the error band flip
+        return d, res["fp32"], float(flips.float().mean())
+
+    # ---- fitted head: ridge regression of the class codewords on the gallery's (hash_features + hash_pe), shared hash_fc
+    code_g = torch.Generator().manual_seed(7)
+    codeword = torch.randn(ncls, nbit, generator=code_g).sign()
+    feats = (hf + sd["hash_pe"].float())[nq:].reshape(-1, cfg["D"]).double()                              # [(384*Q), D]
+    target = codeword[labels[nq:]].reshape(-1, Q, nbit // Q).reshape(-1, nbit // Q).double()              # concept-major bits
+    mu = feats.mean(0, keepdim=True)
+    A = feats - mu
+    lam = 0.1 * float(A.pow(2).sum()) / cfg["D"]                     # 10 % of the mean diagonal of A^T A
+    Wt = torch.linalg.solve(A.t() @ A + lam * torch.eye(cfg["D"], dtype=torch.float64), A.t() @ (target - target.mean(0, keepdim=True)))
+    sd_fit = dict(sd)
+    sd_fit["hash_fc.weight"] = Wt.t().float().contiguous()                                               # [nbit/Q, D]
+    v = ((hf + sd["hash_pe"].float()) @ sd_fit["hash_fc.weight"].t()).reshape(hf.shape[0], -1)[nq:]      # pre-BN, gallery
+    sd_fit["hash_bn.running_mean"] = v.mean(0)
+    sd_fit["hash_bn.running_var"] = v.var(0, unbiased=False)
+    sd_fit["hash_bn.weight"] = torch.ones(nbit)
+    sd_fit["hash_bn.bias"] = torch.zeros(nbit)
+    d_fit, map_fit, rate_fit = measure("fitted", sd_fit)
+    assert map_fit > 0.5                       # the fitted head retrieves by class on held-out queries
+    assert d_fit < 1e-3                        # the north-star bound
+    d_rnd, map_rnd, rate_rnd = measure("random", sd)
+    assert 1.0 / ncls < map_rnd < 1.0
+    assert rate_rnd < 5e-3 and d_rnd < 2e-2    # unsaturated codes at near-chance ranking: reported worst case, loosely bounded
+
+
+# ---- (f) ---------------------------------------------------------------------------------------------------------
+def test_outlier_residual_channels_through_full_depth(dev):
+    """Real CLIP towers carry a few residual channels two orders of magnitude above the rest.  Here 6 channels of the
+    residual stream are driven x100 (pre-LN gamma, the rows of out_proj / fc2 / up_proj that write them) with the LayerNorm
+    gammas of every consumer set to 1/100 on those channels, through 12 ViT-B/16 layers: the single-pass folded statistics
+    (E[x^2] - mean^2 in fp32 on the raw bf16 rows) stay within the encode tolerance of the fp32 oracle."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_b16"])
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    VM = "backbone.vision_model."
+    ch = torch.tensor([5, 77, 200, 391, 512, 760])
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd[VM + "pre_layrnorm.weight"][ch] *= 100.0
+    for i in range(cfg["L"]):
+        pre = VM + f"encoder.layers.{i}."
+        for name in ("self_attn.out_proj", "mlp.fc2", "adapt_mlp_1.up_proj", "adapt_mlp_2.up_proj"):
+            sd[pre + name + ".weight"][ch, :] *= 100.0
+            sd[pre + name + ".bias"][ch] *= 100.0
+        for name in ("layer_norm1", "layer_norm2", "adapt_mlp_1.adapter_layer_norm", "adapt_mlp_2.adapter_layer_norm"):
+            sd[pre + name + ".weight"][ch] *= 0.01
+    sd["hash_fc.weight"][:, ch] *= 0.01
+    x = eo.synthetic_images(2, cfg["image"])
+    st = {}
+    ref = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False, stages=st)
+    hl = st[f"h{cfg['L']}"]
+    ratio = float(hl[..., ch].abs().mean() / hl.abs().mean())
+    print(f"outlier channels carry {ratio:.1f}x the mean magnitude of the final residual stream")
+    assert ratio > 15
+    enc = _encoder(sd, cfg["heads"], max_batch=2)
+    out = enc.encode(x.to(dev), want=("codes", "hash_features"))
+    hid = enc.hidden_states(x.to(dev), cfg["L"]).cpu()
+    torch.cuda.synchronize()
+    e_codes, r_codes = _rel_err(out["codes"].cpu(), ref["codes"]), _rms_err(out["codes"].cpu(), ref["codes"])
+    keep = torch.ones(cfg["D"], dtype=torch.bool)
+    keep[ch] = False
+    e_rest = _rel_err(hid[..., keep], hl[..., keep])
+    e_out = _rel_err(hid[..., ch], hl[..., ch])          # max-abs error / RMS of the outlier channels themselves
+    print(f"outlier weights: codes {e_codes:.2e} (rms {r_codes:.2e}); final residual, ordinary channels {e_rest:.2e}, "
+          f"outlier channels {e_out:.2e}")
+    assert e_codes < 4e-2 and r_codes < 1e-2
+    assert e_rest < 4e-2 and e_out < 4e-2

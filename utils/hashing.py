@@ -61,19 +61,16 @@ def _evaluate(db_codes, db_labels, test_codes, test_labels, R, ks, remove_first)
 def calculate_mAP(db_codes, db_labels, test_codes, test_labels, R, threshold=0., dist_metric="hamming", PRs=None,
                   remove_first_retrieved=False, landmark_gt=None, db_id=None, test_id=None, multiclass=False):
     """-> (mAP, recalls, precisions); `mAP` is a list when `R` is a list (experiments/test_hashing.py:124-128).
-    R <= 0 means the whole database."""
+    R <= 0 means the whole database.  One histogram pass + one AP pass whatever the length of R and PRs: every R and every k
+    is a rank limit of the same gallery scan."""
     _check(dist_metric, threshold, landmark_gt)
     ks = [int(k) for k in (PRs or [])]
-    Rs = list(R) if isinstance(R, (list, tuple)) or (hasattr(R, "__iter__") and not isinstance(R, (int, float))) else None
-    if Rs is None:
-        res = _evaluate(db_codes, db_labels, test_codes, test_labels, int(R), ks, remove_first_retrieved)
-        return res["mAP"], res["recalls"], res["precisions"]
-    out: List[float] = []
-    res = None
-    for r in Rs:
-        res = _evaluate(db_codes, db_labels, test_codes, test_labels, int(r), ks, remove_first_retrieved)
-        out.append(res["mAP"])
-    return out, (res["recalls"] if res else []), (res["precisions"] if res else [])
+    many = isinstance(R, (list, tuple)) or (hasattr(R, "__iter__") and not isinstance(R, (int, float)))
+    Rs = [int(r) for r in R] if many else int(R)
+    if many and not Rs:
+        return [], [], []
+    res = _evaluate(db_codes, db_labels, test_codes, test_labels, Rs, ks, remove_first_retrieved)
+    return res["mAP"], res["recalls"], res["precisions"]
 
 
 def pr_curve_points(n_db: int) -> List[int]:
@@ -92,14 +89,17 @@ def pr_curve_points(n_db: int) -> List[int]:
 def calculate_pr_curve(db_codes, db_labels, test_codes, test_labels, threshold=0., dist_metric="hamming",
                        remove_first_retrieved=False, Rs: Sequence[int] = None):
     """-> (recalls, precisions, Rs): mean precision / recall at each retrieval depth R (experiments/test_hashing.py:153-167).
-    #relevant-in-top-R comes from the exact rank computation of the AP pass with `rank_limit = R`."""
+    Every depth is a rank limit of ONE AP pass (16 limits per gallery scan): #relevant-in-top-R is that limit's `nrel`."""
     _check(dist_metric, threshold, None)
     n = db_codes.shape[0] - (1 if remove_first_retrieved else 0)
     Rs = [int(r) for r in (Rs if Rs is not None else pr_curve_points(max(n, 1)))]
+    if not Rs:
+        return [], [], []
+    res = _evaluate(db_codes, db_labels, test_codes, test_labels, Rs, [], remove_first_retrieved)
+    total = res["total"].double()
     recalls, precisions = [], []
-    for r in Rs:
-        res = _evaluate(db_codes, db_labels, test_codes, test_labels, r, [], remove_first_retrieved)
-        nrel, total = res["nrel"].double(), res["total"].double()
+    for r, nrel in zip(Rs, res["nrel"]):
+        nrel = nrel.double()
         precisions.append(float((nrel / r).mean().item()) if nrel.numel() else 0.0)
         recalls.append(float(torch.where(total > 0, nrel / total.clamp_min(1), torch.zeros_like(nrel)).mean().item())
                        if nrel.numel() else 0.0)
