@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ConceptHash encode-and-retrieve benchmark (BASELINE.json metric), one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without WORLD_SIZE: starts its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One STEP (per rank) = the hot path over one batch of synthetic input already resident in HBM:
@@ -12,23 +12,27 @@ One STEP (per rank) = the hot path over one batch of synthetic input already res
 Encode shards by image (no collective); retrieval shards the gallery by rows.  `value` is whole-job
 images/s = N * 256 * K / max-over-ranks time.  Weak scaling: per-rank batch and per-rank gallery shard are fixed.
 
-Also reported (outside the timed region, same process): the Hamming scan on the 1M x 128-bit synthetic gallery
-(BASELINE.json config 5 size), and -- rank 0, N == 1 only -- the CPU baseline: the oracle (PyTorch fp32 restatement of
-the reference forward + the C Hamming oracle) on a bounded sample of the same workload.
+`value` is measured in the library's default launch mode: the batch as TWO micro-batches whose launch chains run on two HIP
+streams (bit-identical codes; `--streams 1` = one chain).  Per-kernel durations stop describing single kernels once launches
+overlap, so the `roofline` numbers come from a second, single-stream pass of the same K steps (HIP events on the launch stream
+around every launch), run right after the timed region; `roofline_pass` says so and gives that pass's ms/step.
+
+Also reported (outside the timed region, same process): the Hamming scan and mAP@all on the 1M x 128-bit synthetic gallery
+(BASELINE.json config 5 size; N > 1: the gallery sharded by rows across the ranks) and at the NABirds / CUB sizes, and --
+rank 0, N == 1 only -- the CPU baselines on the host cores, on bounded samples of the same workloads.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
@@ -43,21 +47,59 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="vit_b16")
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--streams", type=int, default=1, help="2: two micro-batches on two HIP streams (DESIGN.md section 3)")
-    ap.add_argument("--report-two-streams", action="store_true",
-                    help="also time the optional two-stream mode after the timed region (extra launches: keep it out of profiled runs)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="micro-batch launch chains on separate HIP streams (library default 2; 1 = a single chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming-scan", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-roofline-pass", action="store_true", help="skip the single-stream profiled pass")
+    return ap.parse_args()
 
-    os.environ["CH_STREAMS"] = str(args.streams)
+
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no launcher environment starts N fresh ranks BEFORE any GPU call
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    import torch   # device_count() does not initialise the GPU on this image; nothing else of torch.cuda is touched here
+    ndev = torch.cuda.device_count()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ndev < args.gpus and "BENCH_BACKEND" not in env:
+        log(f"[bench] {args.gpus} ranks requested but {ndev} GPU(s) visible: REHEARSAL -- ranks share GPUs, collectives over gloo")
+        env["BENCH_BACKEND"] = "gloo"
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        log(f"[bench] ranks failed: {bad}")
+        return 1
+    return 0
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import numpy as np
+    import torch
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -87,6 +129,7 @@ def main():
     t_setup = time.perf_counter()
     sd = syn.synthetic_state_dict(cfg, nbit=NBIT, nclass=NCLASS, seed=42)
     log(f"[bench r{rank}] synthetic weights ready ({time.perf_counter() - t_setup:.1f} s)")
+    os.environ["CH_STREAMS"] = str(args.streams)
     enc = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=B, device=dev)
     log(f"[bench r{rank}] model on device: {enc.device_bytes / 2**20:.0f} MiB ({time.perf_counter() - t_setup:.1f} s)")
     images = syn.synthetic_images(B, cfg["image"], seed=42 + rank).to(dev).to(torch.bfloat16)
@@ -94,23 +137,26 @@ def main():
     gallery = torch.from_numpy(g_np.view(np.int64)).to(dev)
     W = gallery.shape[1]
 
-    def step():
-        out = enc.encode(images, want=("codes", "packed"))
-        q = out["packed"]
-        if world > 1:
-            allq = torch.empty(world * B, W, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allq, q)
-            q = allq
-        idx, dst = rt.hamming_topk(q, gallery, TOPK, g_index_base=rank * GALLERY_ROWS)
-        if world > 1:
-            nq = q.shape[0]        # output = concatenation along dim 0 (the form every backend accepts), viewed per shard
-            li = torch.empty(world * nq, TOPK, dtype=torch.int64, device=dev)
-            ld = torch.empty(world * nq, TOPK, dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(li, idx)
-            dist.all_gather_into_tensor(ld, dst)
-            idx, dst = rt.topk_merge(li.view(world, nq, TOPK), ld.view(world, nq, TOPK))
-        return out["codes"], idx, dst
+    def make_step(encoder):
+        def step():
+            out = encoder.encode(images, want=("codes", "packed"))
+            q = out["packed"]
+            if world > 1:
+                allq = torch.empty(world * B, W, dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(allq, q)
+                q = allq
+            idx, dst = rt.hamming_topk(q, gallery, TOPK, g_index_base=rank * GALLERY_ROWS)
+            if world > 1:
+                nq = q.shape[0]        # output = concatenation along dim 0 (the form every backend accepts), viewed per shard
+                li = torch.empty(world * nq, TOPK, dtype=torch.int64, device=dev)
+                ld = torch.empty(world * nq, TOPK, dtype=torch.int32, device=dev)
+                dist.all_gather_into_tensor(li, idx)
+                dist.all_gather_into_tensor(ld, dst)
+                idx, dst = rt.topk_merge(li.view(world, nq, TOPK), ld.view(world, nq, TOPK))
+            return out["codes"], idx, dst
+        return step
 
+    step = make_step(enc)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -118,7 +164,6 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    enc.profile_begin(args.steps * (enc.launches_per_encode + 2) + 8)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         codes, idx, dst = step()
@@ -127,7 +172,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof = enc.profile_end()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -135,55 +179,33 @@ def main():
     assert torch.isfinite(codes).all()
     log(f"[bench r{rank}] timed region: {args.steps} steps in {elapsed:.3f} s")
 
+    # ---- roofline pass: the same K steps as ONE launch chain on one stream, every launch bracketed by HIP events ----------
+    prof, prof_ms_per_step, codes_same = None, None, None
+    if not args.no_roofline_pass:
+        if args.streams == 1:
+            enc1 = enc
+        else:
+            os.environ["CH_STREAMS"] = "1"
+            enc1 = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=B, device=dev)
+            os.environ["CH_STREAMS"] = str(args.streams)
+        step1 = make_step(enc1)
+        c1 = step1()[0]
+        codes_same = bool(torch.equal(c1, codes))     # micro-batching never changes a bit
+        torch.cuda.synchronize()
+        enc1.profile_begin(args.steps * (enc1.launches_per_encode + 2) + 8)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step1()
+        torch.cuda.synchronize()
+        prof_ms_per_step = (time.perf_counter() - t0) / args.steps * 1e3
+        prof = enc1.profile_end()
+        if enc1 is not enc:
+            enc1.close()
+
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        gemm_cats = [c for c in prof if c.startswith("gemm_")]
-        gemm_ms = sum(prof[c]["ms"] for c in gemm_cats)
-        gemm_flops = sum(prof[c]["flops"] for c in gemm_cats)
-        gemm_launches = sum(prof[c]["launches"] for c in gemm_cats)
-        achieved_all = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        total_ms = sum(p["ms"] for p in prof.values())
-        traffic_tab = {}
-        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic_tab = json.load(open(tpath)).get("per_kernel", {})
-            except Exception:
-                traffic_tab = {}
-        # kernel instances as rocprofv3 names them (default chain, LayerNorm folded): (label, rocprof name, launch categories)
-        rows_tok = B * enc.ntok
-        D_, b_pad = enc.cfg["dim"], (enc.cfg["adapter_dim"] + 127) // 128 * 128
-        up_bytes = rows_tok * (D_ * 4 * 2 + D_ * 2 * 2 + b_pad * 2) + D_ * b_pad * 2      # fp32 RMW + bf16 addend + bf16 copy + X, W
-        down_bytes = rows_tok * (D_ * 2 + b_pad * 2) + D_ * b_pad * 2
-        instances = [
-            ("gemm_pp_kernel<EPI_BIAS_STATS> (out_proj + fc2, 256x256 ping-pong)", "gemm_pp_kernel<6, 0>", ["gemm_out", "gemm_fc2"], None),
-            ("gemm_pp_kernel<EPI_FOLD_QUICKGELU> (fc1)", "gemm_pp_kernel<9, 0>", ["gemm_fc1"], None),
-            ("gemm_pp_kernel<EPI_FOLD_BIAS> (qkv)", "gemm_pp_kernel<8, 0>", ["gemm_qkv"], None),
-            ("gemm_bf16_kernel<EPI_SCALE_RESID_STATS> (adapter up, 128x128)", "gemm_bf16_kernel<7>", ["gemm_up"], up_bytes),
-            ("gemm_bf16_kernel<EPI_FOLD_GELU> (adapter down, 128x128)", "gemm_bf16_kernel<10>", ["gemm_down"], down_bytes),
-        ]
-        per_kernel = []
-        for label, rname, cats, hbm_bytes in instances:
-            ms = sum(prof[c]["ms"] for c in cats if c in prof)
-            n = sum(prof[c]["launches"] for c in cats if c in prof)
-            fl = sum(prof[c]["flops"] for c in cats if c in prof)
-            if n == 0 or ms <= 0:
-                continue
-            tf = fl / (ms * 1e-3) / 1e12
-            row = {"kernel": label, "rocprof_name": rname, "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS,
-                   "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3 / n, 2),
-                   "launches_per_step": n // max(1, args.steps), "ms_per_step": round(ms / args.steps, 3),
-                   "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
-                   "traffic": traffic_tab.get(rname, {}).get("hbm_bytes_per_launch")}
-            if hbm_bytes is not None:   # short-K adapter GEMMs: priced against HBM (algorithmic bytes per launch / duration)
-                gbs = hbm_bytes / (ms * 1e-3 / n) / 1e9
-                row.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(hbm_bytes),
-                            "tflops": round(tf, 2)})
-            per_kernel.append(row)
-        dominant = max(per_kernel, key=lambda r: r["ms_per_step"]) if per_kernel else None
         result = {
             "metric": "images/s encode (ViT+hash) + Hamming top-10 retrieval, CUB-200 64-bit",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,183 +217,331 @@ def main():
                        "hip_streams": args.streams,
                        "parallelism": f"images x{world} (no collective), gallery rows x{world} (RCCL all_gather of packed "
                                       f"queries + lists)" if world > 1 else "single GPU"},
-            # dominant kernel = the instance with the most time per step (first row of profiles/*_kernel_stats.csv)
-            "roofline": ({k: dominant[k] for k in ("bound", "kernel", "rocprof_name", "achieved", "peak", "unit", "frac", "traffic",
-                                                   "avg_launch_us", "launches_per_step", "algorithmic_gflop_per_launch")}
-                         if dominant else None),
-            "roofline_per_kernel": per_kernel,
-            "roofline_all_gemm_launches": {"bound": "mfma", "achieved": round(achieved_all, 2), "peak": PEAK_BF16_TFLOPS,
-                                           "unit": "TFLOP/s", "frac": round(achieved_all / PEAK_BF16_TFLOPS, 4),
-                                           "avg_launch_us": round(gemm_ms * 1e3 / max(1, gemm_launches), 2),
-                                           "launches_per_step": gemm_launches // max(1, args.steps),
-                                           "algorithmic_gflop_per_step": round(gemm_flops / max(1, args.steps) / 1e9, 2),
-                                           "note": "every GEMM launch of the step, HBM-bound adapter projections included"},
             "encode_tflops_end_to_end": round(enc.flops_per_image * B / (ms_per_step * 1e-3) / 1e12, 2),
-            "kernel_ms_per_step": {c: round(p["ms"] / args.steps, 4) for c, p in prof.items()},
-            "kernel_ms_per_step_total": round(total_ms / args.steps, 3),
+            "encode_mfma_frac_end_to_end": round(enc.flops_per_image * B / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         }
+        if prof is not None:
+            result.update(roofline_block(prof, args, enc, B, prof_ms_per_step, codes_same))
 
     # ---- PCIe-inclusive variant (outside the timed region): the same step fed from pinned host memory each time -----
     if rank == 0:
-        host = images.cpu().pin_memory()
-        dev_in = torch.empty_like(images)
+        result["pcie_inclusive"] = pcie_block(torch, enc, images, B)
 
-        def step_h2d():
-            dev_in.copy_(host, non_blocking=True)
-            return enc.encode(dev_in, want=("codes", "packed"))
+    # ---- Hamming blocks (outside the timed region) -------------------------------------------------------------------
+    if not args.no_hamming_scan:
+        hb = hamming_block(torch, np, rt, syn, dist, dev, rank, world)
+        if rank == 0:
+            result["hamming"] = hb
 
-        step_h2d()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            step_h2d()
-        torch.cuda.synchronize()
-        pcie_s = (time.perf_counter() - t0) / 5
-        # double-buffered feed: the copy of batch i+1 runs on a side stream while batch i is encoded
-        bufs = [dev_in, torch.empty_like(images)]
-        copy_stream = torch.cuda.Stream(device=dev)
-        ready = [torch.cuda.Event(), torch.cuda.Event()]      # copy into buffer j finished
-        freed = [torch.cuda.Event(), torch.cuda.Event()]      # encode of buffer j finished (it may be overwritten)
-        main = torch.cuda.current_stream(dev)
-        for e in freed:
-            e.record(main)
-
-        def feed(j):
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(freed[j])
-                bufs[j].copy_(host, non_blocking=True)
-                ready[j].record(copy_stream)
-
-        nrep = 8
-        feed(0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(nrep):
-            j = i & 1
-            if i + 1 < nrep:
-                feed(j ^ 1)
-            main.wait_event(ready[j])
-            enc.encode(bufs[j], want=("codes", "packed"))
-            freed[j].record(main)
-        torch.cuda.synchronize()
-        pipe_s = (time.perf_counter() - t0) / nrep
-        result["pcie_inclusive"] = {"images_per_s": round(B / pcie_s, 1), "ms_per_step": round(pcie_s * 1e3, 3),
-                                    "note": f"encode only, batch copied from pinned host memory every step on the same stream "
-                                            f"({host.numel() * 2 / 2**20:.0f} MiB bf16, no overlap); never used for `value`",
-                                    "double_buffered": {"images_per_s": round(B / pipe_s, 1), "ms_per_step": round(pipe_s * 1e3, 3),
-                                                        "note": "copy of batch i+1 on a side stream under the encode of batch i"}}
-        del bufs
-        del host, dev_in
-
-    # ---- optional two-stream mode (outside the timed region): same step, two micro-batches on two HIP streams ---------
-    if rank == 0 and world == 1 and args.streams == 1 and args.report_two_streams:
-        os.environ["CH_STREAMS"] = "2"
-        enc2 = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=B, device=dev)
-        os.environ["CH_STREAMS"] = "1"
-        c1 = enc.encode(images, want=("codes", "packed"))
-        c2 = enc2.encode(images, want=("codes", "packed"))
-        same = bool(torch.equal(c1["codes"], c2["codes"]) and torch.equal(c1["packed"], c2["packed"]))
-        for _ in range(2):
-            enc2.encode(images, want=("codes", "packed"))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            o2 = enc2.encode(images, want=("codes", "packed"))
-            rt.hamming_topk(o2["packed"], gallery, TOPK)
-        torch.cuda.synchronize()
-        s2 = (time.perf_counter() - t0) / 10
-        result["two_streams"] = {"images_per_s": round(B / s2, 1), "ms_per_step": round(s2 * 1e3, 3), "codes_identical": same,
-                                 "note": "CH_STREAMS=2 / --streams 2: the tile-quantisation tails of one micro-batch's launches are "
-                                         "filled by the other's; not the default because per-launch durations (the roofline above) "
-                                         "stop describing single kernels once launches overlap; never used for `value`"}
-        enc2.close()
-        del enc2
-
-    # ---- Hamming scan at BASELINE config-5 size (outside the timed region; per rank, reported by rank 0) -----------
-    if rank == 0 and not args.no_hamming_scan:
-        G5, Q5, NB5 = 1_000_000, 16384, 128
-        g5 = torch.randint(-2 ** 63, 2 ** 63 - 1, (G5, NB5 // 64), dtype=torch.int64, device=dev)
-        q5 = torch.randint(-2 ** 63, 2 ** 63 - 1, (Q5, NB5 // 64), dtype=torch.int64, device=dev)
-        rt.hamming_topk(q5, g5, TOPK)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
-        e0.record()
-        for _ in range(reps):
-            rt.hamming_topk(q5, g5, TOPK)
-        e1.record()
-        torch.cuda.synchronize()
-        sec = e0.elapsed_time(e1) * 1e-3 / reps
-        log(f"[bench] hamming scan {Q5} x {G5} x {NB5} b: {sec * 1e3:.2f} ms")
-        tq = 256
-        alg_bytes = -(-Q5 // tq) * G5 * (NB5 // 64) * 8 + Q5 * ((NB5 // 64) + TOPK) * 8
-        result["hamming"] = {
-            "workload": f"{Q5} queries x {G5} gallery rows x {NB5} bit, exact top-{TOPK}, 1 GPU",
-            "queries_per_s": round(Q5 / sec, 1), "comparisons_per_s": float(f"{Q5 * G5 / sec:.4g}"),
-            "ms": round(sec * 1e3, 3),
-            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / sec / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(alg_bytes / sec / 1e9 / PEAK_HBM_GBS, 5), "traffic": None,
-                         "note": "algorithmic bytes = ceil(Qn/256)*G*W*8 + Qn*(W+k)*8; the scan is VALU-bound "
-                                 "(xor+popcount+select), see DESIGN.md"},
-            # the bound that applies (PMC-backed): 9.75 integer VALU instructions per 128-bit pair at
-            # 4 cycles per wave64 instruction on 1024 SIMDs at 2.4 GHz, insertion passes not counted
-            "valu_ceiling_comparisons_per_s": 4.0e12, "valu_frac": round(Q5 * G5 / sec / 4.0e12, 4),
-        }
-        del g5, q5
-        # mAP@all + P@k/R@k at the CUB-200 size (5,794 queries x 5,994 gallery rows x 64 bit, real class-count statistics)
-        qn_np, ql_np = syn.synthetic_codes(5794, NBIT, seed=77, nclass=NCLASS)
-        qn = torch.from_numpy(qn_np.view(np.int64)).to(dev)
-        qlab, glab = torch.from_numpy(ql_np).to(dev), torch.from_numpy(gl_np).to(dev)
-        rt.evaluate(qn, gallery, qlab, glab)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            ev = rt.evaluate(qn, gallery, qlab, glab)
-        torch.cuda.synchronize()
-        ev_s = (time.perf_counter() - t0) / 5
-        result["hamming"]["map_eval"] = {"workload": "mAP@all + P/R@{1,5,10}: 5794 queries x 5994 gallery rows x 64 bit, 200 classes",
-                                         "ms": round(ev_s * 1e3, 3), "queries_per_s": round(5794 / ev_s, 1),
-                                         "mAP": round(ev["mAP"], 6)}
-
-    # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N == 1 only) ---------------------------------
+    # ---- CPU baselines: oracle on the host cores, bounded samples (rank 0, N == 1 only) -------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import encoder_oracle as eo     # the ONLY use of oracle/ in this file: the CPU baseline being timed
-        from oracle import hamming_oracle as ho
-        # the box exposes all host cores to os.cpu_count() but grants a CPU share: use the affinity mask, capped at 16
-        cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-        torch.set_num_threads(cores)
-        bs = 8
-        x = syn.synthetic_images(bs, cfg["image"], seed=42)
-        eo.encode(sd, x[:1], heads=cfg["heads"], with_pooled=False)  # warm-up
-        log(f"[bench] cpu baseline: {cores} threads, warm-up done")
-        t0 = time.perf_counter()
-        nb = 0
-        while nb < BATCH // bs and (nb == 0 or time.perf_counter() - t0 < 12.0):   # 10-30 s of CPU work, at most one bench batch
-            c = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False)["codes"]
-            pk = ho.pack(c.numpy())
-            ho.topk(pk, g_np, TOPK)
-            nb += 1
-            log(f"[bench] cpu baseline batch {nb}: {time.perf_counter() - t0:.1f} s")
-        cpu_s = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": round(nb * bs / cpu_s, 2), "unit": "images/s", "cores": cores, "kind": "port",
-                                  "sample": f"{nb} batches of {bs} images: oracle/encoder_oracle.py (PyTorch CPU fp32 "
-                                            f"restatement of the reference forward) + oracle/hamming_oracle.c pack + "
-                                            f"top-{TOPK} vs the same {GALLERY_ROWS}-row gallery; {cpu_s:.1f} s"}
-        nhq = 4096
-        hq, hg = syn.synthetic_codes(nhq, 128, seed=1)[0], syn.synthetic_codes(1_000_000, 128, seed=2)[0]
-        log("[bench] cpu hamming baseline inputs ready")
-        t0 = time.perf_counter()
-        ho.bench_topk(hq, hg, TOPK)
-        hs = time.perf_counter() - t0
-        result["cpu_baseline_hamming"] = {"value": float(f"{nhq * 1_000_000 / hs:.4g}"), "unit": "comparisons/s", "cores": 1,
-                                          "kind": "port", "sample": f"{nhq} queries x 1M x 128 bit, C oracle (popcount + "
-                                                                    f"counting-sort ranking), {hs:.1f} s"}
+        result.update(cpu_baselines(torch, np, syn, sd, cfg, g_np))
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_block(prof, args, enc, B, prof_ms_per_step, codes_same):
+    gemm_cats = [c for c in prof if c.startswith("gemm_")]
+    gemm_ms = sum(prof[c]["ms"] for c in gemm_cats)
+    gemm_flops = sum(prof[c]["flops"] for c in gemm_cats)
+    gemm_launches = sum(prof[c]["launches"] for c in gemm_cats)
+    achieved_all = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    total_ms = sum(p["ms"] for p in prof.values())
+    traffic_tab = {}
+    tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic_tab = json.load(open(tpath)).get("per_kernel", {})
+        except Exception:
+            traffic_tab = {}
+    # kernel instances as rocprofv3 names them (default chain, LayerNorm folded): (label, rocprof name, launch categories)
+    rows_tok = B * enc.ntok
+    D_, b_pad = enc.cfg["dim"], (enc.cfg["adapter_dim"] + 127) // 128 * 128
+    up_bytes = rows_tok * (D_ * 4 * 2 + D_ * 2 * 2 + b_pad * 2) + D_ * b_pad * 2      # fp32 RMW + bf16 addend + bf16 copy + X, W
+    down_bytes = rows_tok * (D_ * 2 + b_pad * 2) + D_ * b_pad * 2
+    instances = [
+        ("gemm_pp_kernel<EPI_BIAS_STATS> (out_proj + fc2, 256x256 ping-pong)", "gemm_pp_kernel<6, 0>", ["gemm_out", "gemm_fc2"], None),
+        ("gemm_pp_kernel<EPI_FOLD_QUICKGELU> (fc1)", "gemm_pp_kernel<9, 0>", ["gemm_fc1"], None),
+        ("gemm_pp_kernel<EPI_FOLD_BIAS> (qkv)", "gemm_pp_kernel<8, 0>", ["gemm_qkv"], None),
+        ("gemm_bf16_kernel<EPI_SCALE_RESID_STATS> (adapter up, 128x128)", "gemm_bf16_kernel<7>", ["gemm_up"], up_bytes),
+        ("gemm_bf16_kernel<EPI_FOLD_GELU> (adapter down, 128x128)", "gemm_bf16_kernel<10>", ["gemm_down"], down_bytes),
+    ]
+    per_kernel = []
+    for label, rname, cats, hbm_bytes in instances:
+        ms = sum(prof[c]["ms"] for c in cats if c in prof)
+        n = sum(prof[c]["launches"] for c in cats if c in prof)
+        fl = sum(prof[c]["flops"] for c in cats if c in prof)
+        if n == 0 or ms <= 0:
+            continue
+        tf = fl / (ms * 1e-3) / 1e12
+        row = {"kernel": label, "rocprof_name": rname, "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS,
+               "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3 / n, 2),
+               "launches_per_step": n // max(1, args.steps), "ms_per_step": round(ms / args.steps, 3),
+               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
+               "traffic": traffic_tab.get(rname, {}).get("hbm_bytes_per_launch")}
+        if hbm_bytes is not None:   # short-K adapter GEMMs: priced against HBM (algorithmic bytes per launch / duration)
+            gbs = hbm_bytes / (ms * 1e-3 / n) / 1e9
+            row.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(hbm_bytes),
+                        "tflops": round(tf, 2)})
+        per_kernel.append(row)
+    dominant = max(per_kernel, key=lambda r: r["ms_per_step"]) if per_kernel else None
+    return {
+        # dominant kernel = the instance with the most time per step (first row of profiles/*_kernel_stats.csv)
+        "roofline": ({k: dominant[k] for k in ("bound", "kernel", "rocprof_name", "achieved", "peak", "unit", "frac", "traffic",
+                                               "avg_launch_us", "launches_per_step", "algorithmic_gflop_per_launch")}
+                     if dominant else None),
+        "roofline_pass": {"hip_streams": 1, "ms_per_step": round(prof_ms_per_step, 3),
+                          "images_per_s": round(B / (prof_ms_per_step * 1e-3), 1), "codes_identical_to_timed_region": codes_same,
+                          "note": "same K steps as ONE launch chain on one stream, HIP events around every launch; "
+                                  "`value` above is the default micro-batched mode" if args.streams != 1 else
+                                  "the timed region itself ran single-stream; this pass repeats it with the launch profiler on"},
+        "roofline_per_kernel": per_kernel,
+        "roofline_all_gemm_launches": {"bound": "mfma", "achieved": round(achieved_all, 2), "peak": PEAK_BF16_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": round(achieved_all / PEAK_BF16_TFLOPS, 4),
+                                       "avg_launch_us": round(gemm_ms * 1e3 / max(1, gemm_launches), 2),
+                                       "launches_per_step": gemm_launches // max(1, args.steps),
+                                       "algorithmic_gflop_per_step": round(gemm_flops / max(1, args.steps) / 1e9, 2),
+                                       "note": "every GEMM launch of the step, HBM-bound adapter projections included"},
+        "kernel_ms_per_step": {c: round(p["ms"] / args.steps, 4) for c, p in prof.items()},
+        "kernel_ms_per_step_total": round(total_ms / args.steps, 3),
+    }
+
+
+def pcie_block(torch, enc, images, B):
+    dev = images.device
+    host = images.cpu().pin_memory()
+    dev_in = torch.empty_like(images)
+
+    def step_h2d():
+        dev_in.copy_(host, non_blocking=True)
+        return enc.encode(dev_in, want=("codes", "packed"))
+
+    step_h2d()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step_h2d()
+    torch.cuda.synchronize()
+    pcie_s = (time.perf_counter() - t0) / 5
+    # double-buffered feed: the copy of batch i+1 runs on a side stream while batch i is encoded
+    bufs = [dev_in, torch.empty_like(images)]
+    copy_stream = torch.cuda.Stream(device=dev)
+    ready = [torch.cuda.Event(), torch.cuda.Event()]      # copy into buffer j finished
+    freed = [torch.cuda.Event(), torch.cuda.Event()]      # encode of buffer j finished (it may be overwritten)
+    main_s = torch.cuda.current_stream(dev)
+    for e in freed:
+        e.record(main_s)
+
+    def feed(j):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(freed[j])
+            bufs[j].copy_(host, non_blocking=True)
+            ready[j].record(copy_stream)
+
+    nrep = 8
+    feed(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(nrep):
+        j = i & 1
+        if i + 1 < nrep:
+            feed(j ^ 1)
+        main_s.wait_event(ready[j])
+        enc.encode(bufs[j], want=("codes", "packed"))
+        freed[j].record(main_s)
+    torch.cuda.synchronize()
+    pipe_s = (time.perf_counter() - t0) / nrep
+    return {"images_per_s": round(B / pcie_s, 1), "ms_per_step": round(pcie_s * 1e3, 3),
+            "note": f"encode only, batch copied from pinned host memory every step on the same stream "
+                    f"({host.numel() * 2 / 2**20:.0f} MiB bf16, no overlap); never used for `value`",
+            "double_buffered": {"images_per_s": round(B / pipe_s, 1), "ms_per_step": round(pipe_s * 1e3, 3),
+                                "note": "copy of batch i+1 on a side stream under the encode of batch i"}}
+
+
+def _ev_time(torch, fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps, out
+
+
+def hamming_block(torch, np, rt, syn, dist, dev, rank, world):
+    """BASELINE.json config 5: 16,384 queries x 1M-row x 128-bit synthetic gallery, exact top-10.  N == 1: the whole gallery on
+    this GPU.  N > 1: the gallery sharded by rows (rank r holds rows [r*1M/N, (r+1)*1M/N)), every rank scans all queries
+    against its shard, the per-shard lists are all-gathered (RCCL) and merged -- comparisons/s is the whole job's."""
+    G5, Q5, NB5 = 1_000_000, 16384, 128
+    W5 = NB5 // 64
+    gen = torch.Generator(device=dev).manual_seed(99)
+    q5 = torch.randint(-2 ** 63, 2 ** 63 - 1, (Q5, W5), dtype=torch.int64, device=dev, generator=gen)   # same queries on every rank
+    lo, hi = rank * G5 // world, (rank + 1) * G5 // world
+    gen_g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    g5 = torch.randint(-2 ** 63, 2 ** 63 - 1, (hi - lo, W5), dtype=torch.int64, device=dev, generator=gen_g)
+
+    def scan():
+        idx, dst = rt.hamming_topk(q5, g5, TOPK, g_index_base=lo)
+        if world > 1:
+            li = torch.empty(world * Q5, TOPK, dtype=torch.int64, device=dev)
+            ld = torch.empty(world * Q5, TOPK, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(li, idx)
+            dist.all_gather_into_tensor(ld, dst)
+            idx, dst = rt.topk_merge(li.view(world, Q5, TOPK), ld.view(world, Q5, TOPK))
+        return idx, dst
+
+    scan()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        scan()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    sec = (time.perf_counter() - t0) / reps
+    if world > 1:
+        t = torch.tensor([sec], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sec = float(t.item())
+    if rank != 0:
+        return None
+    log(f"[bench] hamming scan {Q5} x {G5} x {NB5} b on {world} GPU(s): {sec * 1e3:.2f} ms")
+    tq = 256
+    alg_bytes = -(-Q5 // tq) * G5 * W5 * 8 + Q5 * (W5 + TOPK) * 8
+    out = {
+        "workload": f"{Q5} queries x {G5} gallery rows x {NB5} bit, exact top-{TOPK}, {world} GPU(s)"
+                    + (f" (gallery sharded by rows, {G5 // world} rows per GPU; all_gather of the per-shard lists + merge included)"
+                       if world > 1 else ""),
+        "queries_per_s": round(Q5 / sec, 1), "comparisons_per_s": float(f"{Q5 * G5 / sec:.4g}"),
+        "comparisons_per_s_per_gpu": float(f"{Q5 * G5 / sec / world:.4g}"), "ms": round(sec * 1e3, 3),
+        "roofline": {"bound": "hbm", "achieved": round(alg_bytes / sec / 1e9, 2), "peak": PEAK_HBM_GBS * world, "unit": "GB/s",
+                     "frac": round(alg_bytes / sec / 1e9 / (PEAK_HBM_GBS * world), 5), "traffic": None,
+                     "note": "algorithmic bytes = ceil(Qn/256)*G*W*8 + Qn*(W+k)*8; the scan is VALU-bound "
+                             "(xor+popcount+select), see DESIGN.md"},
+        # the bound that applies (DESIGN.md section 4, PMC-backed): 9.75 integer VALU instructions per 128-bit pair at
+        # 4 cycles per wave64 instruction on 1024 SIMDs at 2.4 GHz, insertion passes not counted
+        "valu_ceiling_comparisons_per_s": 4.0e12 * world, "valu_frac": round(Q5 * G5 / sec / (4.0e12 * world), 4),
+    }
+    if world > 1:
+        return out
+    # ---- single GPU only: mAP@all (histogram pass + prefix + one multi-limit AP pass) at three sizes --------------------
+    def map_eval(name, qn, gn, nbit, ncls, reps):
+        Wm = nbit // 64
+        gg = torch.Generator(device=dev).manual_seed(7)
+        gq = torch.randint(-2 ** 63, 2 ** 63 - 1, (qn, Wm), dtype=torch.int64, device=dev, generator=gg)
+        ga = torch.randint(-2 ** 63, 2 ** 63 - 1, (gn, Wm), dtype=torch.int64, device=dev, generator=gg)
+        ql = torch.randint(0, ncls, (qn,), dtype=torch.int32, device=dev, generator=gg)
+        gl = torch.randint(0, ncls, (gn,), dtype=torch.int32, device=dev, generator=gg)
+        seg = rt.map_seg_rows(qn, gn, Wm)
+        s_h, hist = _ev_time(torch, lambda: rt.hamming_hist(gq, ga, ql, gl, 0, seg), reps)
+        s_p, (base, _) = _ev_time(torch, lambda: rt.hist_prefix(hist), reps)
+        limits, _ = rt.normalize_limits([-1, 1, 5, 10])
+        s_a, _ = _ev_time(torch, lambda: rt.hamming_ap_multi(gq, ga, ql, gl, 0, seg, base, limits), reps)
+        s_e, ev = _ev_time(torch, lambda: rt.evaluate(gq, ga, ql, gl, R=-1, ks=(1, 5, 10)), max(1, reps // 2))
+        pairs = qn * gn
+        return {"workload": f"{name}: mAP@all + P/R@{{1,5,10}}, {qn} queries x {gn} gallery rows x {nbit} bit, {ncls} classes",
+                "ms": round(s_e * 1e3, 3), "queries_per_s": round(qn / s_e, 1), "mAP": round(ev["mAP"], 6),
+                "hist_pass_ms": round(s_h * 1e3, 3), "hist_prefix_ms": round(s_p * 1e3, 3), "ap_pass_ms": round(s_a * 1e3, 3),
+                "hist_pass_comparisons_per_s": float(f"{pairs / s_h:.4g}"), "ap_pass_comparisons_per_s": float(f"{pairs / s_a:.4g}"),
+                # VALU ceilings (DESIGN.md section 4): instructions per pair of the row loop at 4 cycles per wave64 instruction
+                "valu_frac_hist_pass": round(pairs / s_h / MAP_VALU_CEILING[nbit][0], 4),
+                "valu_frac_ap_pass": round(pairs / s_a / MAP_VALU_CEILING[nbit][1], 4)}
+
+    del g5
+    out["map_eval"] = map_eval("CUB-200 size", 5794, 5994, 64, 200, 6)
+    out["map_eval_nabirds"] = map_eval("NABirds size", 24633, 23929, 64, 555, 4)
+    out["map_eval_1m"] = map_eval("BASELINE config 5 size", 16384, 1_000_000, 128, 200, 2)
+    return out
+
+
+# comparisons/s ceilings of the mAP row loops: (histogram pass, AP pass) at 4 cycles per wave64 VALU instruction on 1024 SIMDs
+# at 2.4 GHz = 6.14e11 wave-instructions/s, 64 pairs per wave-instruction slot: 3.93e13 / (VALU instructions per row)
+MAP_VALU_CEILING = {64: (3.93e13 / 8.0, 3.93e13 / 8.0), 128: (3.93e13 / 12.0, 3.93e13 / 12.0)}
+
+
+def cpu_baselines(torch, np, syn, sd, cfg, g_np):
+    from oracle import encoder_oracle as eo     # the ONLY use of oracle/ in this file: the CPU baselines being timed
+    from oracle import hamming_oracle as ho
+    out = {}
+    # the box exposes all host cores to os.cpu_count() but grants a CPU share: use the affinity mask, capped at 16
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    bs = 8
+    x = syn.synthetic_images(bs, cfg["image"], seed=42)
+    eo.encode(sd, x[:1], heads=cfg["heads"], with_pooled=False)  # warm-up
+    log(f"[bench] cpu baseline: {cores} threads, warm-up done")
+    t0 = time.perf_counter()
+    nb = 0
+    while nb < BATCH // bs and (nb == 0 or time.perf_counter() - t0 < 12.0):   # 10-30 s of CPU work, at most one bench batch
+        c = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False)["codes"]
+        pk = ho.pack(c.numpy())
+        ho.topk(pk, g_np, TOPK)
+        nb += 1
+    cpu_s = time.perf_counter() - t0
+    log(f"[bench] cpu baseline: {nb} batches in {cpu_s:.1f} s")
+    out["cpu_baseline"] = {"value": round(nb * bs / cpu_s, 2), "unit": "images/s", "cores": cores, "kind": "port",
+                           "sample": f"{nb} batches of {bs} images: oracle/encoder_oracle.py (PyTorch CPU fp32 "
+                                     f"restatement of the reference forward) + oracle/hamming_oracle.c pack + "
+                                     f"top-{TOPK} vs the same {GALLERY_ROWS}-row gallery; {cpu_s:.1f} s"}
+    # ---- Hamming, SURVEY.md section 8(d): reference-style float matmul + topk on all granted cores, a packed numpy
+    # XOR/popcount, and the C oracle; 3 warm-up + 5 timed iterations each, median
+    G, nbit = 1_000_000, 128
+    hg = syn.synthetic_codes(G, nbit, seed=2)[0]
+
+    def median_time(fn, warm=3, timed=5):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    nq_f = 128
+    hq = syn.synthetic_codes(nq_f, nbit, seed=1)[0]
+    bits_g = torch.from_numpy(np.unpackbits(hg.view(np.uint8), axis=1, bitorder="little").astype(np.float32) * 2 - 1)   # +-1 [G, nbit]
+    bits_q = torch.from_numpy(np.unpackbits(hq.view(np.uint8), axis=1, bitorder="little").astype(np.float32) * 2 - 1)
+
+    def ref_style():   # get_hd formula (trainers/orthohash.py:263-264, un-normalised) + topk, as the reference-style path ranks
+        d = 0.5 * (nbit - bits_q @ bits_g.t())
+        return torch.topk(d, TOPK, dim=1, largest=False)
+
+    t_f = median_time(ref_style)
+    log(f"[bench] cpu hamming: float matmul + topk {t_f:.2f} s per {nq_f} queries")
+
+    def np_popcount():
+        d = np.zeros((nq_f, G), dtype=np.uint8)
+        for w in range(hg.shape[1]):
+            d += np.bitwise_count(hq[:, w][:, None] ^ hg[:, w][None, :])
+        return np.argpartition(d, TOPK, axis=1)[:, :TOPK]
+
+    t_n = median_time(np_popcount, warm=1, timed=3)
+    log(f"[bench] cpu hamming: numpy popcount + argpartition {t_n:.2f} s per {nq_f} queries")
+    nq_c = 1024
+    hq_c = syn.synthetic_codes(nq_c, nbit, seed=1)[0]
+    t_c = median_time(lambda: ho.bench_topk(hq_c, hg, TOPK), warm=1, timed=3)
+    out["cpu_baseline_hamming"] = {
+        "value": float(f"{nq_f * G / t_f:.4g}"), "unit": "comparisons/s", "cores": cores, "kind": "port",
+        "sample": f"{nq_f} queries x 1M x {nbit} bit: reference-style 0.5*(nbit - sign(q) sign(g)^T) float32 matmul + torch.topk "
+                  f"(k = {TOPK}) on {cores} threads, 3 warm-up + 5 timed, median {t_f:.2f} s",
+        "numpy_packed_popcount": {"value": float(f"{nq_f * G / t_n:.4g}"), "unit": "comparisons/s", "cores": 1,
+                                  "sample": f"{nq_f} queries x 1M x {nbit} bit: numpy xor + bitwise_count + argpartition, "
+                                            f"1 warm-up + 3 timed, median {t_n:.2f} s"},
+        "c_oracle": {"value": float(f"{nq_c * G / t_c:.4g}"), "unit": "comparisons/s", "cores": 1,
+                     "sample": f"{nq_c} queries x 1M x {nbit} bit: oracle/hamming_oracle.c (popcount + counting-sort ranking), "
+                               f"1 warm-up + 3 timed, median {t_c:.2f} s"}}
+    return out
 
 
 if __name__ == "__main__":

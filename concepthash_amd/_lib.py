@@ -21,6 +21,11 @@ class ModelConfig(Structure):
                [("ln_eps", c_float), ("bn_eps", c_float)]
 
 
+class ImageDesc(Structure):
+    _fields_ = [("src_offset", c_int64), ("tmp_offset", c_int64)] + \
+               [(n, c_int32) for n in ("h", "w", "nh", "nw", "top", "left", "row0", "nrows")]
+
+
 class Tensor(Structure):
     _fields_ = [("name", c_char_p), ("data", POINTER(c_float)), ("numel", c_int64)]
 
@@ -43,11 +48,15 @@ SIGNATURES = {
     "ch_debug_set_gemm_variant": (None, [c_int32]),
     "ch_debug_gemm_dispatch_count": (c_int64, [c_int32]),
     "ch_debug_set_gemm_splitk": (None, [c_int32]),
+    "ch_debug_copy_buffer": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "ch_debug_adapter": (c_int, [c_void_p] * 2 + [c_int32] * 3 + [c_void_p] * 10 + [c_int32, c_void_p]),
     "ch_debug_attention": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "ch_encode": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_encode_hidden": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "ch_preprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p,
+                              c_int32, c_void_p, c_void_p]),
+    "ch_preprocess_max_taps": (c_int32, []),
     "ch_pack_sign": (c_int, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "ch_hamming_dist": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "ch_hamming_topk_workspace": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),

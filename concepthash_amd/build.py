@@ -10,10 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libconcepthash_hip.so")
-SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "adapter_fused.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip"]
+SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "adapter_fused.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip", "preprocess.hip"]
 HEADERS = ["ch_common.h", "kernels.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "concepthash_hip.h")]
 # attention post-processes every MFMA result on the VALU: keep accumulators in VGPRs (no v_accvgpr_read round trips)
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# preprocess reproduces Pillow's double-precision filter coefficients bit for bit: no fused multiply-adds there
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "preprocess.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

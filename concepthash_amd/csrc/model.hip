@@ -722,6 +722,27 @@ extern "C" int ch_encode_hidden(ch_model *m, const void *images, int32_t image_d
     return 0;
 }
 
+// test tap: copy the first nbytes of one workspace buffer (as the last ch_encode / ch_encode_hidden left it) to `out`
+extern "C" int ch_debug_copy_buffer(ch_model *m, int32_t which, void *out, int64_t nbytes, void *stream) {
+    CH_REQUIRE(m != nullptr && out != nullptr && nbytes >= 0, "debug_copy_buffer: null pointer");
+    const int64_t rows = m->rows_alloc, D = m->cfg.dim;
+    const void *src = nullptr;
+    int64_t size = 0;
+    switch (which) {
+        case 0: src = m->H; size = rows * D * 4; break;
+        case 1: src = m->Xn; size = rows * D * 2; break;
+        case 2: src = m->QKV; size = rows * 3 * D * 2; break;
+        case 3: src = m->AO; size = rows * D * 2; break;
+        case 4: src = m->A; size = rows * D * 2; break;
+        case 5: src = m->AD; size = rows * std::max(m->bpad, 128) * 2; break;
+        case 6: src = m->F1; size = rows * (int64_t)m->cfg.ffn * 2; break;
+        default: CH_REQUIRE(false, "debug_copy_buffer: which must be 0..6 (H, Xn, QKV, AO, A, AD, F1)");
+    }
+    CH_REQUIRE(nbytes <= size, "debug_copy_buffer: more bytes requested than the buffer holds");
+    CH_CHECK_HIP(hipMemcpyAsync(out, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int ch_pack_sign(const float *codes, int64_t rows, int32_t nbit, float threshold, uint64_t *out_packed,
                             void *stream) {
     CH_REQUIRE(rows >= 0 && nbit > 0, "pack_sign: rows must be >= 0 and nbit > 0");

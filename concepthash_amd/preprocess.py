@@ -1,0 +1,99 @@
+"""GPU image pre-processing through the C-ABI (csrc/preprocess.hip): decoded uint8 HWC images of arbitrary size ->
+Resize(shorter side, bicubic) -> CenterCrop -> ToTensor -> normalize -> the NCHW bf16 / fp32 batch the encoder reads.
+
+Replaces the CPU-worker transform chain of the reference's dataset configs (configs/dataset/cub200.yaml:31-47) for the
+evaluation loop; the arithmetic is Pillow's two-pass 8-bit bicubic resampler, reproduced bit for bit on the GPU, so the
+output equals ``utils.transforms``' PIL path exactly.  Host code here only derives the per-image integers whose rounding
+rules are Python's (torchvision ``int(size * long / short)``, round-half-even crop origin, the first / last source row the
+vertical pass touches).  PyTorch supplies device buffers and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _resized_size(w: int, h: int, size: int):
+    if w <= h:
+        return size, max(1, int(size * h / w))
+    return max(1, int(size * w / h)), size
+
+
+def _row_bounds(in_size: int, out_size: int, xx: int):
+    """(first source index, count) of output index xx -- Pillow precompute_coeffs bounds."""
+    scale = float(np.float32(in_size)) / out_size
+    support = 2.0 * max(scale, 1.0)
+    center = (xx + 0.5) * scale
+    xmin = max(int(center - support + 0.5), 0)
+    xmax = min(int(center + support + 0.5), in_size) - xmin
+    return xmin, xmax
+
+
+class GpuPreprocess:
+    """Resize(resize, bicubic) -> CenterCrop(crop) -> ToTensor -> Normalize(mean, std), on the GPU."""
+
+    def __init__(self, resize: int = 256, crop: int = 224, mean: Sequence[float] = (0.48145466, 0.4578275, 0.40821073),
+                 std: Sequence[float] = (0.26862954, 0.26130258, 0.27577711), out_dtype: torch.dtype = torch.bfloat16,
+                 device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("GpuPreprocess needs a GPU (MI355X); the CPU chain is utils.transforms")
+        if out_dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError("out_dtype must be bfloat16 or float32")
+        if not (1 <= crop <= 256 and crop <= resize):
+            raise ValueError("need 1 <= crop <= 256 and crop <= resize")
+        self.resize, self.crop, self.out_dtype = int(resize), int(crop), out_dtype
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._mean = (ctypes.c_float * 3)(*[float(np.float32(m)) for m in mean])
+        self._std = (ctypes.c_float * 3)(*[float(np.float32(s)) for s in std])
+        self.max_taps = int(self.lib.ch_preprocess_max_taps())
+
+    def plan(self, sizes: Sequence[tuple]):
+        """sizes: [(h, w)] -> (descriptor array, total source bytes, workspace bytes, max rows)."""
+        B = len(sizes)
+        desc = (_lib.ImageDesc * B)()
+        src_off = tmp_off = 0
+        max_rows = 1
+        for i, (h, w) in enumerate(sizes):
+            h, w = int(h), int(w)
+            nw, nh = _resized_size(w, h, self.resize)
+            left, top = int(round((nw - self.crop) / 2.0)), int(round((nh - self.crop) / 2.0))
+            for n_in, n_out in ((w, nw), (h, nh)):
+                if 2 * math.ceil(2.0 * max(n_in / n_out, 1.0)) + 1 > self.max_taps:
+                    raise ValueError(f"image {i} ({h}x{w}) needs more than {self.max_taps} filter taps (down-scaling > ~15x)")
+            r0, _ = _row_bounds(h, nh, top)
+            rl, cl = _row_bounds(h, nh, top + self.crop - 1)
+            nrows = rl + cl - r0
+            d = desc[i]
+            d.src_offset, d.tmp_offset = src_off, tmp_off
+            d.h, d.w, d.nh, d.nw, d.top, d.left, d.row0, d.nrows = h, w, nh, nw, top, left, r0, nrows
+            src_off += h * w * 3
+            tmp_off += nrows * self.crop * 3
+            max_rows = max(max_rows, nrows)
+        return desc, src_off, tmp_off, max_rows
+
+    def __call__(self, pixels: torch.Tensor, sizes: Sequence[tuple], stream=None) -> torch.Tensor:
+        """pixels: uint8 device tensor, the images' HWC bytes back to back (image i is [h_i, w_i, 3]); sizes: [(h, w)]."""
+        if pixels.dtype != torch.uint8 or not pixels.is_cuda:
+            raise TypeError("pixels must be a uint8 GPU tensor (decoded RGB bytes, images concatenated)")
+        B = len(sizes)
+        out = torch.empty(B, 3, self.crop, self.crop, dtype=self.out_dtype, device=pixels.device)
+        if B == 0:
+            return out
+        desc, nbytes, ws_bytes, max_rows = self.plan(sizes)
+        if pixels.numel() != nbytes:
+            raise ValueError(f"pixels holds {pixels.numel()} bytes, the sizes add up to {nbytes}")
+        pixels = pixels.contiguous()
+        ddev = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(pixels.device)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=pixels.device)
+        with torch.cuda.device(pixels.device):
+            _lib.check(self.lib.ch_preprocess(_lib.ptr(pixels), _lib.ptr(ddev), B, max_rows, self.crop, self._mean, self._std,
+                                              _lib.ptr(out), 1 if self.out_dtype == torch.bfloat16 else 0, _lib.ptr(ws),
+                                              _lib.stream_ptr(stream)), "ch_preprocess")
+        return out

@@ -44,10 +44,19 @@ class RetrievalEvaluation:
         if config.exp not in ("descriptor", "extract"):
             trainer.load_model_state(f"{logdir}/models/{modelfn}.pth")
         trainer.to_device()
-        self.eval_logdir = config.eval_logdir
-        os.makedirs(self.eval_logdir, exist_ok=True)
-        with open(os.path.join(self.eval_logdir, "eval_config.yaml"), "w") as f:
-            yaml.safe_dump(to_container(config), f)
+        # one process per GPU: `eval_logdir` defaults to a time-stamped directory (configs/val.yaml), which every rank would
+        # compose differently -> rank 0 decides and broadcasts, and only rank 0 writes files
+        import torch.distributed as dist
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.rank = dist.get_rank() if self.distributed else 0
+        box = [str(config.eval_logdir)]
+        if self.distributed:
+            dist.broadcast_object_list(box, src=0)
+        self.eval_logdir = box[0]
+        if self.rank == 0:
+            os.makedirs(self.eval_logdir, exist_ok=True)
+            with open(os.path.join(self.eval_logdir, "eval_config.yaml"), "w") as f:
+                yaml.safe_dump(to_container(config), f)
         self.config, self.trainer = config, trainer
 
     # ---- code post-processing (reference :83-103) ----------------------------------------------------------------
@@ -81,7 +90,7 @@ class RetrievalEvaluation:
                     db_labels = F.one_hot(db_labels, cfg.dataset.nclass)
                     test_labels = F.one_hot(test_labels, cfg.dataset.nclass)
                 db_codes, test_codes = db_out[name], test_out[name]
-                if cfg.get("sub_code_eval"):
+                if cfg.get("compute_mAP") and cfg.get("sub_code_eval"):      # reference: only inside `if compute_mAP` (:76-98)
                     db_codes, test_codes = self._sub_codes(db_codes, test_codes)
                 if cfg.get("compute_mAP") and cfg.get("zero_mean_eval"):
                     mean = db_codes.mean(dim=0, keepdim=True)        # database mean, applied to both sets (:100-103)
@@ -108,9 +117,10 @@ class RetrievalEvaluation:
                     for R, r, p in zip(Rs, recalls, precisions):
                         print(f"P@{R}: {p:.4f}; R@{R}: {r:.4f}")
                 print()
-            with open(os.path.join(self.eval_logdir, "history.json"), "w") as f:
-                json.dump(res, f)
-        if cfg.get("save_code") or cfg.exp == "extract":
+            if self.rank == 0:
+                with open(os.path.join(self.eval_logdir, "history.json"), "w") as f:
+                    json.dump(res, f)
+        if (cfg.get("save_code") or cfg.exp == "extract") and self.rank == 0:
             print("Saving code")
             io.fast_save({"test": test_out, "db": db_out}, os.path.join(self.eval_logdir, "outputs.pth"))
         total = time.time() - self.start_time

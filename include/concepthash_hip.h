@@ -125,6 +125,10 @@ void ch_debug_set_gemm_variant(int32_t variant);
 /* How many GEMMs the dispatcher has sent to the 128x128 (which = 0) / 256x256 ping-pong (which = 1) kernel since the
  * library was loaded: lets a parity test prove which kernel produced the output it compared. */
 int64_t ch_debug_gemm_dispatch_count(int32_t which);
+/* Copy the first nbytes of one activation buffer of the model's workspace, as the last ch_encode / ch_encode_hidden call left
+ * it, to `out` (device): which = 0 H fp32 [rows, D] | 1 Xn | 2 QKV [rows, 3D] | 3 AO | 4 A | 5 AD [rows, max(bpad, 128)] |
+ * 6 F1 [rows, ffn] (1..6 bf16).  tools/stage_probe.py compares every stage of a layer with the rounding-emulating oracle. */
+int ch_debug_copy_buffer(ch_model *m, int32_t which, void *out, int64_t nbytes, void *stream);
 /* Let the debug GEMM taps use the split-K tail of the 256x256 kernel (off by default: a split tile sums its K slices in a
  * different order, so it is no longer bit-identical to the 128x128 kernel). */
 void ch_debug_set_gemm_splitk(int32_t on);
@@ -138,6 +142,33 @@ int ch_debug_attention(const void *qkv, int32_t B, int32_t ntok, int32_t heads, 
 
 /* Algorithmic FLOPs of one image through ch_encode (SURVEY.md section 8d formula). */
 double ch_model_flops_per_image(const ch_model *m);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Pre-process  (replaces the CPU-worker transform chain of configs/dataset/cub200.yaml:31-47 -- torchvision
+ * Resize(size, bicubic) -> CenterCrop(crop) -> ToTensor -> normalize -- as run by engine.dataloader, engine.py:41-54)
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* One decoded image inside the concatenated uint8 HWC (RGB, 3 bytes per pixel) buffer.  The derived integers follow
+ * Python / torchvision rounding and are computed by the host (concepthash_amd/preprocess.py):
+ *   nw, nh      size after Resize(size): shorter side = size, the other int(size * long / short);
+ *   left, top   CenterCrop origin int(round((n - crop) / 2.0)) (round-half-even);
+ *   row0, nrows source rows the vertical pass needs for the crop's rows; tmp_offset: byte offset of this image's
+ *               [nrows, crop, 3] intermediate in the workspace. */
+typedef struct ch_image_desc {
+    int64_t src_offset; /* bytes from `pixels` to this image's first pixel */
+    int64_t tmp_offset;
+    int32_t h, w, nh, nw, top, left, row0, nrows;
+} ch_image_desc;
+
+/* pixels: device uint8; desc_device: device array of B descriptors; max_rows = max nrows over the batch;
+ * mean3_host / std3_host: HOST float[3]; out: device NCHW [B,3,crop,crop], out_dtype 0 = fp32, 1 = bf16;
+ * workspace: device bytes, >= sum of nrows * crop * 3.  Resampling is Pillow's two-pass 8-bit bicubic (22-bit fixed-point
+ * coefficients, uint8 intermediate): the uint8 pixels are bit-equal to PIL's, the output to the CPU chain's. */
+int ch_preprocess(const uint8_t *pixels, const ch_image_desc *desc_device, int32_t B, int32_t max_rows, int32_t crop,
+                  const float *mean3_host, const float *std3_host, void *out, int32_t out_dtype, uint8_t *workspace,
+                  void *stream);
+/* largest number of filter taps per output pixel the kernels hold (down-scaling factor up to ~15.5) */
+int32_t ch_preprocess_max_taps(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Retrieve  (replaces the un-vendored utils.hashing.{calculate_mAP, calculate_pr_curve, get_hamm_dist}; call sites

@@ -1,0 +1,91 @@
+"""Image pre-processing: Resize(256, bicubic) -> CenterCrop(224) -> ToTensor -> normalize
+(reference configs/dataset/cub200.yaml:31-47, torchvision transforms on PIL images).
+
+CPU: oracle/preprocess_oracle.py (numpy restatement of the Pillow resampler) is PINNED against Pillow itself, and
+utils.transforms' Resize follows torchvision's truncating size rule.
+GPU: csrc/preprocess.hip through the C-ABI equals the PIL chain of utils.transforms BIT FOR BIT (fp32 output), and its bf16
+output is the RNE rounding of that -- tolerance 0."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+SIZES = [(375, 500), (500, 375), (333, 500), (64, 48), (100, 731), (256, 256), (257, 300), (1200, 900), (229, 1000)]
+
+
+def _image(h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 127 + 90 * np.sin(yy[..., None] / (7.0 + seed) + np.arange(3)) * np.cos(xx[..., None] / (11.0 + seed))
+    return np.clip(base + rng.normal(0, 25, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def _pil_chain(img, resize, crop, norm):
+    from utils import transforms as T
+    chain = T.Compose([T.Resize(resize, T.interpolation("bicubic")), T.CenterCrop(crop), T.ToTensor(), T.normalize_transform(norm)])
+    return chain(Image.fromarray(img))
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_oracle_resampler_is_bit_equal_to_pillow(h, w):
+    from oracle import preprocess_oracle as po
+    img = _image(h, w, h % 7)
+    nw, nh = po.resized_size(w, h, 256)
+    ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BICUBIC))
+    assert np.array_equal(po.resize_bicubic(img, nw, nh), ref)
+    out = po.preprocess(img, 256, 224, (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711))
+    assert np.array_equal(out, _pil_chain(img, 256, 224, 3).numpy())
+
+
+def test_resize_truncates_the_long_side_like_torchvision():
+    from utils import transforms as T
+    # 500 x 333: 256 * 500 / 333 = 384.38 -> 384; 731 x 100: 256 * 731 / 100 = 1871.36 -> 1871;
+    # 453 x 300: 256 * 453 / 300 = 386.56 -> 386 (rounding would give 387)
+    for (w, h), want in (((500, 333), (384, 256)), ((100, 731), (256, 1871)), ((453, 300), (386, 256))):
+        img = Image.fromarray(np.zeros((h, w, 3), np.uint8))
+        assert T.Resize(256, Image.BICUBIC)(img).size == want
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_equals_the_pil_chain_bit_for_bit():
+    from concepthash_amd.preprocess import GpuPreprocess
+    dev = torch.device("cuda:0")
+    imgs = [_image(h, w, i) for i, (h, w) in enumerate(SIZES)]
+    pixels = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).to(dev)
+    sizes = [im.shape[:2] for im in imgs]
+    for norm in (3, 2):
+        from utils.transforms import _NORMS
+        mean, std = _NORMS[norm]
+        want = torch.stack([_pil_chain(im, 256, 224, norm) for im in imgs])
+        got32 = GpuPreprocess(256, 224, mean, std, out_dtype=torch.float32, device=dev)(pixels, sizes).cpu()
+        assert got32.shape == want.shape == (len(imgs), 3, 224, 224)
+        assert torch.equal(got32, want), float((got32 - want).abs().max())
+        got16 = GpuPreprocess(256, 224, mean, std, out_dtype=torch.bfloat16, device=dev)(pixels, sizes).cpu()
+        assert torch.equal(got16, want.to(torch.bfloat16))
+    # other geometry: Resize(160) -> CenterCrop(128), up-scaling of the small image included
+    want = torch.stack([_pil_chain(im, 160, 128, 1) for im in imgs])
+    got = GpuPreprocess(160, 128, *_NORMS[1], out_dtype=torch.float32, device=dev)(pixels, sizes).cpu()
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        GpuPreprocess(256, 224, device=dev)(torch.zeros(5000 * 40 * 3, dtype=torch.uint8, device=dev), [(5000, 40)])   # > 15x
+    with pytest.raises(TypeError):
+        GpuPreprocess(256, 224, device=dev)(pixels.float(), sizes)
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_feeds_the_encoder():
+    """decoded bytes -> GPU pre-processing -> ch_encode: same codes as the CPU chain's tensors given to the encoder."""
+    from concepthash_amd.encoder import ConceptHashEncoder
+    from concepthash_amd.preprocess import GpuPreprocess
+    from concepthash_amd import synthetic as syn
+    dev = torch.device("cuda:0")
+    cfg = dict(syn.CONFIGS["vit_s16"])
+    cfg["L"] = 2
+    sd = syn.synthetic_state_dict(cfg, nbit=32, nclass=10)
+    imgs = [_image(h, w, i) for i, (h, w) in enumerate(SIZES[:4])]
+    pixels = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).to(dev)
+    batch = GpuPreprocess(256, 224, device=dev)(pixels, [im.shape[:2] for im in imgs])
+    enc = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=4, device=dev)
+    a = enc.encode(batch)["codes"]
+    b = enc.encode(torch.stack([_pil_chain(im, 256, 224, 3) for im in imgs]).to(dev).to(torch.bfloat16))["codes"]
+    assert torch.equal(a, b)

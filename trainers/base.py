@@ -95,18 +95,32 @@ class BaseTrainer:
         if not return_codes:
             return meters
         res = {}
-        for key, vals in ret.items():
-            if isinstance(vals[0], torch.Tensor):
-                t = torch.cat(vals)
-                if self.distributed:              # ranks hold contiguous blocks -> rank-major concatenation == dataset order
-                    from concepthash_amd.distributed import _all_gather_ragged
-                    t, _ = _all_gather_ragged(t.contiguous())
-                res[key] = t.cpu()                # one device->host copy per output per epoch
-            else:
-                res[key] = np.concatenate(vals)
+        if self.distributed:
+            # every rank enters the SAME sequence of collectives, also one whose shard produced no batch: the ranks first agree
+            # on the output keys (name, trailing shape, dtype) -- taken from any rank that has data -- and an empty rank
+            # contributes zero-row tensors of that description
+            import torch.distributed as dist
+            from concepthash_amd.distributed import _all_gather_ragged
+            mine = [(k, tuple(v[0].shape[1:]), str(v[0].dtype).replace("torch.", "")) for k, v in sorted(ret.items())
+                    if isinstance(v[0], torch.Tensor)]
+            allk = [None] * self.world_size
+            dist.all_gather_object(allk, mine)
+            spec = next((x for x in allk if x), [])
+            for key, tail, dt in spec:
+                t = torch.cat(ret[key]) if key in ret else torch.zeros((0,) + tuple(tail), dtype=getattr(torch, dt), device=self.device)
+                t, _ = _all_gather_ragged(t.contiguous())      # ranks hold contiguous blocks -> rank-major == dataset order
+                res[key] = t.cpu()
+        else:
+            for key, vals in ret.items():
+                if isinstance(vals[0], torch.Tensor):
+                    res[key] = torch.cat(vals).cpu()  # one device->host copy per output per epoch
+                else:
+                    res[key] = np.concatenate(vals)
         if self.distributed:                      # meters: sample-weighted average over ranks
             import torch.distributed as dist
-            for k in sorted(meters):
+            names = [None] * self.world_size
+            dist.all_gather_object(names, sorted(meters))          # a rank without batches has no meters of its own
+            for k in sorted(set().union(*names)):
                 v = torch.tensor([meters[k].sum, float(meters[k].count)], dtype=torch.float64, device=self.device)
                 dist.all_reduce(v)
                 meters[k].sum, meters[k].count = float(v[0]), int(v[1])

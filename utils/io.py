@@ -21,7 +21,7 @@ def _run():
         obj, path = item
         try:
             os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-            tmp = path + ".tmp"
+            tmp = f"{path}.{os.getpid()}.tmp"     # unique per process: two ranks never share a temporary name
             torch.save(obj, tmp)
             os.replace(tmp, path)
         finally:

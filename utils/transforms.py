@@ -41,12 +41,12 @@ class Resize:
         self.size, self.interp = size, interpolation
 
     def __call__(self, img):
-        if isinstance(self.size, int):          # shorter side -> size, aspect kept (torchvision semantics)
-            w, h = img.size
+        if isinstance(self.size, int):          # shorter side -> size, aspect kept; the long side TRUNCATES, as
+            w, h = img.size                     # torchvision's _compute_resized_output_size does: int(size * long / short)
             if w <= h:
-                nw, nh = self.size, max(1, int(round(h * self.size / w)))
+                nw, nh = self.size, max(1, int(self.size * h / w))
             else:
-                nw, nh = max(1, int(round(w * self.size / h))), self.size
+                nw, nh = max(1, int(self.size * w / h)), self.size
             return img.resize((nw, nh), self.interp)
         return img.resize((self.size[1], self.size[0]), self.interp)
 
