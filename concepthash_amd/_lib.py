@@ -47,6 +47,7 @@ SIGNATURES = {
                                  c_void_p]),
     "ch_debug_set_gemm_variant": (None, [c_int32]),
     "ch_debug_gemm_dispatch_count": (c_int64, [c_int32]),
+    "ch_debug_experiments_built": (c_int32, []),
     "ch_debug_set_gemm_splitk": (None, [c_int32]),
     "ch_debug_copy_buffer": (c_int, [c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "ch_debug_adapter": (c_int, [c_void_p] * 2 + [c_int32] * 3 + [c_void_p] * 10 + [c_int32, c_void_p]),

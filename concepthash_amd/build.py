@@ -10,7 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libconcepthash_hip.so")
-SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "adapter_fused.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip", "preprocess.hip"]
+SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip",
+           "preprocess.hip"]
+# kernels that lost to the dispatched ones: kept in the tree with their parity tests, compiled only
+# into an experiments build (CH_BUILD_EXPERIMENTS=1), never into the product library
+EXPERIMENT_SOURCES = ["gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "adapter_fused.hip"]
 HEADERS = ["ch_common.h", "kernels.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "concepthash_hip.h")]
 # attention post-processes every MFMA result on the VALU: keep accumulators in VGPRs (no v_accvgpr_read round trips)
 # preprocess reproduces Pillow's double-precision filter coefficients bit for bit: no fused multiply-adds there
@@ -35,15 +39,23 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
+    experiments = os.environ.get("CH_BUILD_EXPERIMENTS", "0") == "1"
+    stamp = os.path.join(OBJDIR, "experiments.flag")
+    if (os.path.exists(stamp) and open(stamp).read().strip() == "1") != experiments:
+        force = True                       # switching between the product and the experiments build recompiles everything
+    with open(stamp, "w") as f:
+        f.write("1" if experiments else "0")
+    sources = SOURCES + (EXPERIMENT_SOURCES if experiments else [])
+    flags = FLAGS + (["-DCH_EXPERIMENTS"] if experiments else [])
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     jobs = []
     objs = []
-    for src in SOURCES:
+    for src in sources:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + hdrs):
-            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op])
+            jobs.append([hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:

@@ -324,40 +324,10 @@ int launch_adapter(const AdapterParams &p, hipStream_t s) {
     return (p.dbg & 16) ? launch_adapter_cfg<BPAD, 128, 4>(p, s) : launch_adapter_cfg<BPAD, 64, 2>(p, s);
 }
 
-// Wd' = bf16(Wd * gamma) (rows >= b zero), c[n] = sum_k float(Wd'[n][k]), d[n] = sum_k beta[k] * Wd[n][k] + bd[n]
-__global__ void fold_ln_kernel(const float *Wd, const float *bd, const float *gamma, const float *beta, int b, int bpad, int D,
-                               bf16_t *Wdf, float *c, float *d) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (n >= bpad) return;
-    float cs = 0.f, ds = 0.f;
-    for (int k = lane; k < D; k += 64) {
-        const float w = n < b ? Wd[(size_t)n * D + k] : 0.f;
-        const bf16_t wb = f2bf(w * gamma[k]);
-        Wdf[(size_t)n * D + k] = wb;
-        cs += bf2f(wb);
-        ds += beta[k] * w;
-    }
-    cs = wave_sum(cs);
-    ds = wave_sum(ds);
-    if (lane == 0) {
-        c[n] = cs;
-        d[n] = ds + (n < b ? bd[n] : 0.f);
-    }
-}
-
 }  // namespace
 
 bool ch_adapter_fused_supported(int D, int bpad) {
     return D % 256 == 0 && D <= 1024 && (bpad == 128 || bpad == 256 || bpad == 384);
-}
-
-int ch_fold_ln(const float *Wd, const float *bd, const float *gamma, const float *beta, int b, int bpad, int D, bf16_t *Wdf,
-               float *c, float *d, hipStream_t s) {
-    hipLaunchKernelGGL(fold_ln_kernel, dim3((unsigned)ceil_div64(bpad, 4)), dim3(256), 0, s, Wd, bd, gamma, beta, b, bpad, D, Wdf,
-                       c, d);
-    CH_LAUNCH_CHECK();
-    return 0;
 }
 
 int ch_adapter_fused(const AdapterParams &p, hipStream_t s) {

@@ -32,7 +32,7 @@ typedef __attribute__((address_space(3))) v4s lds_v4s;
 // hashing head reads -- CLS and the `ncon` concept tokens -- are queries, and the output is [B * (1 + ncon), D] (final layer)
 template <int KB, bool TAP, bool COMPACT>
 __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__restrict__ qkv, int ntok, int heads, float scale_log2e,
-                                                        bf16_t *__restrict__ out, float *__restrict__ cattn, int ncon) {
+                                                        bf16_t *__restrict__ out, float *__restrict__ cattn, int ncon, int rev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = KB * 2;   // 16-key tiles
     constexpr int KP = KB * 32;  // padded keys
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__r
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const int bid = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int b = bid / heads, h = bid - b * heads;
     const int D = heads * HD;
     const size_t ld = (size_t)3 * D;
     const bf16_t *base = qkv + (size_t)b * ntok * ld + h * HD;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__r
 }
 
 template <int KB, bool TAP, bool COMPACT>
-int launch_attn_inst(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, float *cattn, int ncon, hipStream_t s) {
+int launch_attn_inst(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, float *cattn, int ncon, int rev, hipStream_t s) {
     const int KP = KB * 32;
     const size_t lds = (size_t)KP * 128 * 2;
     CH_REQUIRE(lds <= 160 * 1024, "attention: sequence too long for the LDS-resident K/V kernel");
@@ -231,35 +232,36 @@ int launch_attn_inst(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out,
     if (int e = ch_func_max_lds((const void *)attention_kernel<KB, TAP, COMPACT>, (int)lds, lds_once)) return e;
     const float scale_log2e = 0.125f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e), head_dim = 64
     hipLaunchKernelGGL((attention_kernel<KB, TAP, COMPACT>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, ntok, heads, scale_log2e,
-                       out, cattn, ncon);
+                       out, cattn, ncon, rev);
     CH_LAUNCH_CHECK();
     return 0;
 }
 template <int KB>
-int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, float *cattn, int ncon, bool compact, hipStream_t s) {
+int launch_attn(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, float *cattn, int ncon, bool compact, int rev, hipStream_t s) {
     if (compact)
-        return cattn ? launch_attn_inst<KB, true, true>(qkv, B, ntok, heads, out, cattn, ncon, s)
-                     : launch_attn_inst<KB, false, true>(qkv, B, ntok, heads, out, cattn, ncon, s);
-    return cattn ? launch_attn_inst<KB, true, false>(qkv, B, ntok, heads, out, cattn, ncon, s)
-                 : launch_attn_inst<KB, false, false>(qkv, B, ntok, heads, out, cattn, ncon, s);
+        return cattn ? launch_attn_inst<KB, true, true>(qkv, B, ntok, heads, out, cattn, ncon, rev, s)
+                     : launch_attn_inst<KB, false, true>(qkv, B, ntok, heads, out, cattn, ncon, rev, s);
+    return cattn ? launch_attn_inst<KB, true, false>(qkv, B, ntok, heads, out, cattn, ncon, rev, s)
+                 : launch_attn_inst<KB, false, false>(qkv, B, ntok, heads, out, cattn, ncon, rev, s);
 }
 
 }  // namespace
 
-int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s, float *cattn, int ncon, bool compact) {
+int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s, float *cattn, int ncon, bool compact,
+                 bool rev) {
     CH_REQUIRE(B > 0 && ntok > 0 && heads > 0, "attention: empty problem");
     CH_REQUIRE(!compact || (ncon >= 1 && ncon < ntok), "attention: compact mode needs 1 <= ncon < ntok");
     const int KB = (ntok + 31) / 32;
     switch (KB) {
-        case 1: return launch_attn<1>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
-        case 2: return launch_attn<2>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
-        case 3: return launch_attn<3>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
-        case 4: return launch_attn<4>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
-        case 5: return launch_attn<5>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
-        case 6: return launch_attn<6>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
-        case 7: return launch_attn<7>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
-        case 8: return launch_attn<8>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
-        case 9: return launch_attn<9>(qkv, B, ntok, heads, out, cattn, ncon, compact, s);
+        case 1: return launch_attn<1>(qkv, B, ntok, heads, out, cattn, ncon, compact, rev ? 1 : 0, s);
+        case 2: return launch_attn<2>(qkv, B, ntok, heads, out, cattn, ncon, compact, rev ? 1 : 0, s);
+        case 3: return launch_attn<3>(qkv, B, ntok, heads, out, cattn, ncon, compact, rev ? 1 : 0, s);
+        case 4: return launch_attn<4>(qkv, B, ntok, heads, out, cattn, ncon, compact, rev ? 1 : 0, s);
+        case 5: return launch_attn<5>(qkv, B, ntok, heads, out, cattn, ncon, compact, rev ? 1 : 0, s);
+        case 6: return launch_attn<6>(qkv, B, ntok, heads, out, cattn, ncon, compact, rev ? 1 : 0, s);
+        case 7: return launch_attn<7>(qkv, B, ntok, heads, out, cattn, ncon, compact, rev ? 1 : 0, s);
+        case 8: return launch_attn<8>(qkv, B, ntok, heads, out, cattn, ncon, compact, rev ? 1 : 0, s);
+        case 9: return launch_attn<9>(qkv, B, ntok, heads, out, cattn, ncon, compact, rev ? 1 : 0, s);
     }
     ch_set_error("attention: more than 288 tokens per image is not supported");
     return 2;

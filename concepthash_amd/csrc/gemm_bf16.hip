@@ -53,7 +53,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
     const int per_group = tiles_m * p.group_n;
     const int g = wg / per_group, rem = wg - g * per_group;
     const int gn = min(p.group_n, tiles_n - g * p.group_n);
-    const int tm = rem / gn, tn = g * p.group_n + (rem - tm * gn);
+    const int tm_fwd = rem / gn, tn = g * p.group_n + (rem - tm_fwd * gn);
+    const int tm = p.rev ? tiles_m - 1 - tm_fwd : tm_fwd;
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- staging addresses: the stage image is [X rows 0..127 ; W rows 0..127] x 128 B, 8 rows per wave-instruction.
@@ -203,6 +204,11 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
         CH_REQUIRE(p.stats_out && (epi == EPI_BIAS_STATS || p.hb_out), "gemm: statistics epilogue needs stats_out (and hb_out)");
     if (g_gemm_variant == 1) return ch_gemm_bf16_v1(p, epi, s);
     if (g_gemm_variant == 2) return ch_gemm_bf16_pp(p, epi, s);
+    if (g_gemm_variant == 4) {  // 256x256 kernel, coarse schedule
+        GemmParams q = p;
+        q.pp_sched = 1;
+        return ch_gemm_bf16_pp(q, epi, s);
+    }
     if (g_gemm_variant == 3) return ch_gemm_bf16_dp(p, epi, s);
     // Short-K GEMMs (the adapter up-projection, K = 384) are epilogue/HBM bound: two 128x128 workgroups per CU overlap one's
     // read-modify-write epilogue with the other's K loop and win there (measured: 152 -> 97 us per launch in the pipeline);

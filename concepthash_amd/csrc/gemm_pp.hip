@@ -60,7 +60,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     } while (0)
 
 // DBG bits (timing-only builds, results are garbage): 1 = no global loads, 2 = no LDS fragment reads, 4 = no epilogue
-template <int EPI, int DBG = 0>
+// SCHED 0: four phases of 16 MFMAs per K-tile (the guide's 8-phase template); SCHED 1: two phases of 32 MFMAs per K-tile
+// (section "coarse schedule" below): same buffers, same fragments, half the barriers.
+template <int EPI, int DBG = 0, int SCHED = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const int per_group = tiles_m * p.group_n;
     const int g = wg / per_group, rem = wg - g * per_group;
     const int gn = min(p.group_n, tiles_n - g * p.group_n);
-    const int tm = rem / gn, tn = g * p.group_n + (rem - tm * gn);
+    const int tm_fwd = rem / gn, tn = g * p.group_n + (rem - tm_fwd * gn);
+    const int tm = p.rev ? tiles_m - 1 - tm_fwd : tm_fwd;
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- prefetch addressing.  A half-tile = 16 wave-instructions of 8 local rows; wave w issues instructions 2w, 2w+1:
@@ -169,93 +172,179 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const int j0 = slice * J;
     const int kb0 = 2 * j0;  // first K-tile (even, so the buffer parity of the schedule is unchanged)
 
-    // ---- prologue: K-tile 0 complete (4 half-tiles) + 3 half-tiles of K-tile 1; retire K-tile 0 with vmcnt(6)
-    f32x4 fold_v[5];
-    if constexpr (ch_epi::traits<EPI>::fold) ch_epi::fold_stats_issue(p, m0, tid, fold_v);  // older than every DMA below
-    issue(0, kb0);
-    issue(2, kb0);
-    issue(3, kb0);
-    issue(1, kb0);
-    issue(0, kb0 + 1);
-    issue(2, kb0 + 1);
-    issue(3, kb0 + 1);
-    PP_WAIT_VM(6);
-    if constexpr (ch_epi::traits<EPI>::fold) {  // per-row (mean, rstd) of the LN-folded input
-        ch_epi::fold_stats_finish(p, tid, fold_v, (float *)(smem + 2 * BUF_BYTES));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    PP_BARRIER();
-    if (wr == 1) PP_BARRIER();  // stagger: waves 4-7 run one barrier behind waves 0-3
+    if constexpr (SCHED == 1) {
+        // ---- coarse schedule: per K-tile kt (buffer b = kt & 1) two phases of 32 MFMAs
+        //   A(kt): read W_h0, W_h1, X_h0 of buffer b (16 x b128); issue X_h1 of K-tile kt+1 (its slot was last read at B(kt-1));
+        //          wait vmcnt(8): retires X_h1 of K-tile kt (read at B(kt), the NEXT phase);  MFMA Q(m0,n0), Q(m0,n1)
+        //   B(kt): read X_h1 of buffer b (8 x b128); issue W_h0, W_h1, X_h0 of K-tile kt+2 into buffer b (last read at A(kt),
+        //          complete behind that phase's lgkmcnt(0) + barrier); wait vmcnt(8): retires W_h0, W_h1, X_h0 of K-tile kt+1
+        //          (read at A(kt+1));  MFMA Q(m1,n1), Q(m1,n0)
+        // Issue order per wave: ..., [W_h0 W_h1 X_h0](kt+1) at B(kt-1), X_h1(kt+1) at A(kt), [W_h0 W_h1 X_h0](kt+2) at B(kt), ...
+        // = 6, 2, 6, 2 loads, so "all but the youngest 8" is exactly what each wait needs.  Every staged half-tile is read one
+        // phase (two barriers) after the wait that retires it; every slot is re-staged one phase after its last read, whose
+        // lgkmcnt(0) precedes the reading wave's barrier -- the same distances as the 8-phase schedule, and the stagger
+        // (waves 4-7 one barrier behind) is unchanged.  No split-K in this schedule.
+        const int nkt = p.K / BK;
+        f32x4 fold_v[5];
+        if constexpr (ch_epi::traits<EPI>::fold) ch_epi::fold_stats_issue(p, m0, tid, fold_v);  // older than every DMA below
+        issue(2, 0);
+        issue(3, 0);
+        issue(0, 0);
+        issue(1, 0);
+        issue(2, 1);
+        issue(3, 1);
+        issue(0, 1);
+        PP_WAIT_VM(8);
+        if constexpr (ch_epi::traits<EPI>::fold) {
+            ch_epi::fold_stats_finish(p, tid, fold_v, (float *)(smem + 2 * BUF_BYTES));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();
+        if (wr == 1) PP_BARRIER();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            // ===== even buffer, K-tile kt =====
+            read_w(Wa, 0, 0);
+            read_w(Wbf, 0, 1);
+            read_x(0, 0);
+            issue(1, kt + 1);  // nkt is even: K-tile kt + 1 exists
+            PP_WAIT_VM(8);
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wa, 0, 0);
+            PP_MFMA(Wbf, 1, 0);
+            PP_BARRIER();
+            read_x(0, 1);
+            if (kt + 2 < nkt) {
+                issue(2, kt + 2);
+                issue(3, kt + 2);
+                issue(0, kt + 2);
+                PP_WAIT_VM(8);
+            } else {
+                PP_WAIT_VM(2);
+            }
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wbf, 1, 1);
+            PP_MFMA(Wa, 0, 1);
+            PP_BARRIER();
+            // ===== odd buffer, K-tile kt + 1 =====
+            read_w(Wa, 1, 0);
+            read_w(Wbf, 1, 1);
+            read_x(1, 0);
+            if (kt + 2 < nkt) {
+                issue(1, kt + 2);
+                PP_WAIT_VM(8);
+            } else {
+                PP_WAIT_VM(0);
+            }
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wa, 0, 0);
+            PP_MFMA(Wbf, 1, 0);
+            PP_BARRIER();
+            read_x(1, 1);
+            if (kt + 3 < nkt) {
+                issue(2, kt + 3);
+                issue(3, kt + 3);
+                issue(0, kt + 3);
+                PP_WAIT_VM(8);
+            }
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wbf, 1, 1);
+            PP_MFMA(Wa, 0, 1);
+            PP_BARRIER();
+        }
+        if (wr == 0) PP_BARRIER();  // balance the stagger barrier
+    } else {
+        // ---- prologue: K-tile 0 complete (4 half-tiles) + 3 half-tiles of K-tile 1; retire K-tile 0 with vmcnt(6)
+        f32x4 fold_v[5];
+        if constexpr (ch_epi::traits<EPI>::fold) ch_epi::fold_stats_issue(p, m0, tid, fold_v);  // older than every DMA below
+        issue(0, kb0);
+        issue(2, kb0);
+        issue(3, kb0);
+        issue(1, kb0);
+        issue(0, kb0 + 1);
+        issue(2, kb0 + 1);
+        issue(3, kb0 + 1);
+        PP_WAIT_VM(6);
+        if constexpr (ch_epi::traits<EPI>::fold) {  // per-row (mean, rstd) of the LN-folded input
+            ch_epi::fold_stats_finish(p, tid, fold_v, (float *)(smem + 2 * BUF_BYTES));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();
+        if (wr == 1) PP_BARRIER();  // stagger: waves 4-7 run one barrier behind waves 0-3
 
-    for (int jj = 0; jj < J; ++jj) {
-        const bool more = (jj + 1 < J);  // K-tiles ke+2 / ke+3 belong to this block
-        const int ke = 2 * (j0 + jj), ko = ke + 1;
-        // ================= even buffer, K-tile ke =================
-        // phase 1
-        read_w(Wa, 0, 0);
-        read_x(0, 0);
-        issue(1, ko);  // X_h1[odd] of K-tile 2j+1 (always exists)
-        PP_WAIT_LGKM0();
-        PP_BARRIER();
-        PP_MFMA(Wa, 0, 0);
-        PP_BARRIER();
-        // phase 2
-        read_w(Wbf, 0, 1);
-        if (more) issue(0, ke + 2);
-        PP_WAIT_LGKM0();
-        PP_BARRIER();
-        PP_MFMA(Wbf, 1, 0);
-        PP_BARRIER();
-        // phase 3
-        read_x(0, 1);
-        if (more) issue(2, ke + 2);
-        PP_WAIT_LGKM0();
-        PP_BARRIER();
-        PP_MFMA(Wbf, 1, 1);
-        PP_BARRIER();
-        // phase 4: retire the odd buffer (everything issued up to phase 1)
-        if (more) {
-            issue(3, ke + 2);
-            PP_WAIT_VM(6);
-        } else {
-            PP_WAIT_VM(0);
+        for (int jj = 0; jj < J; ++jj) {
+            const bool more = (jj + 1 < J);  // K-tiles ke+2 / ke+3 belong to this block
+            const int ke = 2 * (j0 + jj), ko = ke + 1;
+            // ================= even buffer, K-tile ke =================
+            // phase 1
+            read_w(Wa, 0, 0);
+            read_x(0, 0);
+            issue(1, ko);  // X_h1[odd] of K-tile 2j+1 (always exists)
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wa, 0, 0);
+            PP_BARRIER();
+            // phase 2
+            read_w(Wbf, 0, 1);
+            if (more) issue(0, ke + 2);
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wbf, 1, 0);
+            PP_BARRIER();
+            // phase 3
+            read_x(0, 1);
+            if (more) issue(2, ke + 2);
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wbf, 1, 1);
+            PP_BARRIER();
+            // phase 4: retire the odd buffer (everything issued up to phase 1)
+            if (more) {
+                issue(3, ke + 2);
+                PP_WAIT_VM(6);
+            } else {
+                PP_WAIT_VM(0);
+            }
+            PP_BARRIER();
+            PP_MFMA(Wa, 0, 1);
+            PP_BARRIER();
+            // ================= odd buffer, K-tile ko =================
+            // phase 5
+            read_w(Wa, 1, 0);
+            read_x(1, 0);
+            if (more) issue(1, ke + 2);
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wa, 0, 0);
+            PP_BARRIER();
+            // phase 6
+            read_w(Wbf, 1, 1);
+            if (more) issue(0, ko + 2);
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wbf, 1, 0);
+            PP_BARRIER();
+            // phase 7
+            read_x(1, 1);
+            if (more) issue(2, ko + 2);
+            PP_WAIT_LGKM0();
+            PP_BARRIER();
+            PP_MFMA(Wbf, 1, 1);
+            PP_BARRIER();
+            // phase 8: retire the even buffer of the next iteration (everything issued up to phase 5)
+            if (more) {
+                issue(3, ko + 2);
+                PP_WAIT_VM(6);
+            }
+            PP_BARRIER();
+            PP_MFMA(Wa, 0, 1);
+            PP_BARRIER();
         }
-        PP_BARRIER();
-        PP_MFMA(Wa, 0, 1);
-        PP_BARRIER();
-        // ================= odd buffer, K-tile ko =================
-        // phase 5
-        read_w(Wa, 1, 0);
-        read_x(1, 0);
-        if (more) issue(1, ke + 2);
-        PP_WAIT_LGKM0();
-        PP_BARRIER();
-        PP_MFMA(Wa, 0, 0);
-        PP_BARRIER();
-        // phase 6
-        read_w(Wbf, 1, 1);
-        if (more) issue(0, ko + 2);
-        PP_WAIT_LGKM0();
-        PP_BARRIER();
-        PP_MFMA(Wbf, 1, 0);
-        PP_BARRIER();
-        // phase 7
-        read_x(1, 1);
-        if (more) issue(2, ko + 2);
-        PP_WAIT_LGKM0();
-        PP_BARRIER();
-        PP_MFMA(Wbf, 1, 1);
-        PP_BARRIER();
-        // phase 8: retire the even buffer of the next iteration (everything issued up to phase 5)
-        if (more) {
-            issue(3, ko + 2);
-            PP_WAIT_VM(6);
-        }
-        PP_BARRIER();
-        PP_MFMA(Wa, 0, 1);
-        PP_BARRIER();
+        if (wr == 0) PP_BARRIER();  // balance the stagger barrier
     }
-    if (wr == 0) PP_BARRIER();  // balance the stagger barrier
 
     // ---- split-K tail: publish this slice's partial tile; the LAST arriver (agent-scope ticket) sums all slices in slice
     // order -- its own included, read back from memory, so the result does not depend on who arrives last -- and runs the
@@ -341,18 +430,33 @@ void ch_pp_choose_split(GemmParams &p, int tiles) {
     p.split_s = S;
 }
 
+template <int EPI, int SCHED>
+int launch_pp_sched(GemmParams &p, int tiles, hipStream_t s) {
+    constexpr int lds = 2 * BUF_BYTES + CH_FOLD_LDS_BYTES + 16;  // operands + (mean, rstd) table + split-K ticket
+    static ch_once_per_device lds_once;
+    if (int e = ch_func_max_lds((const void *)gemm_pp_kernel<EPI, 0, SCHED>, lds, lds_once)) return e;
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, 0, SCHED>), dim3(p.split_full + (tiles - p.split_full) * p.split_s), dim3(NTHREADS), lds,
+                       s, p);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int EPI>
 int launch_pp(const GemmParams &p0, hipStream_t s) {
     GemmParams p = p0;
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-    constexpr int lds = 2 * BUF_BYTES + CH_FOLD_LDS_BYTES + 16;  // operands + (mean, rstd) table + split-K ticket
+    if (p.pp_sched == 1) {  // coarse schedule (experiment, DESIGN.md section 3.8: bit-identical, no faster): no split-K
+#ifdef CH_EXPERIMENTS
+        p.split_full = tiles;
+        p.split_s = 1;
+        return launch_pp_sched<EPI, 1>(p, tiles, s);
+#else
+        return ch_experiments_not_built();
+#endif
+    }
     ch_pp_choose_split(p, tiles);
-    static ch_once_per_device lds_once;
-    if (int e = ch_func_max_lds((const void *)gemm_pp_kernel<EPI>, lds, lds_once)) return e;
-    hipLaunchKernelGGL(gemm_pp_kernel<EPI>, dim3(p.split_full + (tiles - p.split_full) * p.split_s), dim3(NTHREADS), lds, s, p);
-    CH_LAUNCH_CHECK();
-    return 0;
+    return launch_pp_sched<EPI, 0>(p, tiles, s);
 }
 
 }  // namespace

@@ -52,6 +52,8 @@ struct GemmParams {
     unsigned *splitk_cnt;
     int split_full, split_s;
     int force_split;         // debug taps: split even though CH_GEMM_SPLITK is off
+    int rev;                 // 1: walk the m-tiles from the last row tile to the first (serpentine launch order)
+    int pp_sched;            // 256x256 kernel: 0 = four phases of 16 MFMAs per K-tile, 1 = two phases of 32 (gemm_pp.hip)
     int pp_min_k;            // dispatcher: smallest K that goes to the 256x256 ping-pong kernel (0 = default 512)
 };
 constexpr size_t CH_SPLITK_WS_BYTES = (size_t)256 * 256 * 256 * 4;  // 64 MiB: at most 256 tail units of one 256x256 fp32 slab
@@ -61,12 +63,24 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);      // dispatche
 int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s);   // gemm_bf16.hip: 128x128x64, two-phase
 int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s);   // gemm_pp.hip: 256x256x64, ping-pong 8-phase
 bool ch_gemm_pp_supported(const GemmParams &p);
+// Experiment kernels that did not beat the dispatched ones: built only with CH_BUILD_EXPERIMENTS=1
+// (-DCH_EXPERIMENTS); the product library does not contain them and their taps say so.
+#ifdef CH_EXPERIMENTS
 int ch_gemm_bf16_pq(const GemmParams &p, int epi, hipStream_t s);   // gemm_pq.hip: 256x128x64, ping-pong, two phases per K-tile
 bool ch_gemm_pq_supported(const GemmParams &p);
 int ch_gemm_bf16_ppp(const GemmParams &p, int epi, hipStream_t s);  // gemm_ppp.hip: persistent ping-pong (bf16-output epilogues)
 bool ch_gemm_ppp_supported(const GemmParams &p, int epi);
 int ch_gemm_bf16_dp(const GemmParams &p, int epi, hipStream_t s);   // gemm_dp.hip: 256x128x32, 3-stage ring, 2 workgroups/CU
 bool ch_gemm_dp_supported(const GemmParams &p);
+#else
+static inline int ch_experiments_not_built() {
+    ch_set_error("experiment kernels are not part of this build (rebuild with CH_BUILD_EXPERIMENTS=1)");
+    return 2;
+}
+static inline int ch_gemm_bf16_pq(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
+static inline int ch_gemm_bf16_ppp(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
+static inline int ch_gemm_bf16_dp(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
+#endif
 int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s);  // timing-only builds (garbage results)
 void ch_gemm_set_variant(int v);
 // n-tiles per weight group for a block tile of bn columns: minimises X re-fetches + W re-fetches
@@ -85,8 +99,14 @@ struct AdapterParams {
     float eps;
     int dbg;              // timing-only ablations (bit 1: skip phase 0, 2: skip phase A loop, 4: skip phase C loop, 8: skip epilogues)
 };
+#ifdef CH_EXPERIMENTS
 bool ch_adapter_fused_supported(int D, int bpad);
 int ch_adapter_fused(const AdapterParams &p, hipStream_t s);
+#else
+static inline bool ch_adapter_fused_supported(int, int) { return false; }
+static inline int ch_adapter_fused(const AdapterParams &, hipStream_t) { return ch_experiments_not_built(); }
+#endif
+// small_f32.hip: LayerNorm fold of a Linear at model build
 int ch_fold_ln(const float *Wd, const float *bd, const float *gamma, const float *beta, int b, int bpad, int D, bf16_t *Wdf,
                float *c, float *d, hipStream_t s);
 
@@ -112,8 +132,9 @@ int ch_gather_head_rows(const float *H, int B, int ntok, int ncon, int D, float 
 // qkv [B*ntok, 3D] bf16 (q | k | v, head h at columns h*64), out [B*ntok, D] bf16.  head_dim == 64.
 // cattn (optional): [B, heads, ncon, ntok - ncon - 1] fp32 softmax rows of the last `ncon` tokens over tokens 1 .. ntok-ncon-1
 // compact: queries are only CLS + the last `ncon` (concept) tokens of every image; out is [B * (1 + ncon), heads * 64]
+// rev: process the (image, head) pairs from the last image to the first (serpentine launch order)
 int ch_attention(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out, hipStream_t s, float *cattn = nullptr,
-                 int ncon = 0, bool compact = false);
+                 int ncon = 0, bool compact = false, bool rev = false);
 
 // ---- head.hip ------------------------------------------------------------------------------------------------
 struct HeadParams {

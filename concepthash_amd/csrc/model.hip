@@ -64,11 +64,12 @@ struct ch_model {
         std::vector<double> flops;
         size_t n = 0;
     } prof[CH_MAX_STREAMS];  // one per micro-batch stream
-    // optional (CH_STREAMS=2): two micro-batches on two HIP streams, so memory-bound launches of one chain (LayerNorm,
-    // epilogue-heavy GEMMs) co-run with MFMA-bound launches of the other.  Measured +8.8 % images/s at B = 256 (16.0k -> 17.5k);
-    // only LDS-free kernels can share a CU with the 128 KB ping-pong GEMM, so the overlap is partial.  Not the default:
-    // per-launch durations (and the roofline computed from them) stop describing the kernels once launches overlap.
-    int nstreams = 1;
+    // CH_STREAMS micro-batches (default 2) on as many HIP streams: memory-bound launches of one chain (adapter up-projection,
+    // attention, epilogue-heavy GEMM tails) co-run with MFMA-bound launches of the other, and partly filled last rounds of
+    // tiles get filled.  Rows are independent, so the outputs are bit-identical for every value.  Measured at B = 256:
+    // 1 -> 2 streams +8 % images/s, 3 and 4 no better.  CH_STREAMS=1 is what a per-kernel profile wants:
+    // per-launch durations stop describing single kernels once launches overlap.
+    int nstreams = 2;
     hipStream_t aux_stream[CH_MAX_STREAMS - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[CH_MAX_STREAMS - 1] = {};
     // workspace
@@ -78,6 +79,11 @@ struct ch_model {
     unsigned *splitk_cnt[CH_MAX_STREAMS] = {};
     // final-layer row pruning: compact fp32 copy of the residual rows the head reads, [max_batch * (1 + Q) (+pad), D]
     bool prune_last = true;
+    // Serpentine launch order (CH_SERPENTINE=1): every row-streaming launch of a chain walks its row
+    // tiles in the direction opposite to its predecessor's, so that it starts on the rows the predecessor wrote LAST -- the
+    // ones that should still be in the 256 MB Infinity Cache.  Measured: no gain (12.44 vs 12.39 ms per step) -> off.
+    bool serpentine = false;
+    int pp_sched = 0;  // CH_GEMM_PP_SCHED: schedule of the 256x256 GEMM (gemm_pp.hip)
     int pp_min_k = 0;  // CH_GEMM_PP_MIN_K at creation (tests: sends small-K GEMMs of a small fixture to the 256x256 kernel)
     float *Hc = nullptr;
     float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn
@@ -453,7 +459,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         GemmParams p{};
         p.X = m->PATCH; p.W = mm->patch_w; p.M = B * np; p.N = D; p.K = mm->Kp; p.X_rows_alloc = m->prow_alloc;
         p.bias = nullptr; p.resid = m->H; p.ldr = D; p.pos = mm->pos; p.tokens_per_img = ntok; p.patches_per_img = np;
-        p.pp_min_k = mm->pp_min_k;
+        p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched;
         if (int e = ch_gemm_bf16(p, EPI_PATCH, s)) return e;
     }
     const LayerW &w0 = mm->layers[0];
@@ -471,13 +477,15 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         bf16_t *hb_out = nullptr;
     };
     const bool fold = mm->ln_fold && c.adapter_dim > 0 && !mm->use_fused_adapter;
+    int dir = 0;              // serpentine: flipped before every row-streaming launch of the chain
+    auto next_dir = [&]() { return mm->serpentine ? (dir ^= 1) : 0; };
     int cur_rows = rows;      // rows the GEMMs work on: all token rows, or the compact head rows in the pruned final layer
     float *cur_H = m->H;      // ... and their residual stream
     auto gemm = [&](int cat, int n_true, int k_true, const bf16_t *X, const bf16_t *W, int N, int K, const float *bias,
                     int epi, bf16_t *out, int ldo, const float *scale, const bf16_t *addend = nullptr, const Fold &f = Fold()) {
         mark(mm, pi, cat, 2.0 * cur_rows * (double)n_true * k_true, s);
         GemmParams p{};
-        p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi]; p.pp_min_k = mm->pp_min_k;
+        p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi]; p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.rev = next_dir();
         p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
         p.X = X; p.W = W; p.M = cur_rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
@@ -539,7 +547,8 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         const bool pruned = prune && fold && mm->prune_last && i == nlayers - 1 && nlayers == c.layers;
         const int nq = 1 + c.ncontext;
         mark(mm, pi, CH_CAT_ATTENTION, 4.0 * B * (double)(pruned ? nq : ntok) * ntok * D, s);
-        if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, i == nlayers - 1 ? concept_attn : nullptr, c.ncontext, pruned))
+        if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, i == nlayers - 1 ? concept_attn : nullptr, c.ncontext, pruned,
+                                 next_dir() != 0))
             return e;
         if (pruned) {
             // from here on every buffer holds B * (1 + Q) compact rows (image-major: CLS, then the concept tokens)
@@ -626,9 +635,20 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
     m->ntok = 1 + m->np + cfg->ncontext;
     m->Kp = (int)round_up64(3 * cfg->patch * cfg->patch, 64);
     if (const char *e = getenv("CH_FUSED_ADAPTER")) m->use_fused_adapter = atoi(e) != 0;
+#ifndef CH_EXPERIMENTS
+    if (m->use_fused_adapter) {
+        ch_set_error("CH_FUSED_ADAPTER=1: the fused adapter kernel is an experiment and not part of this build (CH_BUILD_EXPERIMENTS=1)");
+        delete m;
+        return 2;
+    }
+#endif
     if (const char *e = getenv("CH_LN_FOLD")) m->ln_fold = atoi(e) != 0;
     if (const char *e = getenv("CH_PRUNE_LAST")) m->prune_last = atoi(e) != 0;
     if (const char *e = getenv("CH_GEMM_PP_MIN_K")) m->pp_min_k = atoi(e);
+    if (const char *e = getenv("CH_SERPENTINE")) m->serpentine = atoi(e) != 0;
+#ifdef CH_EXPERIMENTS
+    if (const char *e = getenv("CH_GEMM_PP_SCHED")) m->pp_sched = atoi(e) == 1 ? 1 : 0;
+#endif
     if (const char *e = getenv("CH_STREAMS")) m->nstreams = std::max(1, std::min(atoi(e), CH_MAX_STREAMS));
     bool aux_ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; aux_ok && i < CH_MAX_STREAMS - 1; ++i)
@@ -825,6 +845,10 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
     if (int e = debug_attach_splitk(p)) return e;
     if (variant == 1) return ch_gemm_bf16_v1(p, epi, s);
     if (variant == 2) return ch_gemm_bf16_pp(p, epi, s);
+    if (variant == 4) {
+        p.pp_sched = 1;
+        return ch_gemm_bf16_pp(p, epi, s);
+    }
     if (variant == 3) return ch_gemm_bf16_dp(p, epi, s);
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
@@ -846,12 +870,19 @@ extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_a
     if (int e = debug_attach_splitk(p)) return e;
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
-    if (variant == 1 || variant == 2) ch_gemm_set_variant(variant);
+    if (variant == 1 || variant == 2 || variant == 4) ch_gemm_set_variant(variant);
     const int rc = ch_gemm_bf16(p, epi, s);
-    if (variant == 1 || variant == 2) ch_gemm_set_variant(0);
+    if (variant == 1 || variant == 2 || variant == 4) ch_gemm_set_variant(0);
     return rc;
 }
 extern "C" void ch_debug_set_gemm_variant(int32_t v) { ch_gemm_set_variant(v); }
+extern "C" int32_t ch_debug_experiments_built(void) {
+#ifdef CH_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int ch_debug_attention(const void *qkv, int32_t B, int32_t ntok, int32_t heads, void *out, void *stream) {
     CH_REQUIRE(qkv && out, "debug_attention: null pointer");

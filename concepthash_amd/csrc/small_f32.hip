@@ -105,6 +105,29 @@ __global__ void bn_fold_kernel(const float *w, const float *b, const float *mean
     shift[i] = b[i] - mean[i] * sc;
 }
 
+// LayerNorm fold of a Linear, done once at model build:
+// Wd' = bf16(Wd * gamma) (rows >= b zero), c[n] = sum_k float(Wd'[n][k]), d[n] = sum_k beta[k] * Wd[n][k] + bd[n]
+__global__ void fold_ln_kernel(const float *Wd, const float *bd, const float *gamma, const float *beta, int b, int bpad, int D,
+                               bf16_t *Wdf, float *c, float *d) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= bpad) return;
+    float cs = 0.f, ds = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const float w = n < b ? Wd[(size_t)n * D + k] : 0.f;
+        const bf16_t wb = f2bf(w * gamma[k]);
+        Wdf[(size_t)n * D + k] = wb;
+        cs += bf2f(wb);
+        ds += beta[k] * w;
+    }
+    cs = wave_sum(cs);
+    ds = wave_sum(ds);
+    if (lane == 0) {
+        c[n] = cs;
+        d[n] = ds + (n < b ? bd[n] : 0.f);
+    }
+}
+
 }  // namespace
 
 int ch_small_linear(const float *x, int rows, int in_f, const float *W, const float *b, int out_f, int act, float *y,
@@ -149,6 +172,13 @@ int ch_bn_fold(const float *w, const float *b, const float *mean, const float *v
                float *shift, hipStream_t s) {
     hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, s, w, b, mean, var, n, eps, scale,
                        shift);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+int ch_fold_ln(const float *Wd, const float *bd, const float *gamma, const float *beta, int b, int bpad, int D, bf16_t *Wdf,
+               float *c, float *d, hipStream_t s) {
+    hipLaunchKernelGGL(fold_ln_kernel, dim3((unsigned)ceil_div64(bpad, 4)), dim3(256), 0, s, Wd, bd, gamma, beta, b, bpad, D, Wdf,
+                       c, d);
     CH_LAUNCH_CHECK();
     return 0;
 }

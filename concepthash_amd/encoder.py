@@ -10,6 +10,7 @@ import ctypes
 import math
 from typing import Dict, Iterable, Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -43,18 +44,71 @@ def infer_config(sd: Dict[str, torch.Tensor], heads: Optional[int] = None) -> di
     return cfg
 
 
+def interpolate_pos_embedding(pos: torch.Tensor, new_grid: int) -> torch.Tensor:
+    """Position-embedding table for an input resolution other than the pretrain one: `interpolate_pos_encoding`
+    (models/arch/coop.py:429-450; twin models/backbone/clip.py:69-89), square inputs.
+
+    pos [1 + g*g, D] -> [1 + new_grid^2, D]: the class row is kept, the g x g patch grid is resized with the arithmetic of the
+    call the reference makes -- `F.interpolate(scale_factor=(new_grid + 0.1) / g, mode="bicubic")`, align_corners False:
+    source coordinate (dst + 0.5) / scale - 0.5, Keys cubic with A = -0.75 on the four neighbours, indices clamped to the grid.
+    The table does not depend on the image, so it is folded once when the model is built (host, fp32) instead of per forward."""
+    pos = pos.detach().to("cpu", torch.float32)
+    n = pos.shape[0] - 1
+    g = int(round(math.sqrt(n)))
+    if g * g != n:
+        raise ValueError(f"position embedding has {n + 1} rows; expected 1 + grid^2")
+    if new_grid == g:
+        return pos.clone()
+    grid = pos[1:].reshape(g, g, -1).numpy().astype(np.float32)
+    inv_scale = np.float32(1.0) / np.float32((new_grid + 0.1) / g)      # torch: scale = 1 / scale_factor (fp32 arithmetic)
+    A = np.float32(-0.75)
+
+    def taps(o):
+        real = inv_scale * np.float32(o + 0.5) - np.float32(0.5)
+        i = int(math.floor(real))
+        t = np.float32(real - i)
+
+        def c1(x):   # |x| <= 1
+            return ((A + 2) * x - (A + 3)) * x * x + 1
+
+        def c2(x):   # 1 < |x| < 2
+            return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+        w = np.array([c2(t + 1), c1(t), c1(1 - t), c2(2 - t)], dtype=np.float32)
+        idx = np.clip(np.arange(i - 1, i + 3), 0, g - 1)
+        return idx, w
+
+    rows = [taps(o) for o in range(new_grid)]
+    out = np.empty((new_grid, new_grid, grid.shape[2]), dtype=np.float32)
+    for oy, (iy, wy) in enumerate(rows):
+        for ox, (ix, wx) in enumerate(rows):
+            patch = grid[np.ix_(iy, ix)]                                 # [4, 4, D]
+            # torch accumulates the horizontal interpolation of each of the four rows, then the vertical one
+            horiz = (patch * wx[None, :, None]).sum(1, dtype=np.float32)
+            out[oy, ox] = (horiz * wy[:, None]).sum(0, dtype=np.float32)
+    return torch.cat([pos[:1], torch.from_numpy(out.reshape(new_grid * new_grid, -1))], dim=0)
+
+
 class ConceptHashEncoder:
     """ViT + concept tokens + hashing head on one MI355X, through the C-ABI."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], heads: Optional[int] = None, upt_heads: int = 8,
                  act: str = "quick_gelu", max_batch: int = 256, device: Optional[torch.device] = None,
-                 ln_eps: float = 1e-5, bn_eps: float = 1e-5):
+                 ln_eps: float = 1e-5, bn_eps: float = 1e-5, image_size: Optional[int] = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("ConceptHashEncoder needs a GPU (MI355X); there is no CPU fallback")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         cfg = infer_config(state_dict, heads)
         cfg.update(upt_heads=upt_heads, act={"quick_gelu": 0, "gelu": 1}[act], max_batch=max_batch)
+        self.pretrain_image_size = cfg["image_size"]
+        if image_size is not None and int(image_size) != cfg["image_size"]:
+            # input resolution other than the pretrain one: interpolated position table (reference coop.py:429-450)
+            if int(image_size) % cfg["patch"]:
+                raise ValueError(f"image_size {image_size} is not a multiple of the patch size {cfg['patch']}")
+            state_dict = dict(state_dict)
+            key = VM + "embeddings.position_embedding.weight"
+            state_dict[key] = interpolate_pos_embedding(state_dict[key], int(image_size) // cfg["patch"])
+            cfg["image_size"] = int(image_size)
         self.cfg = cfg
         c = _lib.ModelConfig(ln_eps=ln_eps, bn_eps=bn_eps, **cfg)
         keep = []

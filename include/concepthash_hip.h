@@ -122,6 +122,10 @@ int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_alloc, const
                      const float *scale_ptr, const void *addend, const float *stats_in, const float *fold_c, float ln_eps,
                      float *stats_out, void *hb_out, void *stream);
 void ch_debug_set_gemm_variant(int32_t variant);
+/* 1 when the library was built with CH_BUILD_EXPERIMENTS=1: the non-dispatched experiment kernels (GEMM variants 3 / 5 / 6 of
+ * the taps above, the fused adapter kernel behind CH_FUSED_ADAPTER=1 and ch_debug_adapter) exist; 0 in the product build, where
+ * those taps return an error. */
+int32_t ch_debug_experiments_built(void);
 /* How many GEMMs the dispatcher has sent to the 128x128 (which = 0) / 256x256 ping-pong (which = 1) kernel since the
  * library was loaded: lets a parity test prove which kernel produced the output it compared. */
 int64_t ch_debug_gemm_dispatch_count(int32_t which);

@@ -161,13 +161,15 @@ class LGHWithoutText(nn.Module):
     def _projected_state_dict(self):
         return super().state_dict()
 
-    def _ensure_engine(self, device) -> ConceptHashEncoder:
-        key = (str(device), tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()))
+    def _ensure_engine(self, device, image_size=None) -> ConceptHashEncoder:
+        """One engine per (device, weights version, input resolution): a resolution other than the pretrain one gets the
+        interpolated position table (reference interpolate_pos_encoding, coop.py:429-450), folded when the engine is built."""
+        key = (str(device), image_size, tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()))
         if self._engine is None or self._engine_key != key:
             if self._engine is not None:
                 self._engine.close()
             self._engine = ConceptHashEncoder(self._projected_state_dict(), heads=self._heads, upt_heads=self._upt_heads,
-                                              act=self._act, max_batch=self.max_batch, device=device)
+                                              act=self._act, max_batch=self.max_batch, device=device, image_size=image_size)
             self._engine_key = key
         return self._engine
 
@@ -176,7 +178,9 @@ class LGHWithoutText(nn.Module):
             raise NotImplementedError("training forward/backward is out of scope for the MI355X path (DESIGN.md section 8)")
         if not x.is_cuda:
             raise RuntimeError("LGHWithFixedPrompt.forward needs a GPU tensor; there is no CPU fallback")
-        eng = self._ensure_engine(x.device)
+        if x.dim() != 4 or x.shape[-1] != x.shape[-2]:
+            raise ValueError("LGHWithFixedPrompt.forward expects square [B, 3, S, S] inputs")
+        eng = self._ensure_engine(x.device, int(x.shape[-1]))
         want = ["codes", "logits_cont", "logits_bin", "hash_features"]
         if self.return_concept_attention:
             want.append("concept_attn")

@@ -134,8 +134,21 @@ def embeddings(sd, images: torch.Tensor, R: _R) -> torch.Tensor:
     x = torch.cat([cls, pe], dim=1)
     pos = sd[VM + "embeddings.position_embedding.weight"].float()
     if pos.shape[0] != x.shape[1]:
-        raise ValueError("oracle covers the pretrain resolution only (reference early-return, coop.py:433-434)")
+        pos = interpolate_pos_encoding(pos, images.shape[2], images.shape[3], p)
     return x + pos.unsqueeze(0)
+
+
+def interpolate_pos_encoding(pos: torch.Tensor, w: int, h: int, patch: int) -> torch.Tensor:
+    """interpolate_pos_encoding (models/arch/coop.py:429-450): bicubic resize of the position-embedding grid for inputs other
+    than the pretrain resolution -- the same torch call with the same arguments ((w0 + 0.1) / sqrt(N) scale factors)."""
+    N = pos.shape[0] - 1
+    g = int(math.sqrt(N))
+    D = pos.shape[1]
+    w0, h0 = w // patch + 0.1, h // patch + 0.1
+    grid = F.interpolate(pos[1:].reshape(1, g, g, D).permute(0, 3, 1, 2), scale_factor=(w0 / math.sqrt(N), h0 / math.sqrt(N)),
+                         mode="bicubic")
+    assert int(w0) == grid.shape[-2] and int(h0) == grid.shape[-1]
+    return torch.cat([pos[:1], grid.permute(0, 2, 3, 1).reshape(-1, D)], dim=0)
 
 
 def attention(sd, pre: str, x_ln: torch.Tensor, heads: int, R: _R, want_probs=False):

@@ -21,12 +21,19 @@ from oracle import encoder_oracle as eo
 
 GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
+# name -> input resolution when it differs from the model's pretrain resolution (reference interpolate_pos_encoding,
+# models/arch/coop.py:429-450: bicubic resize of the position-embedding grid)
+INPUT_SIZE = {"encode_interp": 96}
+
 FIXTURES = {
     # name: (vision dims, nbit, nclass, adapter b, center_dim, batch, hidden_act)
     "encode_tiny": (dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
                          image_size=64, patch_size=16, projection_dim=32), 16, 10, 384, 32, 3, "quick_gelu"),
     "encode_hd64": (dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
                          image_size=64, patch_size=16, projection_dim=64), 64, 20, 64, 48, 4, "quick_gelu"),
+    # pretrain grid 4 x 4 (64 px), evaluated at 96 px (6 x 6): 1 + 36 + 4 = 41 tokens
+    "encode_interp": (dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                           image_size=64, patch_size=16, projection_dim=64), 64, 20, 64, 48, 2, "quick_gelu"),
 }
 # Fixtures whose weights and images are rounded to bf16-representable values BEFORE the reference runs (stored as the
 # uint16 bit patterns, "sdbf/..." / "inbf/...": half the bytes, and the HIP path's weight conversion is exact).
@@ -111,7 +118,7 @@ def main():
         missing, unexpected = model.load_state_dict(syn, strict=False)
         assert not unexpected, unexpected
         model.eval()
-        x = eo.synthetic_images(batch, vd["image_size"], seed=5)
+        x = eo.synthetic_images(batch, INPUT_SIZE.get(name, vd["image_size"]), seed=5)
         with torch.no_grad():
             feats, out = model(x)
         sd = model.state_dict()

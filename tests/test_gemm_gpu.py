@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_BIAS_RESID, EPI_SCALE_RESID = range(5)
 
 
+def _need_experiments():
+    """Variants 3 / 5 / 6 (gemm_dp / gemm_ppp / gemm_pq: measured, lost) exist only in an experiments
+    build (CH_BUILD_EXPERIMENTS=1); the product library does not carry them."""
+    from concepthash_amd import _lib
+    if not _lib.load().ch_debug_experiments_built():
+        pytest.skip("experiment kernels are not part of the product build (CH_BUILD_EXPERIMENTS=1 builds them)")
+
+
 def _gemm(variant, X, W, bias, M, epi, out=None, resid=None, scale=None, addend=None):
     from concepthash_amd import _lib
     lib = _lib.load()
@@ -51,6 +59,8 @@ def _inputs(M, N, K, seed=0):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 768, 768), (2011, 2304, 768), (513, 768, 3072), (700, 3072, 768),
                                    (300, 768, 384), (257, 256, 640)])
 def test_gemm_against_torch_fp32(variant, M, N, K):
+    if variant == 3:
+        _need_experiments()
     X, W, bias, resid0 = _inputs(M, N, K)
     scale = torch.tensor([0.7], device="cuda")
     for epi in (EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_BIAS_RESID, EPI_SCALE_RESID):
@@ -83,25 +93,19 @@ def test_pingpong_equals_two_phase_bitwise_and_is_race_free(M, N, K):
     r_ref = resid0.clone()
     _gemm(1, X, W, bias, M, EPI_BIAS_RESID, out=ref, resid=r_ref)
     junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")   # 256 MiB: evicts L2 + MALL when written
-    for it in range(6):
-        out = torch.zeros_like(ref)
-        r = resid0.clone()
-        if it % 2:
-            junk.fill_(float(it))
-        _gemm(2 + it // 3, X, W, bias, M, EPI_BIAS_RESID, out=out, resid=r)        # iterations 0-2: ping-pong, 3-5: dual-WG ring
-        torch.cuda.synchronize()
-        assert torch.equal(out[:M].view(torch.int16), ref[:M].view(torch.int16)), f"iteration {it}"
-        assert torch.equal(r[:M], r_ref[:M]), f"iteration {it}"
-
-
-def test_unsupported_shapes_are_rejected_loudly():
-    X, W, bias, _ = _inputs(256, 384, 768)
-    out = torch.empty(256, 384, dtype=torch.bfloat16, device="cuda")
-    with pytest.raises(RuntimeError, match="gemm_pp"):
-        _gemm(2, X, W, bias, 256, EPI_BIAS, out=out)             # N % 256 != 0 -> only the 128x128 kernel takes it
-    _gemm(0, X, W, bias, 256, EPI_BIAS, out=out)                 # auto dispatch falls to the 128x128 kernel
-    with pytest.raises(RuntimeError, match="multiple of 128"):
-        _gemm(1, X, W[:100], bias, 256, EPI_BIAS, out=out)
+    from concepthash_amd import _lib
+    # 2: ping-pong, four phases per K-tile; 4: the same kernel's coarse schedule (two phases per K-tile); 3: dual-WG ring (experiment)
+    variants = [2] + ([4, 3] if _lib.load().ch_debug_experiments_built() else [])
+    for variant in variants:
+        for it in range(4):
+            out = torch.zeros_like(ref)
+            r = resid0.clone()
+            if it % 2:
+                junk.fill_(float(it))
+            _gemm(variant, X, W, bias, M, EPI_BIAS_RESID, out=out, resid=r)
+            torch.cuda.synchronize()
+            assert torch.equal(out[:M].view(torch.int16), ref[:M].view(torch.int16)), f"variant {variant} iteration {it}"
+            assert torch.equal(r[:M], r_ref[:M]), f"variant {variant} iteration {it}"
 
 
 @pytest.mark.parametrize("M,N,K", [(51456, 2304, 768), (51456, 768, 768), (4000, 3072, 768), (2500, 768, 3072), (256, 256, 128),
@@ -109,6 +113,7 @@ def test_unsupported_shapes_are_rejected_loudly():
 def test_persistent_pingpong_equals_two_phase_bitwise(M, N, K):
     """gemm_ppp.hip (variant 5): tiles streamed by persistent workgroups with cross-tile prefetch; bf16-output epilogues.
     Same MFMA / k order as the 128x128 kernel -> bit-identical outputs; repeated with cold and warm caches as a race screen."""
+    _need_experiments()
     X, W, bias, _ = _inputs(M, N, K, seed=2)
     junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
     for epi in (EPI_BIAS, EPI_QGELU):
@@ -182,11 +187,13 @@ def test_statistics_producers(variant, M, N, K):
     assert bool(torch.isnan(stats[M:]).all())
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 @pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (700, 3072, 768), (515, 384, 768), (300, 256, 128), (257, 512, 1280)])
 def test_layernorm_folded_consumers(variant, M, N, K):
     """y = act(LN(x) W^T + b) computed as act(rstd * (x W'^T - mean * c) + d) with W' = bf16(W * gamma)."""
-    if variant == 2 and N % 256:
+    if variant == 4:
+        _need_experiments()
+    if variant in (2, 4) and N % 256:
         pytest.skip("the 256x256 kernel needs N % 256 == 0")
     g = torch.Generator(device="cuda").manual_seed(5)
     Mp = (M + 255) // 256 * 256
@@ -272,6 +279,7 @@ def test_splitk_tail_of_the_pingpong_kernel(splitk, M, N, K):
 def test_256x128_pingpong_equals_two_phase_bitwise_and_is_race_free(M, N, K):
     """gemm_pq.hip (variant 6): 256x128 tile, two phases per K-tile, three 16 KB units per K-tile.  Same MFMA and the same k
     order per output element as the 128x128 kernel -> bit-identical for every epilogue; repeated with cold and warm caches."""
+    _need_experiments()
     X, W, bias, resid0 = _inputs(M, N, K, seed=9)
     scale = torch.tensor([0.7], device="cuda")
     addend = torch.randn(X.shape[0], N, device="cuda").to(torch.bfloat16)

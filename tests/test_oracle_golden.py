@@ -49,6 +49,29 @@ def test_encode_matches_reference_outputs_at_201_tokens():
     assert bool(((out["codes"] > 0) == (torch.from_numpy(z["out/codes"]) > 0)).all())
 
 
+def test_non_pretrain_resolution_matches_reference_outputs():
+    """encode_interp: the reference model pretrained at 64 px (4 x 4 grid) evaluated on 96 px inputs -- its
+    interpolate_pos_encoding (models/arch/coop.py:429-450) resizes the position table to 6 x 6.  Oracle vs reference outputs, and
+    the product's load-time fold of that table (concepthash_amd.encoder.interpolate_pos_embedding) vs the torch call."""
+    from concepthash_amd.encoder import interpolate_pos_embedding
+    sd, z = load_fixture("encode_interp")
+    x = torch.from_numpy(z["in/images"])
+    assert x.shape[-1] == 96 and sd[eo.VM + "embeddings.position_embedding.weight"].shape[0] == 17
+    stages = {}
+    out = eo.encode(sd, x, heads=int(z["meta/heads"]), upt_heads=int(z["meta/upt_heads"]), act=str(z["meta/act"]), stages=stages)
+    for key in ("codes", "hash_features", "logits_cont", "logits_bin", "logits_concept", "image_features"):
+        ref = torch.from_numpy(z["out/" + key])
+        assert torch.allclose(out[key], ref, atol=ATOL, rtol=0), (key, float((out[key] - ref).abs().max()))
+    assert stages["h0"].shape == (2, 1 + 36 + 4, 128)
+    assert torch.allclose(stages["h0"], torch.from_numpy(z["out/h0"]), atol=ATOL, rtol=0)
+    pos = sd[eo.VM + "embeddings.position_embedding.weight"]
+    for new_grid in (6, 3, 9):
+        want = eo.interpolate_pos_encoding(pos, new_grid * 16, new_grid * 16, 16)
+        got = interpolate_pos_embedding(pos, new_grid)
+        assert got.shape == want.shape and torch.allclose(got, want, atol=1e-5, rtol=0), float((got - want).abs().max())
+    assert torch.equal(interpolate_pos_embedding(pos, 4), pos)
+
+
 def test_state_dict_key_layout_matches_reference():
     """Every reference state_dict key is either consumed by the oracle/HIP loader or a documented alias."""
     sd, z = load_fixture("encode_tiny")

@@ -91,6 +91,29 @@ def test_reference_golden_at_201_tokens(dev, monkeypatch, pp_min_k):
     assert bool((refc[flips].abs() < 2e-2 * refc.pow(2).mean().sqrt()).all())
 
 
+def test_non_pretrain_resolution_against_reference_golden(dev):
+    """inputs other than the pretrain resolution.  tests/golden/encode_interp.npz = the reference model
+    pretrained at 64 px evaluated at 96 px (interpolate_pos_encoding, models/arch/coop.py:429-450); here the interpolated table
+    is folded when the engine is built (ConceptHashEncoder(image_size=96)), and models.arch.coop picks the engine by input size."""
+    sd, z = load_fixture("encode_interp")
+    heads = int(z["meta/heads"])
+    x = torch.from_numpy(z["in/images"]).to(dev)
+    enc = _encoder(sd, heads, max_batch=2, image_size=96)
+    assert enc.ntok == 1 + 36 + 4 and enc.pretrain_image_size == 64
+    out = enc.encode(x, want=("codes", "hash_features", "logits_cont", "image_features"))
+    torch.cuda.synchronize()
+    for key in ("codes", "hash_features", "logits_cont", "image_features"):
+        e = _rel_err(out[key].cpu(), torch.from_numpy(z["out/" + key]))
+        print(f"96 px on a 64 px model, {key}: rel err vs reference golden {e:.2e}")
+        assert e < 2e-2, key
+    h0 = enc.hidden_states(x, 0).cpu()
+    assert _rel_err(h0, torch.from_numpy(z["out/h0"])) < 1e-2
+    with pytest.raises(ValueError):
+        _encoder(sd, heads, max_batch=2).encode(x)              # the 64 px engine refuses 96 px inputs loudly
+    with pytest.raises(ValueError):
+        _encoder(sd, heads, image_size=100)                     # not a multiple of the patch size
+
+
 # ---- (c) + (g) ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg_name,batch,nbit,nclass", [("vit_l14", 1, 128, 555), ("vit_s16", 2, 16, 200), ("vit_b16", 2, 64, 200)])
 def test_full_depth_against_fp32_and_fold_emulating_oracle(dev, cfg_name, batch, nbit, nclass):

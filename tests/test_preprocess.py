@@ -67,7 +67,7 @@ def test_gpu_preprocess_equals_the_pil_chain_bit_for_bit():
     got = GpuPreprocess(160, 128, *_NORMS[1], out_dtype=torch.float32, device=dev)(pixels, sizes).cpu()
     assert torch.equal(got, want)
     with pytest.raises(ValueError):
-        GpuPreprocess(256, 224, device=dev)(torch.zeros(5000 * 40 * 3, dtype=torch.uint8, device=dev), [(5000, 40)])   # > 15x
+        GpuPreprocess(256, 224, device=dev)(torch.zeros(4200 * 4100 * 3, dtype=torch.uint8, device=dev), [(4200, 4100)])   # 16x down
     with pytest.raises(TypeError):
         GpuPreprocess(256, 224, device=dev)(pixels.float(), sizes)
 

@@ -48,7 +48,7 @@ got = dict(H=buf(0, D, torch.float32), Xn=buf(1, D, torch.bfloat16), QKV=buf(2, 
 VM = eo.VM
 pre = VM + "encoder.layers.0."
 st = {}
-eo.encode(sd, x, heads=heads, with_pooled=False, stages=st)   # only for h0 (fp32, identical to the HIP tap at 2e-6)
+eo.encode(sd, x, heads=heads, with_pooled=False, stages=st, emulate_bf16=True)   # only for h0: bf16 patch-embed operands, equals the HIP tap to 2e-6
 h = st["h0"]
 bf = eo._bf16
 hd = D // heads
