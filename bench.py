@@ -227,6 +227,10 @@ def main():
     if rank == 0:
         result["pcie_inclusive"] = pcie_block(torch, enc, images, B)
 
+    # ---- decode-inclusive variant (outside the timed region): decoded uint8 bytes -> GPU pre-processing -> encode ------------
+    if rank == 0:
+        result["decode_inclusive"] = decode_block(torch, enc, B, dev)
+
     # ---- Hamming blocks (outside the timed region) -------------------------------------------------------------------
     if not args.no_hamming_scan:
         hb = hamming_block(torch, np, rt, syn, dist, dev, rank, world)
@@ -264,9 +268,9 @@ def roofline_block(prof, args, enc, B, prof_ms_per_step, codes_same):
     up_bytes = rows_tok * (D_ * 4 * 2 + D_ * 2 * 2 + b_pad * 2) + D_ * b_pad * 2      # fp32 RMW + bf16 addend + bf16 copy + X, W
     down_bytes = rows_tok * (D_ * 2 + b_pad * 2) + D_ * b_pad * 2
     instances = [
-        ("gemm_pp_kernel<EPI_BIAS_STATS> (out_proj + fc2, 256x256 ping-pong)", "gemm_pp_kernel<6, 0>", ["gemm_out", "gemm_fc2"], None),
-        ("gemm_pp_kernel<EPI_FOLD_QUICKGELU> (fc1)", "gemm_pp_kernel<9, 0>", ["gemm_fc1"], None),
-        ("gemm_pp_kernel<EPI_FOLD_BIAS> (qkv)", "gemm_pp_kernel<8, 0>", ["gemm_qkv"], None),
+        ("gemm_pp_kernel<EPI_BIAS_STATS> (out_proj + fc2, 256x256 ping-pong)", "gemm_pp_kernel<6, 0, 0>", ["gemm_out", "gemm_fc2"], None),
+        ("gemm_pp_kernel<EPI_FOLD_QUICKGELU> (fc1)", "gemm_pp_kernel<9, 0, 0>", ["gemm_fc1"], None),
+        ("gemm_pp_kernel<EPI_FOLD_BIAS> (qkv)", "gemm_pp_kernel<8, 0, 0>", ["gemm_qkv"], None),
         ("gemm_bf16_kernel<EPI_SCALE_RESID_STATS> (adapter up, 128x128)", "gemm_bf16_kernel<7>", ["gemm_up"], up_bytes),
         ("gemm_bf16_kernel<EPI_FOLD_GELU> (adapter down, 128x128)", "gemm_bf16_kernel<10>", ["gemm_down"], down_bytes),
     ]
@@ -361,6 +365,25 @@ def pcie_block(torch, enc, images, B):
                     f"({host.numel() * 2 / 2**20:.0f} MiB bf16, no overlap); never used for `value`",
             "double_buffered": {"images_per_s": round(B / pipe_s, 1), "ms_per_step": round(pipe_s * 1e3, 3),
                                 "note": "copy of batch i+1 on a side stream under the encode of batch i"}}
+
+
+def decode_block(torch, enc, B, dev):
+    """the evaluation loader's Resize(256, bicubic) -> CenterCrop(224) -> ToTensor -> normalize on the
+    GPU (ch_preprocess, Pillow-exact) in front of the encoder: B decoded 500 x 375 RGB images (the common CUB-200 size) resident
+    in HBM as uint8 -> bf16 NCHW batch -> codes.  JPEG decoding itself is not part of it (CPU workers)."""
+    from concepthash_amd.preprocess import GpuPreprocess
+    h, w = 375, 500
+    gen = torch.Generator(device=dev).manual_seed(5)
+    pixels = torch.randint(0, 256, (B * h * w * 3,), dtype=torch.uint8, device=dev, generator=gen)
+    sizes = [(h, w)] * B
+    pre = GpuPreprocess(256, 224, out_dtype=torch.bfloat16, device=dev)
+    s_pre, batch = _ev_time(torch, lambda: pre(pixels, sizes), 5)
+    s_all, _ = _ev_time(torch, lambda: enc.encode(pre(pixels, sizes), want=("codes", "packed")), 5)
+    return {"images_per_s": round(B / s_all, 1), "ms_per_step": round(s_all * 1e3, 3), "preprocess_ms": round(s_pre * 1e3, 3),
+            "preprocess_images_per_s": round(B / s_pre, 1),
+            "preprocess_gbs": round((B * h * w * 3 + B * 3 * 224 * 224 * 2) / s_pre / 1e9, 1),
+            "note": f"{B} decoded {w}x{h} uint8 RGB images resident in HBM -> ch_preprocess (bit-equal to the PIL chain) -> "
+                    f"ch_encode; host-side descriptor planning included; never used for `value`"}
 
 
 def _ev_time(torch, fn, reps):

@@ -59,7 +59,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
         __builtin_amdgcn_sched_barrier(0);                    \
     } while (0)
 
-// DBG bits (timing-only builds, results are garbage): 1 = no global loads, 2 = no LDS fragment reads, 4 = no epilogue
+// DBG bits (timing-only builds, results are garbage): 1 = no global loads, 2 = no LDS fragment reads, 4 = no epilogue;
+// 8 = (results valid) wave 0 stamps s_memtime / s_memrealtime at entry, after the prologue, after the K loop, after the epilogue's
+// last store is issued and after the stores have completed, plus HW_ID / XCC_ID, into p.resid as uint64[tiles][8]
+// (tools/tile_timeline.py)
 // SCHED 0: four phases of 16 MFMAs per K-tile (the guide's 8-phase template); SCHED 1: two phases of 32 MFMAs per K-tile
 // (section "coarse schedule" below): same buffers, same fragments, half the barriers.
 template <int EPI, int DBG = 0, int SCHED = 0>
@@ -69,6 +72,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;  // wr also selects the stagger group (waves 4-7 run one barrier behind)
+    unsigned long long stamp[6] = {};
+    if constexpr (DBG & 8) {
+        stamp[0] = __builtin_amdgcn_s_memrealtime();
+        stamp[1] = __builtin_amdgcn_s_memtime();
+    }
 
     const int tiles_n = p.N / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         PP_BARRIER();
+        if constexpr (DBG & 8) stamp[2] = __builtin_amdgcn_s_memtime();
         if (wr == 1) PP_BARRIER();  // stagger: waves 4-7 run one barrier behind waves 0-3
 
         for (int jj = 0; jj < J; ++jj) {
@@ -398,8 +407,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     }
     // ---- epilogue (gemm_epilogue.h): every wave has passed the balance barrier, so no wave still reads staged operands
     // and no LDS-DMA is in flight (vmcnt(0) in the last iteration); each wave transposes through its own 16 KB.
+    if constexpr (DBG & 8) stamp[3] = __builtin_amdgcn_s_memtime();
     ch_epi::store_tile<EPI, 8>(p, acc, smem + wid * 16384, m0 + wr * 128, n0 + wc * 64, lane,
                                (const float *)(smem + 2 * BUF_BYTES) + 2 * (wr * 128));
+    if constexpr (DBG & 8) {
+        stamp[4] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[5] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned long long *st = (unsigned long long *)p.resid + (size_t)blockIdx.x * 8;
+            st[0] = stamp[0];
+            st[1] = stamp[1];
+            st[2] = stamp[2];
+            st[3] = stamp[3];
+            st[4] = stamp[4];
+            st[5] = stamp[5];
+            st[6] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);
+            st[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 }
 
 // Tail split: with G compute units, tiles = full rounds * G + R.  The R tiles of the last round would keep R units busy for
@@ -487,6 +513,20 @@ int ch_gemm_bf16_pp_dbg(const GemmParams &p0, int dbg, hipStream_t s) {
         PP_DBG_CASE(5)
         PP_DBG_CASE(6)
         PP_DBG_CASE(7)
+        case 8:   // stamped, valid results; EPI_BIAS
+        case 9: { // stamped, EPI_BIAS_QUICKGELU
+            if (!p.resid) return 2;
+            constexpr int lds = 2 * BUF_BYTES + CH_FOLD_LDS_BYTES + 16;
+            if (dbg == 8) {
+                (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI_BIAS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL((gemm_pp_kernel<EPI_BIAS, 8>), dim3(tiles), dim3(NTHREADS), lds, s, p);
+            } else {
+                (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI_BIAS_QUICKGELU, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          lds);
+                hipLaunchKernelGGL((gemm_pp_kernel<EPI_BIAS_QUICKGELU, 8>), dim3(tiles), dim3(NTHREADS), lds, s, p);
+            }
+            break;
+        }
         default: return 2;
     }
     CH_LAUNCH_CHECK();

@@ -852,7 +852,7 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
     if (variant == 3) return ch_gemm_bf16_dp(p, epi, s);
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
-    if (variant >= 21 && variant <= 27) return ch_gemm_bf16_pp_dbg(p, variant - 20, s);  // timing-only builds
+    if (variant >= 21 && variant <= 29) return ch_gemm_bf16_pp_dbg(p, variant - 20, s);  // timing-only / stamped builds
     return ch_gemm_bf16(p, epi, s);
 }
 extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_alloc, const void *W, const float *bias,

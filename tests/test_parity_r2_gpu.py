@@ -54,6 +54,7 @@ def test_reference_golden_at_201_tokens(dev, monkeypatch, pp_min_k):
     heads = int(z["meta/heads"])
     if pp_min_k:
         monkeypatch.setenv("CH_GEMM_PP_MIN_K", str(pp_min_k))
+    monkeypatch.setenv("CH_STREAMS", "1")        # one launch chain, so that the dispatch counts below are per encode call
     enc = _encoder(sd, heads, max_batch=2)
     lib = _lib.load()
     n_small0, n_pp0 = lib.ch_debug_gemm_dispatch_count(0), lib.ch_debug_gemm_dispatch_count(1)
