@@ -83,8 +83,13 @@ def self_launch(args) -> int:
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
+    lines = out0.decode().splitlines()
+    js = [ln for ln in lines if ln.startswith("{")]
+    for ln in lines:                      # library chatter on rank 0's stdout (e.g. gloo's connection notice) goes to stderr:
+        if not js or ln is not js[-1]:    # stdout carries exactly ONE line, the JSON
+            log(ln)
+    if js:
+        print(js[-1], flush=True)
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         log(f"[bench] ranks failed: {bad}")

@@ -21,6 +21,8 @@
 //   last LDS read -- and that read is complete (lgkmcnt(0)) before the reading wave's barrier; a half-tile is first read
 //   one phase after the vmcnt/barrier that retires it.
 // K must be a multiple of 128 (an even number of K-tiles), N a multiple of 256, X padded to a multiple of 256 rows.
+#include <cstdlib>
+
 #include "ch_common.h"
 #include "kernels.h"
 #include "gemm_epilogue.h"
@@ -31,6 +33,7 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;       // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;      // 64 KiB: [X_h0][X_h1][W_h0][W_h1]
 constexpr int NTHREADS = 512;
+constexpr int PP_LDS_BYTES = 2 * BUF_BYTES + CH_FOLD_LDS_BYTES + 16;  // operands + (mean, rstd) table + split-K ticket
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
@@ -458,7 +461,7 @@ void ch_pp_choose_split(GemmParams &p, int tiles) {
 
 template <int EPI, int SCHED>
 int launch_pp_sched(GemmParams &p, int tiles, hipStream_t s) {
-    constexpr int lds = 2 * BUF_BYTES + CH_FOLD_LDS_BYTES + 16;  // operands + (mean, rstd) table + split-K ticket
+    constexpr int lds = PP_LDS_BYTES;
     static ch_once_per_device lds_once;
     if (int e = ch_func_max_lds((const void *)gemm_pp_kernel<EPI, 0, SCHED>, lds, lds_once)) return e;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, 0, SCHED>), dim3(p.split_full + (tiles - p.split_full) * p.split_s), dim3(NTHREADS), lds,
@@ -516,7 +519,7 @@ int ch_gemm_bf16_pp_dbg(const GemmParams &p0, int dbg, hipStream_t s) {
         case 8:   // stamped, valid results; EPI_BIAS
         case 9: { // stamped, EPI_BIAS_QUICKGELU
             if (!p.resid) return 2;
-            constexpr int lds = 2 * BUF_BYTES + CH_FOLD_LDS_BYTES + 16;
+            constexpr int lds = PP_LDS_BYTES;
             if (dbg == 8) {
                 (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<EPI_BIAS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 hipLaunchKernelGGL((gemm_pp_kernel<EPI_BIAS, 8>), dim3(tiles), dim3(NTHREADS), lds, s, p);
