@@ -40,14 +40,17 @@ def _worker(rank, world, port, bounds, remove_first, R, out_dir):
         assert torch.equal(q_all, tt(q))
         idx, dst = sr.topk(q_all, 12)
         ev = sr.evaluate(q_all, tt(ql), R=R, ks=(1, 5, 10), remove_first=remove_first, seg_rows=97)
+        if isinstance(R, list):          # a list of R: one AP pass, per-R results -- keep the layout [nR, Qn]
+            ev["S"], ev["nrel"] = torch.stack(ev["S"]), torch.stack(ev["nrel"])
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=idx.numpy(), dst=dst.numpy(), S=ev["S"].numpy(),
-                 nrel=ev["nrel"].numpy(), hits=ev["hits"].numpy(), total=ev["total"].numpy(), mAP=ev["mAP"],
+                 nrel=ev["nrel"].numpy(), hits=ev["hits"].numpy(), total=ev["total"].numpy(), mAP=np.array(ev["mAP"]),
                  P=np.array(ev["precisions"]), Rc=np.array(ev["recalls"]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bounds,remove_first,R", [([0, 300, 700], False, -1), ([0, 1, 450], True, 40), ([0, 0, 333], False, -1)])
+@pytest.mark.parametrize("bounds,remove_first,R", [([0, 300, 700], False, -1), ([0, 1, 450], True, 40), ([0, 0, 333], False, -1),
+                                                   ([0, 250, 600], True, [5, 100, -1])])
 def test_two_rank_sharded_retrieval_matches_oracle(tmp_path, bounds, remove_first, R):
     from oracle import hamming_oracle as ho
     port = _free_port()
@@ -55,10 +58,17 @@ def test_two_rank_sharded_retrieval_matches_oracle(tmp_path, bounds, remove_firs
     q, ql = ho.synthetic_codes(61, 64, seed=5, nclass=6)
     g, gl = ho.synthetic_codes(bounds[-1], 64, seed=6, nclass=6)
     ridx, rdst = ho.topk(q, g, 12)
-    ref = ho.mean_ap(q, g, ql, gl, R=R, ks=(1, 5, 10), remove_first=remove_first)
+    Rs = R if isinstance(R, list) else [R]
+    refs = [ho.mean_ap(q, g, ql, gl, R=r_, ks=(1, 5, 10), remove_first=remove_first) for r_ in Rs]
+    ref = refs[-1]
     for r in range(2):
         z = np.load(tmp_path / f"r{r}.npz")
         assert np.array_equal(z["idx"], ridx.astype(np.int64)) and np.array_equal(z["dst"], rdst)
+        if isinstance(R, list):
+            for i, rf in enumerate(refs):
+                assert np.array_equal(z["S"][i].view(np.uint64), rf["S"]) and np.array_equal(z["nrel"][i].astype(np.uint32), rf["nrel"])
+                assert abs(float(z["mAP"][i]) - rf["mAP"]) < 1e-12
+            z = dict(z, S=z["S"][-1], nrel=z["nrel"][-1], mAP=z["mAP"][-1])
         assert np.array_equal(z["S"].view(np.uint64), ref["S"])
         assert np.array_equal(z["nrel"].astype(np.uint32), ref["nrel"])
         assert np.array_equal(z["hits"].astype(np.uint32), ref["hits"])
@@ -105,6 +115,12 @@ def _trainer_worker(rank, world, port, out_dir):
         tr.model, tr.criterion = FakeModel(), FakeCriterion()
         meters, out = tr.inference_one_epoch("db", True)
         torch.save({"codes": out["codes"], "labels": out["labels"], "n": meters["loss"].count}, os.path.join(out_dir, f"t{rank}.pt"))
+        # a split with fewer samples than ranks: rank 1's shard is EMPTY -- it must still enter every collective (no hang) and
+        # get the gathered outputs
+        tr.dataset["test"] = SyntheticHashingDataset(5, size=1, image_size=4, seed=3)
+        tr.load_dataloader()
+        m1, o1 = tr.inference_one_epoch("test", True)
+        torch.save({"codes": o1["codes"], "labels": o1["labels"], "n": m1["loss"].count}, os.path.join(out_dir, f"e{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -120,3 +136,8 @@ def test_trainer_shards_encode_and_gathers_in_dataset_order(tmp_path):
     for r in range(2):
         got = torch.load(tmp_path / f"t{r}.pt")
         assert torch.equal(got["codes"], want) and torch.equal(got["labels"], labels) and got["n"] == 40
+    one = SyntheticHashingDataset(5, size=1, image_size=4, seed=3)
+    for r in range(2):          # the one-sample split: rank 1 had no batch, both ranks hold the same gathered result
+        got = torch.load(tmp_path / f"e{r}.pt")
+        assert got["codes"].shape == (1, 8) and torch.equal(got["codes"][0], one[0][0].flatten()[:8]) and got["n"] == 1
+        assert torch.equal(got["labels"][0], one[0][1])
