@@ -17,6 +17,8 @@
 //  * AP:      the same LDS counters, read-modify-write with return: the returned value is the row's position inside its
 //             (query, distance) bucket in gallery order, which with the prefix "base" gives its exact global rank and
 //             relevant-rank; AP numerators are accumulated in 2^-32 fixed point (integer, order independent).
+#include <cstdlib>
+
 #include "../../include/concepthash_hip.h"
 #include "ch_common.h"
 #include "kernels.h"
@@ -265,7 +267,13 @@ struct RankLimits {
 //           when some lane of the wave holds a relevant row in the trip are the four "ranked before" bases gathered (four
 //           independent 8-byte loads in flight) and the AP terms of the relevant rows added -- to NR accumulators, one per
 //           rank limit, so that mAP@R for a list of R, P@k and R@k all come out of a single pass.
-template <int W, int BLK, int MODE, int NR>
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// VM: the gallery block of a trip (codes and labels of four rows) arrives by VMEM broadcast loads -- every lane reads the same
+// address, in-order vmcnt, two blocks in flight -- instead of scalar loads.  SMEM shares lgkmcnt with the LDS atomics and returns
+// out of order, so the scalar form's per-trip `s_waitcnt lgkmcnt(0)` also drains the previous trip's four atomics; with VMEM the
+// row loop of the histogram pass never waits for an atomic, and the AP pass only inside the rare relevant-row branch.
+template <int W, int BLK, int MODE, int NR, bool VM>
 __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restrict__ q, int64_t Qn,
                                                        const uint64_t *__restrict__ g, int64_t G, const void *q_labels,
                                                        const void *g_labels, int LW, int seg_rows,
@@ -337,7 +345,130 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
     };
 
     int j = 0;
-    if (LW == 0) {
+    if (LW == 0 && VM) {
+        constexpr int CV = UB * W / 2;  // dwordx4 loads per block of codes (UB rows x W words x 8 B = CV x 16 B); CV in {2, 4, 6, 8}
+        struct VBlk {
+            u32x4_t c[CV];
+            u32x4_t lab;
+        };
+        VBlk bA, bB;
+        // lane-constant but VGPR-resident running pointers (a uniform pointer would be re-materialised from SGPRs per load)
+        uint32_t zero_v;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+        const char *pc = (const char *)gp + zero_v;
+        const char *pl = (const char *)gl32 + zero_v;
+#define CH_VLOAD(dst, ptr, off) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr) : "memory")
+        // block A of an iteration sits at offset 0 of the running pointers, block B right behind it
+        auto issue_a = [&]() {
+            CH_VLOAD(bA.c[0], pc, 0);
+            CH_VLOAD(bA.c[1], pc, 16);
+            if constexpr (CV > 2) { CH_VLOAD(bA.c[2], pc, 32); CH_VLOAD(bA.c[3], pc, 48); }
+            if constexpr (CV > 4) { CH_VLOAD(bA.c[4], pc, 64); CH_VLOAD(bA.c[5], pc, 80); }
+            if constexpr (CV > 6) { CH_VLOAD(bA.c[6], pc, 96); CH_VLOAD(bA.c[7], pc, 112); }
+            CH_VLOAD(bA.lab, pl, 0);
+        };
+        auto issue_b = [&]() {
+            if constexpr (CV == 2) { CH_VLOAD(bB.c[0], pc, 32); CH_VLOAD(bB.c[1], pc, 48); }
+            if constexpr (CV == 4) { CH_VLOAD(bB.c[0], pc, 64); CH_VLOAD(bB.c[1], pc, 80); CH_VLOAD(bB.c[2], pc, 96); CH_VLOAD(bB.c[3], pc, 112); }
+            if constexpr (CV == 6) {
+                CH_VLOAD(bB.c[0], pc, 96); CH_VLOAD(bB.c[1], pc, 112); CH_VLOAD(bB.c[2], pc, 128); CH_VLOAD(bB.c[3], pc, 144);
+                CH_VLOAD(bB.c[4], pc, 160); CH_VLOAD(bB.c[5], pc, 176);
+            }
+            if constexpr (CV == 8) {
+                CH_VLOAD(bB.c[0], pc, 128); CH_VLOAD(bB.c[1], pc, 144); CH_VLOAD(bB.c[2], pc, 160); CH_VLOAD(bB.c[3], pc, 176);
+                CH_VLOAD(bB.c[4], pc, 192); CH_VLOAD(bB.c[5], pc, 208); CH_VLOAD(bB.c[6], pc, 224); CH_VLOAD(bB.c[7], pc, 240);
+            }
+            CH_VLOAD(bB.lab, pl, 16);
+        };
+#undef CH_VLOAD
+        // wait until all but the youngest `CV + 1` loads (= the other block's) have landed; the "+v" operands pin every use of
+        // the block behind the wait
+        auto landed = [&](VBlk &b, bool other_in_flight) {
+            if (other_in_flight) {
+                if constexpr (CV == 2) asm volatile("s_waitcnt vmcnt(3)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.lab));
+                if constexpr (CV == 4) asm volatile("s_waitcnt vmcnt(5)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.lab));
+                if constexpr (CV == 6)
+                    asm volatile("s_waitcnt vmcnt(7)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.c[4]), "+v"(b.c[5]), "+v"(b.lab));
+                if constexpr (CV == 8)
+                    asm volatile("s_waitcnt vmcnt(9)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.c[4]), "+v"(b.c[5]),
+                                 "+v"(b.c[6]), "+v"(b.c[7]), "+v"(b.lab));
+            } else {
+                if constexpr (CV == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.lab));
+                if constexpr (CV == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.lab));
+                if constexpr (CV == 6)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.c[4]), "+v"(b.c[5]), "+v"(b.lab));
+                if constexpr (CV == 8)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.c[4]), "+v"(b.c[5]),
+                                 "+v"(b.c[6]), "+v"(b.c[7]), "+v"(b.lab));
+            }
+        };
+        auto scan_vblk = [&](const VBlk &b) {
+            uint32_t d[UB], old[UB];
+            bool rel[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int w = 0; w < 2 * W; ++w) {
+                    const int idx = u * 2 * W + w;
+                    acc = bcnt_acc(qw[w] ^ b.c[idx >> 2][idx & 3], acc);
+                }
+                d[u] = acc;
+                rel[u] = valid && ((int32_t)b.lab[u] == qlab);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {  // in row order: two rows of a trip may share a bucket
+                const uint32_t inc = 1u | ((uint32_t)rel[u] << 16);
+                if (MODE == 0)
+                    atomicAdd(col + d[u] * BLK, inc);
+                else
+                    old[u] = atomicAdd(col + d[u] * BLK, inc);
+            }
+            if (MODE == 1) {
+                if (__builtin_amdgcn_ballot_w64(rel[0] | rel[1] | rel[2] | rel[3]) != 0ull) {
+                    uint2 bs[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) bs[u] = *(const uint2 *)(base + brow + 2 * d[u]);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+                        if (rel[u]) account(bs[u], old[u]);
+                }
+            }
+        };
+        // Two blocks in flight, no register copies: {wait A, scan A, re-issue A two blocks ahead, wait B, scan B, re-issue B}.
+        // A wait leaves exactly the other block's CV + 1 loads outstanding.  In MODE 1 the base gathers are compiler-managed
+        // loads: its own waits may drain our prefetch early (slower, never wrong: vmcnt retires in order).
+        const int npair = n / (2 * UB);
+        {   // the query words come from a compiler-managed load: consume them once HERE, or the compiler's own wait for them
+            // (vmcnt(0): it cannot see the asm loads) lands inside the loop and drains the prefetch every iteration
+            uint32_t use = 0;
+#pragma unroll
+            for (int w = 0; w < 2 * W; ++w) use |= qw[w];
+            asm volatile("" ::"v"(use), "v"(qlab));
+        }
+        if (npair > 0) {
+            issue_a();
+            issue_b();
+        }
+        for (int it = 0; it + 1 < npair; ++it) {   // steady state: branch free
+            landed(bA, true);
+            scan_vblk(bA);
+            pc += 2 * UB * W * 8;   // the running pointers now address the next pair
+            pl += 2 * UB * 4;
+            issue_a();
+            landed(bB, true);       // B is older than the A just issued
+            scan_vblk(bB);
+            issue_b();
+        }
+        if (npair > 0) {            // last pair: nothing left to issue
+            landed(bA, true);
+            scan_vblk(bA);
+            landed(bB, false);
+            scan_vblk(bB);
+        }
+        j = npair * 2 * UB;
+        for (; j < n; ++j) row(gp + (size_t)j * W, valid && (gl32[j] == qlab));
+    } else if (LW == 0) {
         uint64_t bufA[UB * W], bufB[UB * W];
         int32_t labA[UB], labB[UB];
         auto load_block = [&](uint64_t (&dst)[UB * W], int32_t (&lab)[UB], int r0) {
@@ -462,19 +593,34 @@ __global__ __launch_bounds__(256) void hist_prefix_kernel(const uint32_t *__rest
     }
 }
 
-template <int W, int BLK, int MODE, int NR>
-int launch_scan_nr(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql, const void *gl, int LW,
+template <int W, int BLK, int MODE, int NR, bool VM>
+int launch_scan_vm(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql, const void *gl, int LW,
                    int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims, int nlim,
                    const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
     const int nseg = (int)ceil_div64(G, seg_rows);
     const size_t lds = sizeof(uint32_t) * (64 * W + 1) * BLK;
     dim3 grid((unsigned)ceil_div64(Qn, BLK), (unsigned)nseg);
     static ch_once_per_device lds_once;
-    if (int e = ch_func_max_lds((const void *)map_scan_kernel<W, BLK, MODE, NR>, (int)lds, lds_once)) return e;
-    hipLaunchKernelGGL((map_scan_kernel<W, BLK, MODE, NR>), grid, dim3(BLK), lds, s, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist,
+    if (int e = ch_func_max_lds((const void *)map_scan_kernel<W, BLK, MODE, NR, VM>, (int)lds, lds_once)) return e;
+    hipLaunchKernelGGL((map_scan_kernel<W, BLK, MODE, NR, VM>), grid, dim3(BLK), lds, s, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist,
                        base, lims, nlim, first_rel, out_S, out_nrel);
     CH_LAUNCH_CHECK();
     return 0;
+}
+
+template <int W, int BLK, int MODE, int NR>
+int launch_scan_nr(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql, const void *gl, int LW,
+                   int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims, int nlim,
+                   const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
+    // Histogram pass: gallery through VMEM broadcast loads (measured 18.9 -> 14.5 ms at 16,384 x 1M x 128 bit, 0.48 -> 0.36 ms at
+    // the NABirds size; CH_HAMMING_VMEM=0 = scalar loads).  AP pass: scalar loads -- there the compiler-managed base gathers
+    // make its own vmcnt(0) waits drain the asm prefetch, and the VMEM form measured slower (39 -> 48 ms).  Same results.
+    static const bool vm_env = !(getenv("CH_HAMMING_VMEM") && atoi(getenv("CH_HAMMING_VMEM")) == 0);
+    if constexpr (MODE == 0) {
+        if (vm_env)
+            return launch_scan_vm<W, BLK, MODE, NR, true>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
+    }
+    return launch_scan_vm<W, BLK, MODE, NR, false>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
 }
 
 template <int W, int BLK>
