@@ -338,3 +338,48 @@ def test_one_pass_multi_limit_evaluation(dev):
         nr, tot = refR["nrel"].astype(np.float64), refR["total"].astype(np.float64)
         assert abs(p_ - float((nr / R).mean())) < 1e-12
         assert abs(r_ - float(np.where(tot > 0, nr / np.maximum(tot, 1), 0).mean())) < 1e-12
+
+
+def test_map_at_config5_size_1m_gallery(dev):
+    """BASELINE.json config 5 size for the mAP path: 1M x 128-bit gallery (16 segments of 62,500 rows, 132 KB of LDS counters per
+    workgroup).  768 queries: S / nrel / hits / total bit-exact against the C oracle for a sample of 48 of them (the oracle ranks
+    1M rows per query), and for ALL of them the 8-way row-sharded evaluation (per-shard histograms -> one prefix -> per-shard AP
+    passes -> integer sum) equals the single call -- the size-independent property."""
+    from concepthash_amd import retrieval as rt
+    from concepthash_amd.distributed import shard_bounds
+    from oracle import hamming_oracle as ho
+    G, Qn, ncls = 1_000_000, 768, 50
+    g, gl = ho.synthetic_codes(G, 128, seed=71, nclass=ncls, flip=0.3)
+    q, ql = ho.synthetic_codes(Qn, 128, seed=72, nclass=ncls, flip=0.3)
+    gq, gg, gql, ggl = _t(q, dev), _t(g, dev), _t(ql, dev), _t(gl, dev)
+    ks = (1, 10, 1000)
+    got = rt.evaluate(gq, gg, gql, ggl, R=[1000, -1], ks=ks)
+    torch.cuda.synchronize()
+    sample = np.arange(0, Qn, 16)
+    for i, R in enumerate((1000, -1)):
+        ref = ho.mean_ap(q[sample], g, ql[sample], gl, R=R, ks=ks)
+        assert np.array_equal(got["S"][i][sample].cpu().numpy().view(np.uint64), ref["S"]), R
+        assert np.array_equal(got["nrel"][i][sample].cpu().numpy().astype(np.uint32), ref["nrel"]), R
+    assert np.array_equal(got["hits"][sample].cpu().numpy().astype(np.uint32), ref["hits"])
+    assert np.array_equal(got["total"][sample].cpu().numpy().astype(np.uint32), ref["total"])
+    # 8 row shards on one GPU == single call, for every query
+    b = shard_bounds(G, 8)
+    qlab, glab, LW = rt.prepare_labels(gql, ggl)
+    seg = rt.map_seg_rows(Qn, b[1] - b[0], 2)
+    nseg = -(-(b[1] - b[0]) // seg)
+    hists = [rt.hamming_hist(gq, gg[b[r]:b[r + 1]], qlab, glab[b[r]:b[r + 1]], LW, seg) for r in range(8)]
+    assert all(h.shape[0] == nseg for h in hists)
+    base_all, totals = rt.hist_prefix(torch.cat(hists))
+    limits, idx_of = rt.normalize_limits([1000, -1] + list(ks))
+    S = torch.zeros(len(limits), Qn, dtype=torch.int64, device=dev)
+    nrel = torch.zeros(len(limits), Qn, dtype=torch.int32, device=dev)
+    for r in range(8):
+        s_r, n_r = rt.hamming_ap_multi(gq, gg[b[r]:b[r + 1]], qlab, glab[b[r]:b[r + 1]], LW, seg,
+                                       base_all[r * nseg:(r + 1) * nseg].contiguous(), limits)
+        S += s_r
+        nrel += n_r
+    for i in range(2):
+        assert torch.equal(S[idx_of[i]], got["S"][i]) and torch.equal(nrel[idx_of[i]], got["nrel"][i])
+    for t in range(len(ks)):
+        assert torch.equal(nrel[idx_of[2 + t]], got["hits"][:, t])
+    assert torch.equal(totals[:, 1], got["total"])
