@@ -19,7 +19,7 @@ def dataloader(d, bs=256, shuffle=False, workers=-1, drop_last=False, sampler=No
     if getattr(d, "in_memory", False):      # tensor-backed datasets need no worker processes
         workers = 0
     return DataLoader(d, bs, shuffle, drop_last=drop_last, num_workers=workers, sampler=sampler,
-                      pin_memory=workers > 0)
+                      pin_memory=workers > 0, collate_fn=getattr(d, "collate_fn", None))
 
 
 class _SequentialSubset(torch.utils.data.Sampler):

@@ -89,3 +89,56 @@ def test_gpu_preprocess_feeds_the_encoder():
     a = enc.encode(batch)["codes"]
     b = enc.encode(torch.stack([_pil_chain(im, 256, 224, 3) for im in imgs]).to(dev).to(torch.bfloat16))["codes"]
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_trainer_with_gpu_preprocess_gives_the_codes_of_the_cpu_chain(tmp_path):
+    """`dataset.gpu_preprocess: true` end to end: list-file dataset of JPEGs of different sizes -> DataLoader workers decode only
+    -> RawImageBatch -> COOPTrainer runs ch_preprocess + ch_encode.  Codes are bit-equal to the run whose CPU workers apply the
+    torchvision-style transform chain (the reference's loader, configs/dataset/cub200.yaml:31-47)."""
+    from concepthash_amd import config as cfglib
+    from concepthash_amd import synthetic as syn
+    from trainers.coop import COOPTrainer
+    from utils import transforms as T
+    from utils.datasets import HashingDataset, OneHot
+    root = tmp_path / "d"
+    (root / "img").mkdir(parents=True)
+    lines = []
+    for i, (h, w) in enumerate(SIZES[:7]):
+        Image.fromarray(_image(h, w, i)).save(root / "img" / f"{i}.png")        # lossless: both runs decode the same pixels
+        lines.append(f"img/{i}.png {i % 3}")
+    (root / "test.txt").write_text("\n".join(lines) + "\n")
+    cfg = dict(syn.CONFIGS["vit_s16"])
+    cfg["L"] = 2
+    sd = syn.synthetic_state_dict(cfg, nbit=32, nclass=3)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            from concepthash_amd.encoder import ConceptHashEncoder
+            self.enc = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=4, device=torch.device("cuda:0"))
+
+        def forward(self, x):
+            out = self.enc.encode(x, want=("codes", "logits_cont", "logits_bin"))
+            return None, out
+
+    class Crit(torch.nn.Module):
+        losses = {}
+
+        def forward(self, out, y):
+            return out["codes"].sum() * 0
+
+    chain = [T.Resize(256, T.interpolation("bicubic")), T.CenterCrop(224), T.ToTensor(), T.normalize_transform(3)]
+    codes = {}
+    for mode in (False, True):
+        conf = cfglib.DictConfig(device="cuda", batch_size=4, model=cfglib.DictConfig(),
+                                 dataset=cfglib.DictConfig(multiclass=False, resize=256, crop=224, norm=3, gpu_preprocess=mode))
+        tr = COOPTrainer(conf)
+        tr.dataset = {"train": [], "db": [], "test": HashingDataset(str(root), "test.txt", transform=chain, target_transform=OneHot(3),
+                                                                     gpu_preprocess=mode)}
+        tr.load_dataloader()
+        tr.model, tr.criterion = Model(), Crit()
+        meters, out = tr.inference_one_epoch("test", True)
+        codes[mode] = out["codes"]
+        assert out["codes"].shape == (7, 32) and out["labels"].shape == (7, 3)
+    assert torch.equal(codes[True], codes[False])

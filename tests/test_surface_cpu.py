@@ -116,6 +116,17 @@ def test_datasets_and_transforms(tmp_path):
                         target_transform=OneHot(3))
     img, target, idx = ds[4]
     assert img.shape == (3, 24, 24) and target.tolist() == [0.0, 1.0, 0.0] and idx == 4 and len(ds) == 5
+    # gpu_preprocess: the CPU side only decodes; batches are RawImageBatch (bytes back to back + sizes)
+    import engine
+    raw = HashingDataset(str(root), "test.txt", transform=[T.Resize(32, T.interpolation("bicubic"))], target_transform=OneHot(3),
+                         gpu_preprocess=True)
+    im, tg, ix = raw[4]
+    assert im.dtype == torch.uint8 and im.shape == (44, 60, 3) and tg.tolist() == [0.0, 1.0, 0.0]
+    batch = next(iter(engine.dataloader(raw, bs=3, workers=0)))
+    rb, targets, idxs = batch
+    assert rb.size(0) == 3 and rb.sizes == [(40, 60), (41, 60), (42, 60)] and rb.pixels.numel() == (40 + 41 + 42) * 60 * 3
+    assert targets.shape == (3, 3) and idxs.tolist() == [0, 1, 2]
+    assert torch.equal(rb.pixels[:40 * 60 * 3].reshape(40, 60, 3), raw[0][0])
     syn = SyntheticHashingDataset(7, size=50, image_size=32, seed=3)
     a, b = syn[10], syn[10]
     assert torch.equal(a[0], b[0]) and a[1].sum() == 1 and len(syn) == 50          # deterministic per index

@@ -43,9 +43,23 @@ class COOPTrainer(BaseTrainer):
         codes, logits = output
         return logits if isinstance(logits, dict) else {"codes": codes, "logits": logits}
 
+    def _gpu_preprocess(self, raw):
+        """`dataset.gpu_preprocess: true`: decoded uint8 images of a batch -> the encoder's bf16 NCHW input, on the GPU, with the
+        geometry and normalisation constants of the dataset config (`resize`, `crop`, `norm`; reference
+        configs/dataset/cub200.yaml:31-47)."""
+        if getattr(self, "_gpu_pre", None) is None:
+            from concepthash_amd.preprocess import GpuPreprocess
+            from utils.transforms import _NORMS
+            ds = self.config.dataset
+            mean, std = _NORMS[int(ds.get("norm", 3))]
+            self._gpu_pre = GpuPreprocess(int(ds.get("resize", 256)), int(ds.get("crop", 224)), mean, std, device=self.device)
+        return self._gpu_pre(raw.pixels, raw.sizes)
+
     def compute_features_one_batch(self, data):
         image, labels, index = data
         image = image.to(self.device, non_blocking=True)
+        if hasattr(image, "pixels"):                      # RawImageBatch from a gpu_preprocess dataset
+            image = self._gpu_preprocess(image)
         labels = labels.to(self.device, non_blocking=True)
         output = self.model(image, labels) if self.config.model.get("pass_labels") else self.model(image)
         return (image, labels, index), self.parse_model_output(output)

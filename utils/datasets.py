@@ -31,12 +31,47 @@ def read_list(path: str):
     return items
 
 
+class RawImageBatch:
+    """Decoded, untransformed images of one batch for the GPU pre-processing path: `pixels` = the uint8 RGB bytes of all images
+    back to back (image i is [h_i, w_i, 3]), `sizes` = [(h, w)].  Quacks enough like a tensor for the trainer's plumbing."""
+
+    def __init__(self, pixels: torch.Tensor, sizes):
+        self.pixels, self.sizes = pixels, list(sizes)
+
+    def size(self, dim=0):
+        if dim != 0:
+            raise IndexError("RawImageBatch only has a batch dimension")
+        return len(self.sizes)
+
+    def to(self, device, non_blocking=False):
+        return RawImageBatch(self.pixels.to(device, non_blocking=non_blocking), self.sizes)
+
+    def pin_memory(self):
+        return RawImageBatch(self.pixels.pin_memory(), self.sizes)
+
+
+def raw_collate(batch):
+    """collate_fn of a `gpu_preprocess` dataset: images stay decoded uint8 of their own sizes (no CPU resize), targets and
+    indices are stacked as usual."""
+    imgs, targets, idxs = zip(*batch)
+    pixels = torch.cat([im.reshape(-1) for im in imgs])
+    targets = torch.stack([t if torch.is_tensor(t) else torch.as_tensor(t) for t in targets])
+    return RawImageBatch(pixels, [tuple(im.shape[:2]) for im in imgs]), targets, torch.as_tensor(idxs)
+
+
 class HashingDataset(Dataset):
-    """Returns (image, target, index), as the trainers unpack it (trainers/coop.py:62)."""
+    """Returns (image, target, index), as the trainers unpack it (trainers/coop.py:62).
+
+    `gpu_preprocess=True` (dataset config key of the same name): `transform` is NOT applied on the CPU worker; the item is the
+    decoded uint8 [H, W, 3] image and the loader collates batches with `raw_collate`; the trainer then runs Resize -> CenterCrop ->
+    ToTensor -> normalize on the GPU (`concepthash_amd.preprocess.GpuPreprocess`, bit-equal to the CPU chain)."""
 
     def __init__(self, root, filename="train.txt", transform=None, target_transform=None, num_classes=None, num_shots=0,
-                 separate_multiclass=False, **kwargs):
+                 separate_multiclass=False, gpu_preprocess=False, **kwargs):
         from utils.transforms import Compose
+        self.gpu_preprocess = bool(gpu_preprocess)
+        if self.gpu_preprocess:
+            self.collate_fn = raw_collate
         self.root = root
         self.items = read_list(os.path.join(root, filename))
         if num_shots:
@@ -62,7 +97,10 @@ class HashingDataset(Dataset):
         from PIL import Image
         rel, lab = self.items[index]
         img = Image.open(self._resolve(rel)).convert("RGB")
-        if self.transform is not None:
+        if self.gpu_preprocess:
+            import numpy as np
+            img = torch.from_numpy(np.array(img, dtype=np.uint8))          # decode only; resize / crop / normalise on the GPU
+        elif self.transform is not None:
             img = self.transform(img)
         target = self.target_transform(lab) if self.target_transform is not None else lab
         return img, target, index
