@@ -63,9 +63,14 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:                                 # one process per GPU: gallery-sharded retrieval
         import torch.distributed as dist
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # nccl = RCCL over xGMI; CH_DIST_BACKEND=gloo only for rehearsing the multi-rank path with several ranks on ONE GPU
+        backend = os.environ.get("CH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     try:
         return run(config)
     finally:

@@ -116,3 +116,42 @@ def test_main_v2_validation_end_to_end(tmp_path):
     has_rel = float(np.mean([(gl == c).any() for c in ql]))          # recall@G is 1 for queries with >= 1 relevant row, else 0
     assert h3["Rs"][-1] == 96 and len(h3["recalls"]) == len(h3["Rs"]) and abs(h3["recalls"][-1] - has_rel) < 1e-12
     assert abs(h3["precisions"][0] - ref["precisions"][0]) < 1e-12   # P@1 of the curve == P@1 of the mAP run
+
+
+def test_main_v2_two_ranks_on_one_gpu_match_the_single_process_run(tmp_path):
+    """The multi-rank evaluation path on hardware (2 ranks sharing the one GPU, collectives over gloo -- a rehearsal of the
+    one-process-per-GPU layout, not a scaling run): every rank encodes its contiguous block of each split, outputs are gathered
+    in dataset order, the gallery is row-sharded for retrieval (histogram all-gather -> global prefix -> integer all-reduce),
+    `eval_logdir` is decided on rank 0 and broadcast, only rank 0 writes files.  history.json and the saved codes equal the
+    single-process run's bit for bit; 5 test images with batch size 4 also leave rank 1 with a single short batch."""
+    import socket
+    logdir = str(tmp_path / "run")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    common = ["dataset=synthetic_cub200", "dataset.limit=37", "data_dir=" + str(tmp_path)]
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synthetic_logdir.py"), logdir,
+                    "model.backbone.name=synthetic/clip-vit-small-patch16", "model.nbit=64"] + common, check=True, env=env,
+                   cwd=str(tmp_path))
+    args = ["--config-name", "val.yaml", "logdir=" + logdir, "batch_size=16", "save_code=True", "R=[5,-1]"] + common
+    ev1 = str(tmp_path / "ev_single")
+    subprocess.run([sys.executable, os.path.join(ROOT, "main_v2.py")] + args + ["eval_logdir=" + ev1], check=True, env=env,
+                   cwd=str(tmp_path))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ev2 = str(tmp_path / "ev_two_ranks")
+    procs = []
+    for r in range(2):
+        e = dict(env, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 CH_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "main_v2.py")] + args + ["eval_logdir=" + ev2], env=e,
+                                      cwd=str(tmp_path)))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    h1, h2 = json.load(open(os.path.join(ev1, "history.json"))), json.load(open(os.path.join(ev2, "history.json")))
+    assert h1["mAP"] == h2["mAP"] and h1["precisions"] == h2["precisions"] and h1["recalls"] == h2["recalls"]
+    o1, o2 = torch.load(os.path.join(ev1, "outputs.pth")), torch.load(os.path.join(ev2, "outputs.pth"))
+    for split in ("test", "db"):
+        assert torch.equal(o1[split]["codes"], o2[split]["codes"]) and torch.equal(o1[split]["labels"], o2[split]["labels"])
+    for k in h1:
+        if k.startswith(("test_", "db_")):
+            assert abs(h1[k] - h2[k]) < 1e-6, k          # sample-weighted meters, reduced over ranks
+    assert sorted(os.listdir(ev2)) == sorted(os.listdir(ev1))      # one set of files, written once
