@@ -383,3 +383,38 @@ def test_map_at_config5_size_1m_gallery(dev):
     for t in range(len(ks)):
         assert torch.equal(nrel[idx_of[2 + t]], got["hits"][:, t])
     assert torch.equal(totals[:, 1], got["total"])
+
+
+def test_randomised_shapes_against_oracle(dev):
+    """40 seeded random problems -- query / gallery sizes off every tile and trip boundary (1 .. 1500 x 1 .. 9000), 64 .. 256 bit,
+    k, explicit segment sizes (whole blocks, pairs of blocks and tails of the row loop), single-label and multi-hot relevance,
+    remove_first, several rank limits -- through top-k and the one-pass evaluation, bit for bit against the oracle."""
+    from concepthash_amd import retrieval as rt
+    from oracle import hamming_oracle as ho
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        nbit = int(rng.choice([64, 128, 192, 256]))
+        Qn, G = int(rng.integers(1, 1500)), int(rng.integers(1, 9000))
+        ncls = int(rng.integers(2, 40))
+        q, ql = ho.synthetic_codes(Qn, nbit, seed=1000 + case, nclass=ncls, flip=0.15)
+        g, gl = ho.synthetic_codes(G, nbit, seed=2000 + case, nclass=ncls, flip=0.15)
+        k = int(rng.integers(1, 40))
+        idx, dst = rt.hamming_topk(_t(q, dev), _t(g, dev), k)
+        ridx, rdst = ho.topk(q, g, k)
+        assert np.array_equal(idx.cpu().numpy(), ridx.astype(np.int64)) and np.array_equal(dst.cpu().numpy(), rdst), case
+        multi = case % 4 == 3
+        if multi:
+            qlab = (rng.random((Qn, 70)) < 0.05).astype(np.int64)
+            glab = (rng.random((G, 70)) < 0.05).astype(np.int64)
+        else:
+            qlab, glab = ql, gl
+        remove_first = bool(case % 2) and G > 1
+        R = int(rng.choice([-1, 1, 7, 100, 5000]))
+        ks = tuple(sorted({int(v) for v in rng.integers(1, 300, size=3)}))
+        seg = int(rng.choice([256, 257, 263, 1000, 4096])) if case % 3 else None
+        got = rt.evaluate(_t(q, dev), _t(g, dev), _t(qlab, dev), _t(glab, dev), R=R, ks=ks, remove_first=remove_first, seg_rows=seg)
+        ref = ho.mean_ap(q, g, qlab, glab, R=R, ks=ks, remove_first=remove_first)
+        assert np.array_equal(got["S"].cpu().numpy().view(np.uint64), ref["S"]), (case, nbit, Qn, G, R, ks, remove_first, seg, multi)
+        assert np.array_equal(got["nrel"].cpu().numpy().astype(np.uint32), ref["nrel"]), case
+        assert np.array_equal(got["hits"].cpu().numpy().astype(np.uint32), ref["hits"]), case
+        assert np.array_equal(got["total"].cpu().numpy().astype(np.uint32), ref["total"]), case
