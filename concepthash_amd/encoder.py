@@ -170,8 +170,9 @@ class ConceptHashEncoder:
 
     @property
     def launches_per_encode(self) -> int:
+        """upper bound of the kernel launches of one ch_encode chain (profile-event capacity)"""
         L, ad = self.cfg["layers"], 1 if self.cfg["adapter_dim"] > 0 else 0
-        return 3 + L * (7 + 6 * ad) + 2
+        return 3 + L * (7 + 8 * ad) + 4
 
     # -- encode ---------------------------------------------------------------------------------------------------
     def _check_images(self, images: torch.Tensor):
