@@ -216,7 +216,9 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
     const int min_k = p.pp_min_k > 0 ? p.pp_min_k : 512;  // per model (CH_GEMM_PP_MIN_K at ch_model_create), not per process
     const bool pp = ch_gemm_pp_supported(p) && p.K >= min_k;
     g_dispatch_count[pp ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
-    return pp ? ch_gemm_bf16_pp(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
+    if (pp) return ch_gemm_bf16_pp(p, epi, s);
+    const bool ring = (p.small_kernel == 2 || g_gemm_variant == 7) && ch_gemm_r4_supported(p);
+    return ring ? ch_gemm_bf16_r4(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
 }
 // test tap: how many GEMMs the dispatcher has sent to the 128x128 (which = 0) / 256x256 ping-pong (which = 1) kernel
 extern "C" int64_t ch_debug_gemm_dispatch_count(int32_t which) {

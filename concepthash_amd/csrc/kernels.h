@@ -55,6 +55,7 @@ struct GemmParams {
     int rev;                 // 1: walk the m-tiles from the last row tile to the first (serpentine launch order)
     int pp_sched;            // 256x256 kernel: 0 = four phases of 16 MFMAs per K-tile, 1 = two phases of 32 (gemm_pp.hip)
     int pp_min_k;            // dispatcher: smallest K that goes to the 256x256 ping-pong kernel (0 = default 512)
+    int small_kernel;        // dispatcher, GEMMs that do not go to the 256x256 kernel: 0 = default, 1 = 128x128x64 two-phase, 2 = 128x128x32 ring (experiments build)
 };
 constexpr size_t CH_SPLITK_WS_BYTES = (size_t)256 * 256 * 256 * 4;  // 64 MiB: at most 256 tail units of one 256x256 fp32 slab
 constexpr size_t CH_SPLITK_CNT_BYTES = 256 * sizeof(unsigned);
@@ -72,6 +73,8 @@ int ch_gemm_bf16_ppp(const GemmParams &p, int epi, hipStream_t s);  // gemm_ppp.
 bool ch_gemm_ppp_supported(const GemmParams &p, int epi);
 int ch_gemm_bf16_dp(const GemmParams &p, int epi, hipStream_t s);   // gemm_dp.hip: 256x128x32, 3-stage ring, 2 workgroups/CU
 bool ch_gemm_dp_supported(const GemmParams &p);
+int ch_gemm_bf16_r4(const GemmParams &p, int epi, hipStream_t s);   // gemm_r4.hip: 128x128x32, 4-stage ring, 2 workgroups/CU
+bool ch_gemm_r4_supported(const GemmParams &p);
 #else
 static inline int ch_experiments_not_built() {
     ch_set_error("experiment kernels are not part of this build (rebuild with CH_BUILD_EXPERIMENTS=1)");
@@ -80,6 +83,8 @@ static inline int ch_experiments_not_built() {
 static inline int ch_gemm_bf16_pq(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
 static inline int ch_gemm_bf16_ppp(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
 static inline int ch_gemm_bf16_dp(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
+static inline int ch_gemm_bf16_r4(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
+static inline bool ch_gemm_r4_supported(const GemmParams &) { return false; }
 #endif
 int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s);  // timing-only builds (garbage results)
 void ch_gemm_set_variant(int v);

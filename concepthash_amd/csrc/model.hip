@@ -84,6 +84,7 @@ struct ch_model {
     // ones that should still be in the 256 MB Infinity Cache.  Measured: no gain (12.44 vs 12.39 ms per step) -> off.
     bool serpentine = false;
     int pp_sched = 0;  // CH_GEMM_PP_SCHED: schedule of the 256x256 GEMM (gemm_pp.hip)
+    int small_kernel = 0;  // CH_GEMM_SMALL at creation: 2 = 128x128x32 four-stage ring, experiments build only (0 = dispatcher default)
     int pp_min_k = 0;  // CH_GEMM_PP_MIN_K at creation (tests: sends small-K GEMMs of a small fixture to the 256x256 kernel)
     float *Hc = nullptr;
     float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn
@@ -459,7 +460,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         GemmParams p{};
         p.X = m->PATCH; p.W = mm->patch_w; p.M = B * np; p.N = D; p.K = mm->Kp; p.X_rows_alloc = m->prow_alloc;
         p.bias = nullptr; p.resid = m->H; p.ldr = D; p.pos = mm->pos; p.tokens_per_img = ntok; p.patches_per_img = np;
-        p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched;
+        p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.small_kernel = mm->small_kernel;
         if (int e = ch_gemm_bf16(p, EPI_PATCH, s)) return e;
     }
     const LayerW &w0 = mm->layers[0];
@@ -485,7 +486,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
                     int epi, bf16_t *out, int ldo, const float *scale, const bf16_t *addend = nullptr, const Fold &f = Fold()) {
         mark(mm, pi, cat, 2.0 * cur_rows * (double)n_true * k_true, s);
         GemmParams p{};
-        p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi]; p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.rev = next_dir();
+        p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi]; p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.small_kernel = mm->small_kernel; p.rev = next_dir();
         p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
         p.X = X; p.W = W; p.M = cur_rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
@@ -645,6 +646,7 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
     if (const char *e = getenv("CH_LN_FOLD")) m->ln_fold = atoi(e) != 0;
     if (const char *e = getenv("CH_PRUNE_LAST")) m->prune_last = atoi(e) != 0;
     if (const char *e = getenv("CH_GEMM_PP_MIN_K")) m->pp_min_k = atoi(e);
+    if (const char *e = getenv("CH_GEMM_SMALL")) m->small_kernel = atoi(e);
     if (const char *e = getenv("CH_SERPENTINE")) m->serpentine = atoi(e) != 0;
 #ifdef CH_EXPERIMENTS
     if (const char *e = getenv("CH_GEMM_PP_SCHED")) m->pp_sched = atoi(e) == 1 ? 1 : 0;
@@ -852,6 +854,7 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
     if (variant == 3) return ch_gemm_bf16_dp(p, epi, s);
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
+    if (variant == 7) return ch_gemm_bf16_r4(p, epi, s);
     if (variant >= 21 && variant <= 29) return ch_gemm_bf16_pp_dbg(p, variant - 20, s);  // timing-only / stamped builds
     return ch_gemm_bf16(p, epi, s);
 }
@@ -870,6 +873,7 @@ extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_a
     if (int e = debug_attach_splitk(p)) return e;
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
+    if (variant == 7) return ch_gemm_bf16_r4(p, epi, s);
     if (variant == 1 || variant == 2 || variant == 4) ch_gemm_set_variant(variant);
     const int rc = ch_gemm_bf16(p, epi, s);
     if (variant == 1 || variant == 2 || variant == 4) ch_gemm_set_variant(0);

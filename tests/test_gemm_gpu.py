@@ -55,11 +55,11 @@ def _inputs(M, N, K, seed=0):
     return X, W, bias, resid
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 7])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 768, 768), (2011, 2304, 768), (513, 768, 3072), (700, 3072, 768),
                                    (300, 768, 384), (257, 256, 640)])
 def test_gemm_against_torch_fp32(variant, M, N, K):
-    if variant == 3:
+    if variant in (3, 7):
         _need_experiments()
     X, W, bias, resid0 = _inputs(M, N, K)
     scale = torch.tensor([0.7], device="cuda")
@@ -108,6 +108,41 @@ def test_pingpong_equals_two_phase_bitwise_and_is_race_free(M, N, K):
             assert torch.equal(r[:M], r_ref[:M]), f"variant {variant} iteration {it}"
 
 
+@pytest.mark.parametrize("M,N,K", [(50432, 384, 768), (50432, 768, 384), (1500, 768, 96), (777, 128, 3072), (300, 2304, 160)])
+def test_ring_kernel_equals_two_phase_bitwise(M, N, K):
+    """gemm_r4.hip (variant 7): 128x128x32 tiles behind a four-stage LDS-DMA ring with three K-steps in flight.  Same MFMA and the
+    same k order per output element as the 128x128x64 two-phase kernel -> identical bits, for every epilogue, with the L2
+    cold and warm (a stage overwritten before its readers finished, or read before it landed, shows up here).  The kernel
+    lost to the one it was meant to replace and is part of the experiments build only."""
+    _need_experiments()
+    X, W, bias, resid0 = _inputs(M, N, K, seed=2)
+    scale = torch.tensor([0.3], device="cuda")
+    addend = torch.randn(X.shape[0], N, device="cuda").to(torch.bfloat16)
+    junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    base = 1 if K % 64 == 0 else None
+    for epi in (EPI_BIAS, EPI_QGELU, EPI_GELU, EPI_BIAS_RESID, EPI_SCALE_RESID):
+        outs = []
+        for variant, it in ((base, 0), (7, 0), (7, 1), (7, 2)):
+            if variant is None:
+                continue
+            out = torch.zeros(X.shape[0], N, dtype=torch.bfloat16, device="cuda")
+            r = resid0.clone()
+            if it == 1:
+                junk.fill_(1.0)
+            _gemm(variant, X, W, bias, M, epi, out=out if epi != EPI_SCALE_RESID else None,
+                  resid=r if epi >= EPI_BIAS_RESID else None, scale=scale, addend=addend if epi == EPI_SCALE_RESID else None)
+            torch.cuda.synchronize()
+            outs.append((out, r))
+        for out, r in outs[1:]:
+            assert torch.equal(out.view(torch.int16), outs[0][0].view(torch.int16)), epi
+            assert torch.equal(r, outs[0][1]), epi
+    if base is None:       # K % 64 != 0: no two-phase kernel to compare with -> fp32 reference
+        out = torch.zeros(X.shape[0], N, dtype=torch.bfloat16, device="cuda")
+        _gemm(7, X, W, bias, M, EPI_BIAS, out=out)
+        v, _ = _ref(X, W, bias, M, EPI_BIAS, resid0, 0.3)
+        assert torch.allclose(out[:M].float(), v, atol=2e-3 + 1e-2, rtol=2 ** -7)
+
+
 @pytest.mark.parametrize("M,N,K", [(51456, 2304, 768), (51456, 768, 768), (4000, 3072, 768), (2500, 768, 3072), (256, 256, 128),
                                    (70000, 256, 256)])
 def test_persistent_pingpong_equals_two_phase_bitwise(M, N, K):
@@ -154,9 +189,11 @@ def _slice_stats(x_bf16, M):
     return torch.stack([x.sum(-1), (x * x).sum(-1)], dim=-1)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 7])
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (513, 768, 3072), (300, 768, 384), (2011, 256, 640)])
 def test_statistics_producers(variant, M, N, K):
+    if variant == 7:
+        _need_experiments()
     X, W, bias, resid0 = _inputs(M, N, K, seed=3)
     # bias + statistics: the output is bit-identical to the plain bias epilogue, statistics describe the ROUNDED output
     ref = torch.zeros(X.shape[0], N, dtype=torch.bfloat16, device="cuda")
@@ -187,11 +224,11 @@ def test_statistics_producers(variant, M, N, K):
     assert bool(torch.isnan(stats[M:]).all())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4])
+@pytest.mark.parametrize("variant", [1, 2, 4, 7])
 @pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (700, 3072, 768), (515, 384, 768), (300, 256, 128), (257, 512, 1280)])
 def test_layernorm_folded_consumers(variant, M, N, K):
     """y = act(LN(x) W^T + b) computed as act(rstd * (x W'^T - mean * c) + d) with W' = bf16(W * gamma)."""
-    if variant == 4:
+    if variant in (4, 7):
         _need_experiments()
     if variant in (2, 4) and N % 256:
         pytest.skip("the 256x256 kernel needs N % 256 == 0")
