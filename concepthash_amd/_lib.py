@@ -70,6 +70,17 @@ SIGNATURES = {
                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_hamming_ap_multi": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
                                     c_void_p, POINTER(c_int64), c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_adapter_arena_numel": (c_int64, [c_void_p]),
+    "ch_trainer_create": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "ch_trainer_destroy": (None, [c_void_p]),
+    "ch_trainer_bytes": (c_int64, [c_void_p]),
+    "ch_trainer_refresh": (c_int, [c_void_p, c_void_p]),
+    "ch_train_forward": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_debug_attention_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "ch_debug_wgrad": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "ch_debug_ln_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_debug_act": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "ch_hamming_hist_prefix": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -1,0 +1,252 @@
+// Backward of the fused multi-head attention (head_dim 64, no mask; HF CLIPAttention as used by
+// models/layers/adapter.py:127-177) for the ConceptHash training step -- one workgroup per (image, head), nothing but
+// qkv and dO read, nothing but dqkv written; the probabilities are recomputed, never stored.
+//
+//   P = softmax(0.125 Q K^T),  O = P V                                   (forward, attention.hip)
+//   dV = P^T dO,  dP = dO V^T,  D_q = sum_j P_qj dP_qj (= dO_q . O_q),  dS = 0.125 P o (dP - D),  dQ = dS K,  dK = dS^T Q
+//
+// Q, K, V and dO of the pair are staged once in LDS (row-major, 128-B rows, 16-B chunk index XOR (row & 7), by LDS-DMA).
+// Phase A -- a wave owns 16-query tiles (the forward's layout: S^T = K Q^T, a lane holds one query's keys):
+//   softmax statistics, dP^T = V dO^T, D_q, dS^T in registers; dQ^T = K^T dS^T with K^T from the hardware transpose read
+//   (ds_read_b64_tr_b16), dS^T being already the B operand; (max, 1/sum, D_q) per query go to LDS.
+// Phase B -- a wave owns 16-key tiles and walks the query tiles: S = Q K^T and dP = dO V^T in the TRANSPOSED lane layout
+//   (a lane holds one key's queries), P and dS rebuilt from the saved statistics; dV^T += dO^T P and dK^T += Q^T dS by
+//   v_mfma_f32_16x16x16_bf16, whose reduction index is the 16 queries of the tile: P / dS in the accumulator layout ARE its B
+//   operand, dO^T / Q^T come through the transpose read.  The second S / dP product costs 4 MFMAs per tile pair and saves a
+//   round trip of P and dS through LDS.
+#include "ch_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int NW = 8;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s lds_v4s;
+
+template <int KB>
+__global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dO, int ntok,
+                                                               int heads, float scale_log2e, bf16_t *__restrict__ dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = KB * 2;   // 16-row tiles
+    constexpr int KP = KB * 32;  // padded rows (keys and queries)
+    char *Ks = smem, *Vs = smem + KP * 128, *Qs = smem + 2 * KP * 128, *Gs = smem + 3 * KP * 128;  // Gs: dO
+    float *stat = (float *)(smem + 4 * KP * 128);                                                    // [KP][4]: mxs, inv, D_q, -
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const int D = heads * HD;
+    const size_t ld = (size_t)3 * D;
+    const bf16_t *base = qkv + (size_t)b * ntok * ld + h * HD;
+    const bf16_t *gbase = dO + (size_t)b * ntok * D + h * HD;
+    bf16_t *obase = dqkv + (size_t)b * ntok * ld + h * HD;
+
+    {  // stage: instruction i covers rows 8i..8i+7; rows past the sequence re-read the last row (finite; masked / zero weight)
+        const int lrow = lane >> 3;
+        const int src_chunk = (lane & 7) ^ lrow;
+        for (int i = wid; i < KP / 8; i += NW) {
+            int row = i * 8 + lrow;
+            row = row < ntok ? row : ntok - 1;
+            const bf16_t *src = base + (size_t)row * ld + src_chunk * 8;
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src), (lds_void_t *)(Qs + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + D), (lds_void_t *)(Ks + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + 2 * D), (lds_void_t *)(Vs + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(gbase + (size_t)row * D + src_chunk * 8), (lds_void_t *)(Gs + i * 1024), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int QT = (ntok + 15) >> 4;  // tiles holding at least one valid row
+    // b128 fragment of row (tile*16 + fr): d = 8*fq .. +8 (off0) and 32 + 8*fq .. (off1)
+    const int off0 = fr * 128 + ((fq ^ (fr & 7)) << 4), off1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
+    // transpose read: lane 4*tq + tp of group fq addresses row 4*fq + tq of a 16-row tile, features 4*tp.. of feature tile dt
+    const int tq = fr >> 2, tp = fr & 3;
+    const int trow7 = ((fq & 1) << 2) | tq;
+    int toff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) toff[dt] = (fq * 4 + tq) * 128 + (((dt * 2 + (tp >> 1)) ^ trow7) << 4) + (tp & 1) * 8;
+
+    // ================================ phase A: per query tile -> statistics and dQ ==========================================
+    for (int qt = wid; qt < QT; qt += NW) {
+        const int q = qt * 16 + fr;
+        const bool qvalid = q < ntok;
+        const bf16x8 qf0 = *(const bf16x8 *)(Qs + qt * 2048 + off0), qf1 = *(const bf16x8 *)(Qs + qt * 2048 + off1);
+        const bf16x8 gf0 = *(const bf16x8 *)(Gs + qt * 2048 + off0), gf1 = *(const bf16x8 *)(Gs + qt * 2048 + off1);
+        f32x4 st[KT], dp[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const bf16x8 k0 = *(const bf16x8 *)(Ks + kt * 2048 + off0), k1 = *(const bf16x8 *)(Ks + kt * 2048 + off1);
+            const bf16x8 v0 = *(const bf16x8 *)(Vs + kt * 2048 + off0), v1 = *(const bf16x8 *)(Vs + kt * 2048 + off1);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, gf0, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, gf1, c, 0, 0, 0);
+            st[kt] = a;   // S^T[key = kt*16 + 4*fq + r][query fr]
+            dp[kt] = c;   // dP^T, same layout
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (kt * 16 + fq * 4 + r >= ntok) st[kt][r] = -1e30f;
+        float mx = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxs = mx * scale_log2e;
+        float sum = 0.f, pd = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(st[kt][r] * scale_log2e - mxs);
+                st[kt][r] = e;
+                sum += e;
+                pd += e * dp[kt][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        pd += __shfl_xor(pd, 16, 64);
+        pd += __shfl_xor(pd, 32, 64);
+        const float inv = 1.0f / sum;
+        const float Dq = pd * inv;
+        if (fq == 0) *(f32x4 *)(stat + q * 4) = f32x4{mxs, qvalid ? inv : 0.f, Dq, 0.f};
+        // dS^T = 0.125 * P^T o (dP^T - D_q), as the bf16 B operand; logical k = 8*fq + j <-> key 32*kb + (j < 4 ? 4*fq + j : 16 + 4*fq + j - 4)
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float w = 0.125f * inv;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            union {
+                bf16x8 v;
+                uint32_t u[4];
+            } pf;
+            pf.u[0] = pack_bf16x2(w * st[2 * kb][0] * (dp[2 * kb][0] - Dq), w * st[2 * kb][1] * (dp[2 * kb][1] - Dq));
+            pf.u[1] = pack_bf16x2(w * st[2 * kb][2] * (dp[2 * kb][2] - Dq), w * st[2 * kb][3] * (dp[2 * kb][3] - Dq));
+            pf.u[2] = pack_bf16x2(w * st[2 * kb + 1][0] * (dp[2 * kb + 1][0] - Dq), w * st[2 * kb + 1][1] * (dp[2 * kb + 1][1] - Dq));
+            pf.u[3] = pack_bf16x2(w * st[2 * kb + 1][2] * (dp[2 * kb + 1][2] - Dq), w * st[2 * kb + 1][3] * (dp[2 * kb + 1][3] - Dq));
+            union {
+                bf16x8 v;
+                v4s hh[2];
+            } kf[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                kf[dt].hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Ks + kb * 4096 + toff[dt]));
+                kf[dt].hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Ks + kb * 4096 + 2048 + toff[dt]));
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[dt].v, pf.v, o[dt], 0, 0, 0);
+        }
+        if (qvalid) {
+            bf16_t *op = obase + (size_t)q * ld + fq * 4;  // dQ[q][dt*16 + 4*fq + r]
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 wv;
+                wv.x = pack_bf16x2(o[dt][0], o[dt][1]);
+                wv.y = pack_bf16x2(o[dt][2], o[dt][3]);
+                *(uint2 *)(op + dt * 16) = wv;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================================ phase B: per key tile -> dK, dV ========================================================
+    for (int kt = wid; kt < QT; kt += NW) {
+        const int key = kt * 16 + fr;
+        const bool kvalid = key < ntok;
+        const bf16x8 k0 = *(const bf16x8 *)(Ks + kt * 2048 + off0), k1 = *(const bf16x8 *)(Ks + kt * 2048 + off1);
+        const bf16x8 v0 = *(const bf16x8 *)(Vs + kt * 2048 + off0), v1 = *(const bf16x8 *)(Vs + kt * 2048 + off1);
+        f32x4 dkt[4], dvt[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dkt[dt] = dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qt = 0; qt < QT; ++qt) {
+            const bf16x8 qf0 = *(const bf16x8 *)(Qs + qt * 2048 + off0), qf1 = *(const bf16x8 *)(Qs + qt * 2048 + off1);
+            const bf16x8 gf0 = *(const bf16x8 *)(Gs + qt * 2048 + off0), gf1 = *(const bf16x8 *)(Gs + qt * 2048 + off1);
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf0, k0, s4, 0, 0, 0);  // S[q = qt*16 + 4*fq + r][key fr]
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1, k1, s4, 0, 0, 0);
+            d4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf0, v0, d4, 0, 0, 0);  // dP, same layout
+            d4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf1, v1, d4, 0, 0, 0);
+            float p[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 sv = *(const f32x4 *)(stat + (qt * 16 + fq * 4 + r) * 4);  // (mxs, inv or 0, D_q)
+                const float pr = kvalid ? __builtin_amdgcn_exp2f(s4[r] * scale_log2e - sv[0]) * sv[1] : 0.f;
+                p[r] = pr;
+                ds[r] = 0.125f * pr * (d4[r] - sv[2]);
+            }
+            union {
+                v4s v;
+                uint32_t u[2];
+            } pb, sb;
+            pb.u[0] = pack_bf16x2(p[0], p[1]);
+            pb.u[1] = pack_bf16x2(p[2], p[3]);
+            sb.u[0] = pack_bf16x2(ds[0], ds[1]);
+            sb.u[1] = pack_bf16x2(ds[2], ds[3]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const v4s gt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Gs + qt * 2048 + toff[dt]));  // dO^T[d][q]
+                const v4s qT = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(Qs + qt * 2048 + toff[dt]));  // Q^T[d][q]
+                dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(gt, pb.v, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, sb.v, dkt[dt], 0, 0, 0);
+            }
+        }
+        if (kvalid) {
+            bf16_t *kp = obase + (size_t)key * ld + D + fq * 4, *vp = kp + D;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 wk, wv;
+                wk.x = pack_bf16x2(dkt[dt][0], dkt[dt][1]);
+                wk.y = pack_bf16x2(dkt[dt][2], dkt[dt][3]);
+                wv.x = pack_bf16x2(dvt[dt][0], dvt[dt][1]);
+                wv.y = pack_bf16x2(dvt[dt][2], dvt[dt][3]);
+                *(uint2 *)(kp + dt * 16) = wk;
+                *(uint2 *)(vp + dt * 16) = wv;
+            }
+        }
+    }
+}
+
+template <int KB>
+int launch_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s) {
+    constexpr int KP = KB * 32;
+    const size_t lds = (size_t)KP * 128 * 4 + (size_t)KP * 16;
+    CH_REQUIRE(lds <= 160 * 1024, "attention backward: sequence too long for the LDS-resident kernel");
+    static ch_once_per_device lds_once;
+    if (int e = ch_func_max_lds((const void *)attention_bwd_kernel<KB>, (int)lds, lds_once)) return e;
+    const float scale_log2e = 0.125f * 1.4426950408889634f;
+    hipLaunchKernelGGL((attention_bwd_kernel<KB>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, dO, ntok, heads, scale_log2e, dqkv);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// qkv [B*ntok, 3D] bf16 (q | k | v), dO [B*ntok, D] bf16 -> dqkv [B*ntok, 3D] bf16 (dq | dk | dv); head_dim 64
+int ch_attention_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s) {
+    CH_REQUIRE(B > 0 && ntok > 0 && heads > 0, "attention backward: empty problem");
+    const int KB = (ntok + 31) / 32;
+    switch (KB) {
+        case 1: return launch_bwd<1>(qkv, dO, B, ntok, heads, dqkv, s);
+        case 2: return launch_bwd<2>(qkv, dO, B, ntok, heads, dqkv, s);
+        case 3: return launch_bwd<3>(qkv, dO, B, ntok, heads, dqkv, s);
+        case 4: return launch_bwd<4>(qkv, dO, B, ntok, heads, dqkv, s);
+        case 5: return launch_bwd<5>(qkv, dO, B, ntok, heads, dqkv, s);
+        case 6: return launch_bwd<6>(qkv, dO, B, ntok, heads, dqkv, s);
+        case 7: return launch_bwd<7>(qkv, dO, B, ntok, heads, dqkv, s);
+        case 8: return launch_bwd<8>(qkv, dO, B, ntok, heads, dqkv, s);
+        case 9: return launch_bwd<9>(qkv, dO, B, ntok, heads, dqkv, s);
+    }
+    ch_set_error("attention backward: more than 288 tokens per image is not built (LDS-resident Q/K/V/dO)");
+    return 2;
+}

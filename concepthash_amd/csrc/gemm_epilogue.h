@@ -172,7 +172,10 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                 uint2 o;
                 o.x = pack_bf16x2(v[0], v[1]);
                 o.y = pack_bf16x2(v[2], v[3]);
-                *(uint2 *)(wave_lds + row * 128 + (((nt * 2 + (fq >> 1)) ^ (row & 7)) << 4) + (fq & 1) * 8) = o;
+                // ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks: rows r and r + 8 of a group share
+                // (row & 7), so the 8-byte half inside the 16-byte chunk is flipped by row bit 3 (un-flipped at read-back);
+                // without it every staging store is a 2-way conflict (SQ_LDS_BANK_CONFLICT: ~1000 cycles per 256x256 tile)
+                *(uint2 *)(wave_lds + row * 128 + (((nt * 2 + (fq >> 1)) ^ (row & 7)) << 4) + (((fq & 1) ^ ((row >> 3) & 1)) << 3)) = o;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -181,7 +184,8 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
         for (int i = 0; i < MT * 2; ++i) {
             const int row = i * 8 + lrow;
             const int chunk = pos ^ (row & 7);
-            const uint4 v = *(const uint4 *)(wave_lds + row * 128 + pos * 16);
+            uint4 v = *(const uint4 *)(wave_lds + row * 128 + pos * 16);
+            if (i & 1) v = make_uint4(v.z, v.w, v.x, v.y);  // rows with bit 3 set (row = 8 i + lrow) hold their 8-byte halves swapped
             const int m = m_base + row;
             if (m < p.M) *(uint4 *)(p.out_bf16 + (size_t)m * p.ldo + n_base + chunk * 8) = v;
             if constexpr (T::stats) {  // partial (sum, sumsq) of this row's 64 rounded outputs: 8 lanes x 8 values

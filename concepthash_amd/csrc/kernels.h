@@ -184,3 +184,38 @@ int ch_convert_bf16(const float *x, int64_t rows, int cols, int cols_pad, bf16_t
 // bn fold: scale = w / sqrt(var + eps), shift = b - mean * scale
 int ch_bn_fold(const float *w, const float *b, const float *mean, const float *var, int n, float eps, float *scale,
                float *shift, hipStream_t s);
+
+// ---- training step (train_kernels.hip, attention_bwd.hip; orchestration in train.hip) -----------------------------------------
+// fp32 rows -> bf16 copy + per-64-column (sum, sum of squares) partials [rows, D/64, 2] (what the LN-folded GEMMs consume)
+int ch_hb_stats(const float *H, int64_t rows, int D, bf16_t *hb, float *stats, hipStream_t s);
+// out = act(pre) on a saved bf16 pre-activation; act: 0 quick_gelu, 1 gelu (erf)
+int ch_act_fwd(const bf16_t *pre, int64_t n, int act, bf16_t *out, hipStream_t s);
+// out = (*scale_ptr or 1) * g * act'(pre)   (out may alias g)
+int ch_act_bwd(const bf16_t *g, const bf16_t *pre, int64_t n, int act, const float *scale_ptr, bf16_t *out, hipStream_t s);
+// x_hat = (x - mean) * rstd from the row statistics, as bf16
+int ch_normalize_bf16(const bf16_t *x, const float *stats, int64_t rows, int D, float eps, bf16_t *out, hipStream_t s);
+// LayerNorm backward per row given dyg = dy * gamma: result = dres_in + rstd (dyg - mean(dyg) - x_hat mean(dyg x_hat)) -> dres_out (fp32,
+// may alias dres_in, may be null), out_b (bf16, may be null)
+int ch_ln_bwd(const bf16_t *dyg, const bf16_t *x, const float *stats, int64_t rows, int D, float eps, const float *dres_in,
+              float *dres_out, bf16_t *out_b, hipStream_t s);
+// out[n][k] = sum_m A[m][n] * B[m][k]  (A [rows, N] ld lda, B [rows, K] ld ldb, bf16; out [N, K] fp32); ws: ch_wgrad_ws_floats floats.
+// Rows up to the next multiple of 32 are read: they must be allocated and zero in A.
+int ch_wgrad_tn(const bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int64_t rows_alloc, int N, int K, float *out,
+                float *ws, hipStream_t s);
+size_t ch_wgrad_ws_floats(int64_t rows, int N, int K);
+// out[n] = sum_m A[m][n]; A bf16 (is_f32 = 0) or fp32 (1); ws: ch_colsum_ws_floats(N) floats
+int ch_colsum(const void *A, int is_f32, int lda, int64_t rows, int N, float *out, float *ws, hipStream_t s);
+size_t ch_colsum_ws_floats(int N);
+// dst[c][r] = bf16(src[r][c] * (colscale ? colscale[c] : 1)); dst [C, ld_dst]
+int ch_transpose_f32_to_bf16(const float *src, int R, int C, int ld_src, const float *colscale, bf16_t *dst, int ld_dst, hipStream_t s);
+int ch_transpose_bf16(const bf16_t *src, int R, int C, int ld_src, bf16_t *dst, int ld_dst, hipStream_t s);
+// gradients of one adapter's parameters from G = dH^T g [D, bpad], cu = colsum(dH), T = dpre^T x_hat [bpad, D], cd = colsum(dpre);
+// params / grads: one adapter's block of the arena ([ln_w D][ln_b D][down_w b*D][down_b b][up_w D*b][up_b D][scale 1])
+int ch_adapter_grads(const float *G, const float *cu, const float *T, const float *cd, const float *params, int D, int b, int bpad,
+                     float *grads, hipStream_t s);
+int ch_concept_rows_sum(const float *dH, int B, int ntok, int Q, int D, float *out, hipStream_t s);
+int ch_scatter_concept_rows(const float *dhf, int B, int ntok, int Q, int D, float *dH, bf16_t *dHb, hipStream_t s);
+int ch_small_ln_bwd(const float *dy, const float *x, const float *gamma, int rows, int D, float eps, float *dx, hipStream_t s);
+int ch_gather_concept_rows(const float *H, int B, int ntok, int Q, int D, float *out, hipStream_t s);
+// qkv [B*ntok, 3D] (q | k | v), dO [B*ntok, D] -> dqkv [B*ntok, 3D]; head_dim 64
+int ch_attention_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s);

@@ -16,80 +16,7 @@ void ch_set_error(const std::string &msg) { g_last_error = msg; }
 extern "C" const char *ch_last_error(void) { return g_last_error.c_str(); }
 extern "C" int ch_abi_version(void) { return CH_ABI_VERSION; }
 
-constexpr int CH_MAX_STREAMS = 4;  // micro-batch chains that may run concurrently (CH_STREAMS)
-
-namespace {
-struct AdapterW {
-    const float *ln_w = nullptr, *ln_b = nullptr, *down_b = nullptr, *up_b = nullptr, *scale = nullptr;
-    const bf16_t *down_w = nullptr, *up_w = nullptr;
-    // adapter LayerNorm folded into the down projection (LN-fold chain and adapter_fused.hip)
-    const bf16_t *down_wf = nullptr;
-    const float *fold_c = nullptr, *fold_d = nullptr;
-};
-struct LayerW {
-    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *out_b, *fc1_b, *fc2_b;
-    const bf16_t *qkv_w, *out_w, *fc1_w, *fc2_w;
-    // layer_norm1 / layer_norm2 folded into qkv / fc1: W' = bf16(W * gamma), c = row sums of W', d = bias + W beta
-    const bf16_t *qkv_wf = nullptr, *fc1_wf = nullptr;
-    const float *qkv_c = nullptr, *qkv_d = nullptr, *fc1_c = nullptr, *fc1_d = nullptr;
-    AdapterW ad[2];
-};
-}  // namespace
-
-struct ch_model {
-    ch_model_config cfg;
-    int np = 0, ntok = 0, Kp = 0, bpad = 0;
-    std::vector<void *> allocs;
-    size_t bytes = 0;
-    // weights
-    const bf16_t *patch_w = nullptr;
-    const float *pos = nullptr, *cls_pos0 = nullptr, *ctx = nullptr, *pre_w = nullptr, *pre_b = nullptr;
-    const float *zero_bias = nullptr;
-    std::vector<LayerW> layers;
-    const float *hash_pe = nullptr, *hash_fc = nullptr, *bn_scale = nullptr, *bn_shift = nullptr;
-    const float *center_l2 = nullptr, *center_bin = nullptr, *concept_pe = nullptr, *concept_cent_l2 = nullptr;
-    const float *post_w = nullptr, *post_b = nullptr, *vis_proj = nullptr;
-    // launch profiler (bench.py): one hipEvent before every launch + one after the last; elapsed(e[j], e[j+1]) is
-    // attributed to launch j's category
-    // adapter_fused.hip is correct (parity-tested) but measured slower than the three-launch chain on MI355X (200 vs 179 us
-    // per call at B=256: its HBM phases and MFMA phases do not overlap) -> opt-in only
-    bool use_fused_adapter = false;
-    // LayerNorm folded into the consumer GEMMs: no LayerNorm launches inside the layer loop.
-    // Needs adapters (their up-projection epilogue is where the bf16 copy of the residual and its row statistics are made).
-    bool ln_fold = true;
-    bool prof_on = false;
-    struct Prof {
-        std::vector<hipEvent_t> ev;
-        std::vector<int> cat;
-        std::vector<double> flops;
-        size_t n = 0;
-    } prof[CH_MAX_STREAMS];  // one per micro-batch stream
-    // CH_STREAMS micro-batches (default 2) on as many HIP streams: memory-bound launches of one chain (adapter up-projection,
-    // attention, epilogue-heavy GEMM tails) co-run with MFMA-bound launches of the other, and partly filled last rounds of
-    // tiles get filled.  Rows are independent, so the outputs are bit-identical for every value.  Measured at B = 256:
-    // 1 -> 2 streams +8 % images/s, 3 and 4 no better.  CH_STREAMS=1 is what a per-kernel profile wants:
-    // per-launch durations stop describing single kernels once launches overlap.
-    int nstreams = 2;
-    hipStream_t aux_stream[CH_MAX_STREAMS - 1] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[CH_MAX_STREAMS - 1] = {};
-    // workspace
-    int64_t rows_alloc = 0, prow_alloc = 0;
-    float *H = nullptr;
-    float *splitk_ws[CH_MAX_STREAMS] = {};      // split-K tail slabs + tickets of the 256x256 GEMM, one set per chain
-    unsigned *splitk_cnt[CH_MAX_STREAMS] = {};
-    // final-layer row pruning: compact fp32 copy of the residual rows the head reads, [max_batch * (1 + Q) (+pad), D]
-    bool prune_last = true;
-    // Serpentine launch order (CH_SERPENTINE=1): every row-streaming launch of a chain walks its row
-    // tiles in the direction opposite to its predecessor's, so that it starts on the rows the predecessor wrote LAST -- the
-    // ones that should still be in the 256 MB Infinity Cache.  Measured: no gain (12.44 vs 12.39 ms per step) -> off.
-    bool serpentine = false;
-    int pp_sched = 0;  // CH_GEMM_PP_SCHED: schedule of the 256x256 GEMM (gemm_pp.hip)
-    int small_kernel = 0;  // CH_GEMM_SMALL at creation: 2 = 128x128x32 four-stage ring, experiments build only (0 = dispatcher default)
-    int pp_min_k = 0;  // CH_GEMM_PP_MIN_K at creation (tests: sends small-K GEMMs of a small fixture to the 256x256 kernel)
-    float *Hc = nullptr;
-    float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn
-    bf16_t *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *A = nullptr, *AD = nullptr, *F1 = nullptr, *PATCH = nullptr;
-};
+#include "model_internal.h"
 
 namespace {
 

@@ -1,0 +1,429 @@
+// ch_trainer: the ConceptHash TRAINING step of the adapters -- forward with saved
+// activations + backward through the frozen CLIP blocks, on the forward's GEMM / attention kernels plus train_kernels.hip
+// and attention_bwd.hip.  Reference: trainers/coop.py:107-131 (train_one_batch: forward, criterion, loss.backward(),
+// optimizer.step()), models/layers/adapter.py:46-60 (Adapter), :127-177 (CLIPEncoderLayerWithAdapter.forward),
+// trainers/base.py:133-152 (what is trainable: the adapters + get_training_modules(); the backbone is frozen).
+//
+// Division of labour: this library owns everything that touches the [B*ntok, *] activations -- the 12
+// encoder layers forward and backward, > 99.9 % of the step's FLOPs -- and the gradients of the 24 adapters.  The concept-token
+// generator (4 tokens), the hashing head on [B, Q, D] and the loss are a few MFLOP; they stay on the host framework's autograd
+// (concepthash_amd/training.py), which hands `concept_tokens` in and d(hash_features) back, and receives d(concept_tokens).
+//
+// Forward = the LN-fold chain of model.hip, one chain, with every layer's operands kept: bf16(H) + row statistics (the
+// LayerNorm inputs), qkv, attention output, a / m (sub-block outputs) + statistics, adapter pre-activations and activations,
+// fc1 pre-activation.  Pre-activations are saved instead of activations, so the activations are applied by a separate
+// elementwise launch in training (act_fwd) rather than in the GEMM epilogue.
+// Backward per layer, dH = gradient of the residual stream (fp32, bf16 copy dHb as the GEMM operand):
+//   adapter:  G = dHb^T g, cu = colsum(dH)                                [weight-gradient products, up]
+//             dpre = s (dHb W_up) o gelu'(pre)                            [dgrad GEMM + act_bwd]
+//             T = dpre^T x_hat, cd = colsum(dpre)                         [weight-gradient products, down]
+//             d(branch input) = dH + LN_bwd(dpre (W_dn o gamma))          [dgrad GEMM with gamma folded into W^T + ln_bwd]
+//   MLP:      dF = (dM W_fc2) o act'(pre), dh = dF (W_fc1 o gamma2), dH += LN_bwd(dh)
+//   attn:     dctx = dA W_o, dqkv = attention_bwd(qkv, dctx), dh = dqkv (W_qkv o gamma1), dH += LN_bwd(dh)
+// Parameter arena (fp32, caller-owned, device): adapters in (layer, adapter) order, each
+//   [ln_w D][ln_b D][down_w b*D][down_b b][up_w D*b][up_b D][scale 1];  the gradient arena has the same layout.
+#include <algorithm>
+#include <vector>
+
+#include "model_internal.h"
+
+namespace {
+struct AdWork {
+    bf16_t *down_wf = nullptr, *up_w = nullptr, *up_wT = nullptr, *down_wgT = nullptr;
+    float *fold_c = nullptr, *fold_d = nullptr;
+};
+struct LayerT {
+    bf16_t *qkv_wgT = nullptr, *out_wT = nullptr, *fc1_wgT = nullptr, *fc2_wT = nullptr;
+};
+struct Saved {
+    bf16_t *Xn1, *QKV, *AO, *A, *P1, *G1, *Xn2, *F1pre, *A2, *P2, *G2;
+    float *st1, *stA, *st2, *stA2;
+};
+}  // namespace
+
+struct ch_trainer {
+    ch_model *m = nullptr;
+    int max_batch = 0, B = 0;
+    int64_t rows_alloc = 0, prow_alloc = 0;
+    float *params = nullptr, *grads = nullptr;
+    int64_t ad_numel = 0;
+    std::vector<void *> allocs;
+    size_t bytes = 0;
+    std::vector<AdWork> ad;     // [L * 2]
+    std::vector<LayerT> lt;     // [L]
+    std::vector<Saved> sv;      // [L]
+    float *H = nullptr, *dH = nullptr, *ctx = nullptr, *dctx_sum = nullptr;
+    bf16_t *dHb = nullptr, *dMb = nullptr, *tD = nullptr, *tD2 = nullptr, *tB = nullptr, *tM = nullptr, *tQKV = nullptr, *F1act = nullptr,
+           *PATCH = nullptr, *XnDummy = nullptr;
+    float *stDummy = nullptr;
+    float *ws_wgrad = nullptr, *ws_colsum = nullptr, *G = nullptr, *T = nullptr, *cu = nullptr, *cd = nullptr;
+    bool forward_done = false;
+};
+
+namespace {
+
+void *talloc(ch_trainer *t, size_t bytes, bool &ok) {
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (!ok) return nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+        ch_set_error("trainer: hipMalloc/hipMemset failed for " + std::to_string(bytes) + " bytes");
+        ok = false;
+        return nullptr;
+    }
+    t->allocs.push_back(p);
+    t->bytes += bytes;
+    return p;
+}
+
+int64_t adapter_numel(const ch_model_config &c) {
+    const int64_t D = c.dim, b = c.adapter_dim;
+    return 2 * D + b * D + b + D * b + D + 1;
+}
+
+struct AdPtr {
+    float *ln_w, *ln_b, *down_w, *down_b, *up_w, *up_b, *scale;
+};
+AdPtr ad_ptrs(float *base, const ch_model_config &c) {
+    const int64_t D = c.dim, b = c.adapter_dim;
+    AdPtr p;
+    p.ln_w = base;
+    p.ln_b = p.ln_w + D;
+    p.down_w = p.ln_b + D;
+    p.down_b = p.down_w + b * D;
+    p.up_w = p.down_b + b;
+    p.up_b = p.up_w + D * b;
+    p.scale = p.up_b + D;
+    return p;
+}
+
+struct GemmCall {
+    int N, K;
+    const bf16_t *X, *W;
+    const float *bias;
+    int epi;
+    bf16_t *out = nullptr;
+    int ldo = 0;
+    float *resid = nullptr;
+    const float *scale = nullptr;
+    const bf16_t *addend = nullptr;
+    const float *stats_in = nullptr, *fold_c = nullptr;
+    float eps = 0.f;
+    float *stats_out = nullptr;
+    bf16_t *hb_out = nullptr;
+};
+int gemm(ch_trainer *t, int rows, const GemmCall &g, hipStream_t s) {
+    const int D = t->m->cfg.dim;
+    GemmParams p{};
+    p.X = g.X; p.W = g.W; p.M = rows; p.N = g.N; p.K = g.K; p.X_rows_alloc = t->rows_alloc;
+    p.bias = g.bias; p.out_bf16 = g.out; p.ldo = g.ldo; p.resid = g.resid; p.ldr = D; p.scale_ptr = g.scale; p.addend = g.addend;
+    p.ld_addend = D; p.stats_in = g.stats_in; p.fold_c = g.fold_c; p.ln_eps = g.eps; p.stats_out = g.stats_out; p.hb_out = g.hb_out;
+    p.ld_hb = D; p.pp_min_k = t->m->pp_min_k;
+    return ch_gemm_bf16(p, g.epi, s);
+}
+
+}  // namespace
+
+extern "C" int64_t ch_adapter_arena_numel(const ch_model *m) {
+    if (!m || m->cfg.adapter_dim <= 0) return 0;
+    return adapter_numel(m->cfg) * m->cfg.layers * 2;
+}
+
+extern "C" void ch_trainer_destroy(ch_trainer *t) {
+    if (!t) return;
+    for (void *p : t->allocs) (void)hipFree(p);
+    delete t;
+}
+
+extern "C" int ch_trainer_refresh(ch_trainer *t, void *stream) {
+    CH_REQUIRE(t != nullptr, "null trainer");
+    hipStream_t s = (hipStream_t)stream;
+    const ch_model_config &c = t->m->cfg;
+    const int D = c.dim, b = c.adapter_dim, bpad = t->m->bpad;
+    for (int l = 0; l < c.layers; ++l)
+        for (int a = 0; a < 2; ++a) {
+            AdWork &w = t->ad[l * 2 + a];
+            const AdPtr p = ad_ptrs(t->params + (int64_t)(l * 2 + a) * t->ad_numel, c);
+            if (int e = ch_fold_ln(p.down_w, p.down_b, p.ln_w, p.ln_b, b, bpad, D, w.down_wf, w.fold_c, w.fold_d, s)) return e;
+            if (int e = ch_convert_bf16(p.up_w, D, b, bpad, w.up_w, s)) return e;
+            if (int e = ch_transpose_f32_to_bf16(p.up_w, D, b, b, nullptr, w.up_wT, D, s)) return e;          // [b (pad bpad), D]
+            if (int e = ch_transpose_f32_to_bf16(p.down_w, b, D, D, p.ln_w, w.down_wgT, bpad, s)) return e;  // [D, bpad]
+        }
+    return 0;
+}
+
+extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, float *grads, ch_trainer **out) {
+    CH_REQUIRE(out != nullptr, "null out pointer");
+    *out = nullptr;
+    CH_REQUIRE(m != nullptr && params != nullptr && grads != nullptr, "trainer: null model / parameter arena / gradient arena");
+    const ch_model_config &c = m->cfg;
+    CH_REQUIRE(c.adapter_dim > 0, "trainer: the model has no adapters (nothing to train in the encoder)");
+    CH_REQUIRE(max_batch >= 1, "trainer: max_batch must be >= 1");
+    CH_REQUIRE(m->layers[0].qkv_wf != nullptr, "trainer: the model was built without the LayerNorm-folded weights");
+    ch_trainer *t = new ch_trainer();
+    t->m = m;
+    t->max_batch = max_batch;
+    t->params = params;
+    t->grads = grads;
+    t->ad_numel = adapter_numel(c);
+    const int D = c.dim, L = c.layers, M = c.ffn, b = c.adapter_dim, bpad = m->bpad, Q = c.ncontext;
+    const int64_t rows = round_up64((int64_t)max_batch * m->ntok, 256) + 256;
+    const int64_t prows = round_up64((int64_t)max_batch * m->np, 256) + 256;
+    t->rows_alloc = rows;
+    t->prow_alloc = prows;
+    bool ok = true;
+    auto bf = [&](int64_t cols) { return (bf16_t *)talloc(t, sizeof(bf16_t) * rows * cols, ok); };
+    auto st = [&]() { return (float *)talloc(t, sizeof(float) * rows * (D / 64) * 2, ok); };
+    t->ad.resize(L * 2);
+    t->lt.resize(L);
+    t->sv.resize(L);
+    for (int i = 0; i < L * 2 && ok; ++i) {
+        AdWork &w = t->ad[i];
+        w.down_wf = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)bpad * D, ok);
+        w.fold_c = (float *)talloc(t, sizeof(float) * bpad, ok);
+        w.fold_d = (float *)talloc(t, sizeof(float) * bpad, ok);
+        w.up_w = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)D * bpad, ok);
+        w.up_wT = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)bpad * D, ok);
+        w.down_wgT = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)D * bpad, ok);
+    }
+    hipStream_t s = nullptr;
+    for (int l = 0; l < L && ok; ++l) {
+        const LayerW &w = m->layers[l];
+        LayerT &x = t->lt[l];
+        x.qkv_wgT = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)D * 3 * D, ok);
+        x.out_wT = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)D * D, ok);
+        x.fc1_wgT = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)D * M, ok);
+        x.fc2_wT = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)M * D, ok);
+        if (!ok) break;
+        // the folded weights already carry gamma: W' = bf16(W * gamma) [N, D] -> (W')^T [D, N]
+        int e = ch_transpose_bf16(w.qkv_wf, 3 * D, D, D, x.qkv_wgT, 3 * D, s);
+        e |= ch_transpose_bf16(w.out_w, D, D, D, x.out_wT, D, s);
+        e |= ch_transpose_bf16(w.fc1_wf, M, D, D, x.fc1_wgT, M, s);
+        e |= ch_transpose_bf16(w.fc2_w, D, M, M, x.fc2_wT, D, s);
+        if (e) ok = false;
+        Saved &v = t->sv[l];
+        v.Xn1 = bf(D); v.QKV = bf(3 * D); v.AO = bf(D); v.A = bf(D); v.P1 = bf(bpad); v.G1 = bf(bpad); v.Xn2 = bf(D);
+        v.F1pre = bf(M); v.A2 = bf(D); v.P2 = bf(bpad); v.G2 = bf(bpad);
+        v.st1 = st(); v.stA = st(); v.st2 = st(); v.stA2 = st();
+    }
+    t->H = (float *)talloc(t, sizeof(float) * rows * D, ok);
+    t->dH = (float *)talloc(t, sizeof(float) * rows * D, ok);
+    t->dHb = bf(D); t->dMb = bf(D); t->tD = bf(D); t->tD2 = bf(D); t->tB = bf(bpad); t->tM = bf(M); t->tQKV = bf(3 * D); t->F1act = bf(M);
+    t->XnDummy = bf(D);
+    t->stDummy = st();
+    t->PATCH = (bf16_t *)talloc(t, sizeof(bf16_t) * prows * m->Kp, ok);
+    t->ctx = (float *)talloc(t, sizeof(float) * Q * D, ok);
+    t->dctx_sum = (float *)talloc(t, sizeof(float) * Q * D, ok);
+    const int64_t max_rows = (int64_t)max_batch * m->ntok;
+    t->ws_wgrad = (float *)talloc(t, sizeof(float) * std::max(ch_wgrad_ws_floats(max_rows, D, bpad), ch_wgrad_ws_floats(max_rows, bpad, D)), ok);
+    t->ws_colsum = (float *)talloc(t, sizeof(float) * ch_colsum_ws_floats(std::max(D, bpad)), ok);
+    t->G = (float *)talloc(t, sizeof(float) * (size_t)D * bpad, ok);
+    t->T = (float *)talloc(t, sizeof(float) * (size_t)bpad * D, ok);
+    t->cu = (float *)talloc(t, sizeof(float) * D, ok);
+    t->cd = (float *)talloc(t, sizeof(float) * bpad, ok);
+    (void)b;
+    if (ok && ch_trainer_refresh(t, nullptr) != 0) ok = false;
+    if (ok && hipDeviceSynchronize() != hipSuccess) {
+        ch_set_error("trainer: device error while preparing the working copies");
+        ok = false;
+    }
+    if (!ok) {
+        ch_trainer_destroy(t);
+        return 4;
+    }
+    *out = t;
+    return 0;
+}
+
+extern "C" int64_t ch_trainer_bytes(const ch_trainer *t) { return t ? (int64_t)t->bytes : 0; }
+
+extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image_dtype, int32_t B, const float *concept_tokens,
+                                float *out_hash_features, float *out_cls, void *stream) {
+    CH_REQUIRE(t != nullptr && images != nullptr && concept_tokens != nullptr && out_hash_features != nullptr, "train_forward: null argument");
+    CH_REQUIRE(B >= 1 && B <= t->max_batch, "train_forward: batch outside [1, max_batch]");
+    CH_REQUIRE(image_dtype == 0 || image_dtype == 1, "train_forward: image_dtype must be 0 (fp32) or 1 (bf16)");
+    hipStream_t s = (hipStream_t)stream;
+    ch_model *m = t->m;
+    const ch_model_config &c = m->cfg;
+    const int D = c.dim, M = c.ffn, ntok = m->ntok, np = m->np, bpad = m->bpad, Q = c.ncontext, L = c.layers;
+    const int rows = B * ntok;
+    t->B = B;
+    t->forward_done = false;
+    CH_CHECK_HIP(hipMemcpyAsync(t->ctx, concept_tokens, sizeof(float) * Q * D, hipMemcpyDeviceToDevice, s));
+    // ---- embeddings (models/arch/coop.py:452-472): im2col + patch GEMM, CLS / position / concept tokens, pre-LN
+    if (int e = ch_im2col(images, image_dtype, B, c.image_size, c.patch, m->Kp, t->PATCH, s)) return e;
+    {
+        GemmParams p{};
+        p.X = t->PATCH; p.W = m->patch_w; p.M = B * np; p.N = D; p.K = m->Kp; p.X_rows_alloc = t->prow_alloc;
+        p.resid = t->H; p.ldr = D; p.pos = m->pos; p.tokens_per_img = ntok; p.patches_per_img = np; p.pp_min_k = m->pp_min_k;
+        if (int e = ch_gemm_bf16(p, EPI_PATCH, s)) return e;
+    }
+    const LayerW &w0 = m->layers[0];
+    if (int e = ch_assemble_preln(t->H, B, ntok, np, D, m->cls_pos0, t->ctx, m->pre_w, m->pre_b, w0.ln1_w, w0.ln1_b, c.ln_eps,
+                                  t->XnDummy, s))
+        return e;
+    if (int e = ch_hb_stats(t->H, rows, D, t->sv[0].Xn1, t->sv[0].st1, s)) return e;
+    for (int l = 0; l < L; ++l) {
+        const LayerW &w = m->layers[l];
+        Saved &v = t->sv[l];
+        GemmCall g;
+        // attention block
+        g = GemmCall{3 * D, D, v.Xn1, w.qkv_wf, w.qkv_d, EPI_FOLD_BIAS};
+        g.out = v.QKV; g.ldo = 3 * D; g.stats_in = v.st1; g.fold_c = w.qkv_c; g.eps = c.ln_eps;
+        if (int e = gemm(t, rows, g, s)) return e;
+        if (int e = ch_attention(v.QKV, B, ntok, c.heads, v.AO, s)) return e;
+        g = GemmCall{D, D, v.AO, w.out_w, w.out_b, EPI_BIAS_STATS};
+        g.out = v.A; g.ldo = D; g.stats_out = v.stA;
+        if (int e = gemm(t, rows, g, s)) return e;
+        for (int a = 0; a < 2; ++a) {
+            const AdWork &aw = t->ad[l * 2 + a];
+            const AdPtr ap = ad_ptrs(t->params + (int64_t)(l * 2 + a) * t->ad_numel, c);
+            const bf16_t *in = a == 0 ? v.A : v.A2;
+            const float *stin = a == 0 ? v.stA : v.stA2;
+            bf16_t *P = a == 0 ? v.P1 : v.P2, *G = a == 0 ? v.G1 : v.G2;
+            g = GemmCall{bpad, D, in, aw.down_wf, aw.fold_d, EPI_FOLD_BIAS};
+            g.out = P; g.ldo = bpad; g.stats_in = stin; g.fold_c = aw.fold_c; g.eps = 1e-5f;
+            if (int e = gemm(t, rows, g, s)) return e;
+            if (int e = ch_act_fwd(P, (int64_t)rows * bpad, 1, G, s)) return e;   // nn.GELU() (models/layers/adapter.py:36)
+            g = GemmCall{D, bpad, G, aw.up_w, ap.up_b, EPI_SCALE_RESID_STATS};
+            g.resid = t->H; g.scale = ap.scale; g.addend = in;
+            if (a == 0) {
+                g.stats_out = v.st2; g.hb_out = v.Xn2;
+            } else {
+                g.stats_out = l + 1 < L ? t->sv[l + 1].st1 : t->stDummy;
+                g.hb_out = l + 1 < L ? t->sv[l + 1].Xn1 : t->XnDummy;
+            }
+            if (int e = gemm(t, rows, g, s)) return e;
+            if (a == 0) {  // MLP
+                g = GemmCall{M, D, v.Xn2, w.fc1_wf, w.fc1_d, EPI_FOLD_BIAS};
+                g.out = v.F1pre; g.ldo = M; g.stats_in = v.st2; g.fold_c = w.fc1_c; g.eps = c.ln_eps;
+                if (int e = gemm(t, rows, g, s)) return e;
+                if (int e = ch_act_fwd(v.F1pre, (int64_t)rows * M, c.act, t->F1act, s)) return e;
+                g = GemmCall{D, M, t->F1act, w.fc2_w, w.fc2_b, EPI_BIAS_STATS};
+                g.out = v.A2; g.ldo = D; g.stats_out = v.stA2;
+                if (int e = gemm(t, rows, g, s)) return e;
+            }
+        }
+    }
+    if (int e = ch_gather_concept_rows(t->H, B, ntok, Q, D, out_hash_features, s)) return e;
+    if (out_cls) {  // CLS rows of the final residual (the pooled branch, models/arch/coop.py:484-499, is not part of the loss)
+        CH_CHECK_HIP(hipMemcpy2DAsync(out_cls, sizeof(float) * D, t->H, sizeof(float) * (size_t)ntok * D, sizeof(float) * D, B,
+                                      hipMemcpyDeviceToDevice, s));
+    }
+    t->forward_done = true;
+    return 0;
+}
+
+extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, float *d_concept_tokens, void *stream) {
+    CH_REQUIRE(t != nullptr && d_hash_features != nullptr && d_concept_tokens != nullptr, "train_backward: null argument");
+    CH_REQUIRE(t->forward_done, "train_backward: call ch_train_forward first (its saved activations are what backward reads)");
+    hipStream_t s = (hipStream_t)stream;
+    ch_model *m = t->m;
+    const ch_model_config &c = m->cfg;
+    const int D = c.dim, M = c.ffn, ntok = m->ntok, bpad = m->bpad, Q = c.ncontext, L = c.layers, b = c.adapter_dim, B = t->B;
+    const int rows = B * ntok;
+    const float *zero = m->zero_bias;
+    // the loss reads only hash_features = H[:, -Q:, :] (models/arch/coop.py:484-486): dH is zero elsewhere
+    if (int e = ch_scatter_concept_rows(d_hash_features, B, ntok, Q, D, t->dH, t->dHb, s)) return e;
+
+    // gradient of the block output arrives in dH / dHb; leaves d(branch input) = dH + adapter path in dMb (bf16 only)
+    auto adapter_bwd = [&](int l, int a) -> int {
+        const AdWork &aw = t->ad[l * 2 + a];
+        const Saved &v = t->sv[l];
+        float *pbase = t->params + (int64_t)(l * 2 + a) * t->ad_numel;
+        const AdPtr ap = ad_ptrs(pbase, c);
+        const bf16_t *in = a == 0 ? v.A : v.A2, *P = a == 0 ? v.P1 : v.P2, *G = a == 0 ? v.G1 : v.G2;
+        const float *stin = a == 0 ? v.stA : v.stA2;
+        // up projection: weight-gradient products (unscaled) and dgrad
+        if (int e = ch_wgrad_tn(t->dHb, D, G, bpad, rows, t->rows_alloc, D, bpad, t->G, t->ws_wgrad, s)) return e;
+        if (int e = ch_colsum(t->dH, 1, D, rows, D, t->cu, t->ws_colsum, s)) return e;
+        GemmCall g{bpad, D, t->dHb, aw.up_wT, zero, EPI_BIAS};
+        g.out = t->tB; g.ldo = bpad;
+        if (int e = gemm(t, rows, g, s)) return e;
+        if (int e = ch_act_bwd(t->tB, P, (int64_t)rows * bpad, 1, ap.scale, t->tB, s)) return e;   // dpre, in place
+        // down projection + adapter LayerNorm
+        if (int e = ch_normalize_bf16(in, stin, rows, D, 1e-5f, t->tD2, s)) return e;
+        if (int e = ch_wgrad_tn(t->tB, bpad, t->tD2, D, rows, t->rows_alloc, bpad, D, t->T, t->ws_wgrad, s)) return e;
+        if (int e = ch_colsum(t->tB, 0, bpad, rows, bpad, t->cd, t->ws_colsum, s)) return e;
+        if (int e = ch_adapter_grads(t->G, t->cu, t->T, t->cd, pbase, D, b, bpad, t->grads + (int64_t)(l * 2 + a) * t->ad_numel, s)) return e;
+        g = GemmCall{D, bpad, t->tB, aw.down_wgT, zero, EPI_BIAS};
+        g.out = t->tD; g.ldo = D;
+        if (int e = gemm(t, rows, g, s)) return e;
+        return ch_ln_bwd(t->tD, in, stin, rows, D, 1e-5f, t->dH, nullptr, t->dMb, s);
+    };
+
+    for (int l = L - 1; l >= 0; --l) {
+        const Saved &v = t->sv[l];
+        const LayerT &x = t->lt[l];
+        // ---- x_out = x_mid + m + adapter_2(m),  m = fc2(act(fc1(LN2(x_mid))))
+        if (int e = adapter_bwd(l, 1)) return e;
+        GemmCall g{M, D, t->dMb, x.fc2_wT, zero, EPI_BIAS};
+        g.out = t->tM; g.ldo = M;
+        if (int e = gemm(t, rows, g, s)) return e;
+        if (int e = ch_act_bwd(t->tM, v.F1pre, (int64_t)rows * M, c.act, nullptr, t->tM, s)) return e;
+        g = GemmCall{D, M, t->tM, x.fc1_wgT, zero, EPI_BIAS};
+        g.out = t->tD; g.ldo = D;
+        if (int e = gemm(t, rows, g, s)) return e;
+        if (int e = ch_ln_bwd(t->tD, v.Xn2, v.st2, rows, D, c.ln_eps, t->dH, t->dH, t->dHb, s)) return e;
+        // ---- x_mid = x_in + a + adapter_1(a),  a = out_proj(attention(qkv(LN1(x_in))))
+        if (int e = adapter_bwd(l, 0)) return e;
+        g = GemmCall{D, D, t->dMb, x.out_wT, zero, EPI_BIAS};
+        g.out = t->tD; g.ldo = D;
+        if (int e = gemm(t, rows, g, s)) return e;
+        if (int e = ch_attention_bwd(v.QKV, t->tD, B, ntok, c.heads, t->tQKV, s)) return e;
+        g = GemmCall{D, 3 * D, t->tQKV, x.qkv_wgT, zero, EPI_BIAS};
+        g.out = t->tD; g.ldo = D;
+        if (int e = gemm(t, rows, g, s)) return e;
+        if (int e = ch_ln_bwd(t->tD, v.Xn1, v.st1, rows, D, c.ln_eps, t->dH, t->dH, t->dHb, s)) return e;
+    }
+    // ---- concept tokens: rows ntok-Q.. of every image are pre_layrnorm(ctx[q]) (models/arch/coop.py:470-472)
+    if (int e = ch_concept_rows_sum(t->dH, B, ntok, Q, D, t->dctx_sum, s)) return e;
+    return ch_small_ln_bwd(t->dctx_sum, t->ctx, m->pre_w, Q, D, c.ln_eps, d_concept_tokens, s);
+}
+
+// ---- kernel taps for the tests -------------------------------------------------------------------------------------------------
+extern "C" int ch_debug_attention_bwd(const void *qkv, const void *dO, int32_t B, int32_t ntok, int32_t heads, void *dqkv, void *stream) {
+    CH_REQUIRE(qkv && dO && dqkv, "debug_attention_bwd: null argument");
+    return ch_attention_bwd((const bf16_t *)qkv, (const bf16_t *)dO, B, ntok, heads, (bf16_t *)dqkv, (hipStream_t)stream);
+}
+extern "C" int ch_debug_wgrad(const void *A, int32_t lda, const void *Bm, int32_t ldb, int64_t rows, int64_t rows_alloc, int32_t N,
+                              int32_t K, float *out, void *stream) {
+    CH_REQUIRE(A && Bm && out, "debug_wgrad: null argument");
+    float *ws = nullptr;
+    CH_CHECK_HIP(hipMalloc((void **)&ws, sizeof(float) * ch_wgrad_ws_floats(rows, N, K)));
+    const int e = ch_wgrad_tn((const bf16_t *)A, lda, (const bf16_t *)Bm, ldb, rows, rows_alloc, N, K, out, ws, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(ws);
+    return e;
+}
+// row statistics of x are computed here (hb_stats on an fp32 copy is what the chain does; the tap takes bf16 x and derives the
+// partials from it through an fp32 round trip), then ln_bwd; xhat_out (optional) receives normalize(x)
+extern "C" int ch_debug_ln_bwd(const void *dyg, const void *x, int64_t rows, int32_t D, float eps, const float *dres_in, float *dres_out,
+                               void *out_b, void *xhat_out, void *stream) {
+    CH_REQUIRE(dyg && x && dres_in, "debug_ln_bwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    float *st = nullptr, *xf = nullptr;
+    bf16_t *hb = nullptr;
+    CH_CHECK_HIP(hipMalloc((void **)&st, sizeof(float) * rows * (D / 64) * 2));
+    CH_CHECK_HIP(hipMalloc((void **)&xf, sizeof(float) * rows * D));
+    CH_CHECK_HIP(hipMalloc((void **)&hb, sizeof(bf16_t) * rows * D));
+    int e = 0;
+    {   // bf16 -> fp32 (exact) by a strided 2-byte copy into the high halves
+        CH_CHECK_HIP(hipMemsetAsync(xf, 0, sizeof(float) * rows * D, s));
+        CH_CHECK_HIP(hipMemcpy2DAsync((char *)xf + 2, 4, x, 2, 2, (size_t)rows * D, hipMemcpyDeviceToDevice, s));
+    }
+    e = ch_hb_stats(xf, rows, D, hb, st, s);
+    if (!e) e = ch_ln_bwd((const bf16_t *)dyg, (const bf16_t *)x, st, rows, D, eps, dres_in, dres_out, (bf16_t *)out_b, s);
+    if (!e && xhat_out) e = ch_normalize_bf16((const bf16_t *)x, st, rows, D, eps, (bf16_t *)xhat_out, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(st);
+    (void)hipFree(xf);
+    (void)hipFree(hb);
+    return e;
+}
+extern "C" int ch_debug_act(const void *g, const void *pre, int64_t n, int32_t act, const float *scale_ptr, int32_t backward, void *out,
+                            void *stream) {
+    CH_REQUIRE(pre && out, "debug_act: null argument");
+    if (backward) return ch_act_bwd((const bf16_t *)g, (const bf16_t *)pre, n, act, scale_ptr, (bf16_t *)out, (hipStream_t)stream);
+    return ch_act_fwd((const bf16_t *)pre, n, act, (bf16_t *)out, (hipStream_t)stream);
+}

@@ -96,6 +96,44 @@ int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, f
 int ch_encode_hidden(ch_model *m, const void *images, int32_t image_dtype, int32_t B, int32_t layer,
                      float *out_hidden, void *stream);
 
+/* ---- Training step of the adapters -----------------------------------------------------------
+ * Replaces, for everything that touches the [B*N, *] activations: the forward and `loss.backward()` of
+ * COOPTrainer.train_one_batch (trainers/coop.py:107-131) through CLIPEncoderLayerWithAdapter.forward
+ * (models/layers/adapter.py:127-177) and Adapter.forward (:46-60), with the backbone frozen and the adapters trainable
+ * (trainers/base.py:133-152, configs/model/concept_hash_final_v1_nosa_apt.yaml `backbone_lr_scale: 0`).  The concept-token
+ * generator (4 tokens), the hashing head on [B,Q,D] and the loss stay with the caller's autograd, which passes
+ * `concept_tokens` in, takes `hash_features` out, and exchanges their gradients.
+ *
+ * Adapter parameter arena (fp32, device, CALLER-owned; the optimizer updates it in place): adapters in (layer, adapter 1, adapter
+ * 2) order, each  [adapter_layer_norm.weight D][.bias D][down_proj.weight b*D][down_proj.bias b][up_proj.weight D*b]
+ * [up_proj.bias D][scale 1];  the gradient arena has the same layout and is OVERWRITTEN by ch_train_backward. */
+typedef struct ch_trainer ch_trainer;
+/* total floats of the adapter arena of this model (0 without adapters) */
+int64_t ch_adapter_arena_numel(const ch_model *m);
+/* Shares the frozen weights of `m` (which must outlive the trainer); allocates the per-layer saved activations for max_batch. */
+int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, float *grads, ch_trainer **out);
+void ch_trainer_destroy(ch_trainer *t);
+int64_t ch_trainer_bytes(const ch_trainer *t);
+/* Re-derive the bf16 / LayerNorm-folded / transposed working copies from the parameter arena: call after every optimizer step. */
+int ch_trainer_refresh(ch_trainer *t, void *stream);
+/* Forward in training mode (adapter dropout 0, as the reference configs have it).
+ *   concept_tokens    [Q,D] fp32 device: forward_hash_query() output (models/arch/coop.py:413-427), before pre_layrnorm
+ *   out_hash_features [B,Q,D] fp32: last-layer states of the concept tokens (coop.py:503-509)
+ *   out_cls           [B,D] fp32 last-layer CLS states (optional, NULL) */
+int ch_train_forward(ch_trainer *t, const void *images, int32_t image_dtype, int32_t B, const float *concept_tokens,
+                     float *out_hash_features, float *out_cls, void *stream);
+/* Backward of the last ch_train_forward: d_hash_features [B,Q,D] fp32 in; adapter gradients into the gradient arena,
+ * d_concept_tokens [Q,D] fp32 out. */
+int ch_train_backward(ch_trainer *t, const float *d_hash_features, float *d_concept_tokens, void *stream);
+/* Kernel taps of the training step (tests): see train_kernels.hip / attention_bwd.hip. */
+int ch_debug_attention_bwd(const void *qkv, const void *dO, int32_t B, int32_t ntok, int32_t heads, void *dqkv, void *stream);
+int ch_debug_wgrad(const void *A, int32_t lda, const void *Bm, int32_t ldb, int64_t rows, int64_t rows_alloc, int32_t N, int32_t K,
+                   float *out, void *stream);
+int ch_debug_ln_bwd(const void *dyg, const void *x, int64_t rows, int32_t D, float eps, const float *dres_in, float *dres_out,
+                    void *out_b, void *xhat_out, void *stream);
+int ch_debug_act(const void *g, const void *pre, int64_t n, int32_t act, const float *scale_ptr, int32_t backward, void *out,
+                 void *stream);
+
 /* Launch profiler for bench.py's roofline: between begin and end every kernel launch of ch_encode is bracketed by
  * HIP events on the caller's stream (capacity max_launches events; launches beyond it are not recorded).
  * ch_model_profile_end waits for the last recorded event and returns, per category, the summed launch durations

@@ -14,12 +14,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/enc_trace -o enc -- $
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/enc_fetch -o enc -- $BENCH1 --steps 3 --warmup 1 > /dev/null 2> $O/enc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/enc_write -o enc -- $BENCH1 --steps 3 --warmup 1 > /dev/null 2> $O/enc_write.err || exit 1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/enc_mfma -o enc -- $BENCH1 --steps 3 --warmup 1 > /dev/null 2> $O/enc_mfma.err || exit 1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/enc_lds -o enc -- $BENCH1 --steps 3 --warmup 1 > /dev/null 2> $O/enc_lds.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ham_trace -o ham -- python3 $R/tools/hamming_scan_bench.py --mode both --reps 3 > $O/ham_1m_timing.txt 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --output-format csv -d $O/ham_pmc -o ham -- python3 $R/tools/hamming_scan_bench.py --mode both --reps 1 > /dev/null 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ham_nab -o ham -- python3 $R/tools/hamming_scan_bench.py --mode both --queries 24633 --rows 23929 --nbit 64 --classes 555 --reps 3 > $O/ham_nabirds_timing.txt 2>&1 || exit 1
 cd $R
 python tools/make_traffic_json.py $O/enc_fetch/enc_counter_collection.csv $O/enc_write/enc_counter_collection.csv $O/gemm_traffic.json
 python tools/pmc_summary.py $O/enc_mfma/enc_counter_collection.csv > $O/enc_mfma_summary.txt
+python tools/pmc_summary.py $O/enc_lds/enc_counter_collection.csv > $O/enc_lds_summary.txt
 python tools/pmc_summary.py $O/ham_pmc/ham_counter_collection.csv > $O/ham_pmc_summary.txt
 python tools/tile_timeline.py > $O/gemm_tile_timeline.txt 2>&1
 python tools/precision_probe.py > $O/precision_probe.txt 2>&1
