@@ -1,0 +1,162 @@
+"""Training step of the ConceptHash adapters on the MI355X HIP library (C-ABI `ch_trainer_*` / `ch_train_*`,
+include/concepthash_hip.h).
+
+What runs where (reference: trainers/coop.py:107-131 `train_one_batch`):
+  * HIP library: the encoder forward with saved activations and its backward -- everything on the [B*N, *] activations, the
+    gradients of the 24 adapters' parameters, and the gradient w.r.t. the concept tokens;
+  * this module: the parameter plumbing.  The adapters' parameters live in ONE fp32 device arena (the layout
+    `ch_adapter_arena_numel` describes); the `nn.Parameter`s of the adapter modules are re-pointed at views of it, their
+    `.grad`s at views of the gradient arena the library overwrites, so an ordinary optimizer updates the arena in place and
+    `refresh()` re-derives the library's bf16 / folded / transposed working copies;
+  * the caller's autograd: the 4-token concept generator, the hashing head on [B, Q, D] and the loss (models/arch/coop.py,
+    models/loss/coop.py) -- a few MFLOP per step -- joined to the library by `EncoderFunction`.
+
+There is no CPU fallback: without the HIP library (or without a GPU) construction raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Sequence
+
+import torch
+
+from . import _lib
+from .encoder import VM, ConceptHashEncoder
+
+ADAPTER_FIELDS = ("adapter_layer_norm.weight", "adapter_layer_norm.bias", "down_proj.weight", "down_proj.bias", "up_proj.weight",
+                  "up_proj.bias", "scale")
+
+
+class TrainEngine:
+    """Owns a frozen-weights `ch_model` + a `ch_trainer` for batches up to `max_batch`, and the adapter arenas.
+
+    adapters: list over layers of (adapt_mlp_1, adapt_mlp_2) modules whose parameters are re-pointed into the arena."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], adapters: Sequence[Sequence[torch.nn.Module]], heads: int,
+                 upt_heads: int = 8, act: str = "quick_gelu", max_batch: int = 64, device=None, image_size=None):
+        self.lib = _lib.load()
+        # the frozen model: its own workspace is never used by training, so it is sized for one image
+        self.encoder = ConceptHashEncoder(state_dict, heads=heads, upt_heads=upt_heads, act=act, max_batch=1, device=device,
+                                          image_size=image_size)
+        self.device = self.encoder.device
+        self.cfg = self.encoder.cfg
+        self.max_batch = int(max_batch)
+        n = int(self.lib.ch_adapter_arena_numel(self.encoder._h))
+        if n <= 0:
+            raise RuntimeError("the model has no adapters: nothing to train in the encoder")
+        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._views: List[tuple] = []   # (parameter, grad view)
+        D, b, L = self.cfg["dim"], self.cfg["adapter_dim"], self.cfg["layers"]
+        sizes = (D, D, b * D, b, D * b, D, 1)
+        if len(adapters) != L or any(len(pair) != 2 for pair in adapters):
+            raise ValueError("adapters must be a list over layers of (adapt_mlp_1, adapt_mlp_2)")
+        off = 0
+        with torch.no_grad():
+            for pair in adapters:
+                for mod in pair:
+                    named = dict(mod.named_parameters())
+                    for field, size in zip(ADAPTER_FIELDS, sizes):
+                        p = named[field]
+                        if p.numel() != size:
+                            raise ValueError(f"adapter parameter {field} has {p.numel()} elements, expected {size}")
+                        view = self.params[off:off + size].view(p.shape)
+                        view.copy_(p.detach().to(self.device, torch.float32))
+                        p.data = view                     # the module's parameter IS the arena from here on
+                        self._views.append((p, self.grads[off:off + size].view(p.shape)))
+                        off += size
+        assert off == n
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ch_trainer_create(self.encoder._h, self.max_batch, _lib.ptr(self.params), _lib.ptr(self.grads),
+                                                  ctypes.byref(h)), "ch_trainer_create")
+        self._t = h
+        self._stale = False
+        # makes autograd call EncoderFunction.backward (which produces the adapters' gradients) even when nothing upstream of the
+        # concept tokens requires a gradient
+        self.anchor = torch.zeros((), device=self.device, requires_grad=True)
+
+    def close(self):
+        if getattr(self, "_t", None) is not None and self._t.value:
+            self.lib.ch_trainer_destroy(self._t)
+            self._t = ctypes.c_void_p()
+        if getattr(self, "encoder", None) is not None:
+            self.encoder.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.lib.ch_trainer_bytes(self._t)) + self.encoder.device_bytes
+
+    def adapter_parameters(self) -> List[torch.nn.Parameter]:
+        return [p for p, _ in self._views]
+
+    def mark_stale(self):
+        """The arena changed (an optimizer step): the working copies are re-derived before the next forward."""
+        self._stale = True
+
+    def sync_versions(self):
+        """In-place updates of the adapter parameters (optimizer.step(), load_state_dict) bump their tensor versions: compare
+        with the versions seen at the last refresh."""
+        ver = sum(p._version for p, _ in self._views)
+        if ver != getattr(self, "_ver", None):
+            self._ver = ver
+            self._stale = True
+
+    def refresh(self, stream=None):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ch_trainer_refresh(self._t, _lib.stream_ptr(stream)), "ch_trainer_refresh")
+        self._stale = False
+
+    def forward(self, images: torch.Tensor, concept_tokens: torch.Tensor, want_cls: bool = False):
+        self.encoder._check_images(images)
+        B = images.shape[0]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds the trainer's max_batch {self.max_batch}")
+        c = self.cfg
+        ct = concept_tokens.detach().to(self.device, torch.float32).reshape(c["ncontext"], c["dim"]).contiguous()
+        if self._stale:
+            self.refresh()
+        images = images.contiguous()
+        hf = torch.empty(B, c["ncontext"], c["dim"], dtype=torch.float32, device=self.device)
+        cls = torch.empty(B, c["dim"], dtype=torch.float32, device=self.device) if want_cls else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ch_train_forward(self._t, _lib.ptr(images), 0 if images.dtype == torch.float32 else 1, B,
+                                                 _lib.ptr(ct), _lib.ptr(hf), _lib.ptr(cls), _lib.stream_ptr()), "ch_train_forward")
+        return hf, cls
+
+    def backward(self, d_hash_features: torch.Tensor) -> torch.Tensor:
+        c = self.cfg
+        g = d_hash_features.detach().to(self.device, torch.float32).contiguous()
+        dct = torch.empty(c["ncontext"], c["dim"], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ch_train_backward(self._t, _lib.ptr(g), _lib.ptr(dct), _lib.stream_ptr()), "ch_train_backward")
+        for p, gview in self._views:      # optimizer.zero_grad(set_to_none=True) drops the views: put them back
+            p.grad = gview
+        return dct
+
+
+class EncoderFunction(torch.autograd.Function):
+    """hash_features = encoder(images; concept_tokens, adapters): forward / backward by the HIP library.  The adapters'
+    gradients do not travel through autograd -- backward writes them into the parameters' `.grad` views (TrainEngine)."""
+
+    @staticmethod
+    def forward(ctx, concept_tokens, images, engine: TrainEngine, anchor):
+        hf, _ = engine.forward(images, concept_tokens)
+        ctx.engine = engine
+        ctx.ct_shape = concept_tokens.shape
+        return hf
+
+    @staticmethod
+    def backward(ctx, d_hf):
+        dct = ctx.engine.backward(d_hf)
+        return dct.view(ctx.ct_shape), None, None, None
+
+
+def adapter_modules(vision_model) -> list:
+    return [(layer.adapt_mlp_1, layer.adapt_mlp_2) for layer in vision_model.encoder.layers]

@@ -5,8 +5,11 @@ What is kept: constructor arguments as the Hydra config passes them
 (configs/model/concept_hash_final_v1_nosa_apt.yaml), `state_dict()` / `load_state_dict()` in the reference key layout
 (including the `adapter_params.*` / `trainable_params.*` aliases), `forward(x) ->
 (image_features, dict)` with the reference's output keys, `get_backbone / get_training_modules / get_adapter /
-get_center`.  What is different: torch modules here are parameter holders only -- `forward` hands the parameters to
-`ch_model_create` once (re-done when they change) and every batch to `ch_encode`.  Eval only; training is out of scope.
+get_center`.  What is different: in eval mode the torch modules are parameter holders only -- `forward` hands the parameters to
+`ch_model_create` once (re-done when they change) and every batch to `ch_encode`.  In training mode (reference
+trainers/coop.py:107-131) the encoder forward + backward run in the HIP library (`ch_train_forward` / `ch_train_backward`, the
+adapters' gradients included) and the three tiny pieces around it -- the 4-token concept generator, the hashing head on
+(B, Q, D) and the loss -- run on torch autograd, joined by `concepthash_amd.training.EncoderFunction`.
 """
 from __future__ import annotations
 
@@ -15,6 +18,7 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from concepthash_amd.encoder import ConceptHashEncoder
 from models.layers.adapter import clip_add_adapter_
@@ -144,18 +148,72 @@ class LGHWithoutText(nn.Module):
                                f"unexpected {unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
         res = super().load_state_dict({k: v for k, v in state_dict.items() if k in own}, strict=False, **kw)
         self._engine_key = None
+        self._drop_train_engine()
         return res
 
+    def _drop_train_engine(self):
+        eng = getattr(self, "_train_engine", None)
+        if eng is not None:
+            eng.close()
+        self._train_engine = None
+
     def _apply(self, fn, *a, **k):
+        self._drop_train_engine()          # the adapters' parameters are views of its arena: release before they are replaced
         out = super()._apply(fn, *a, **k)
         self._engine_key = None
         return out
 
-    def train(self, mode: bool = True):
-        if mode:
-            logging.warning("LGHWithFixedPrompt: training mode requested; the MI355X path is inference-only "
-                            "(forward will refuse while training=True)")
-        return super().train(mode)
+    # ---- training mode (reference forward, models/arch/coop.py:524-598, with self.training = True) -----------------------
+    def forward_hash_query(self):
+        """The concept-token generator (reference :413-427, the non-"v2" residual form norm(x) + f(x)) on torch autograd."""
+        ha = self.hash_attention
+        x = self.hash_queries
+        x = ha.norm1(x) + ha.sa(x, x, x)[0]
+        x = ha.norm2(x) + ha.ffn(x)
+        return ha.ffn2(x)                                       # (1, Q, D)
+
+    def forward_concept(self, concept_features):
+        """reference :269-276 with CosSim (models/layers/cossim.py:37-82, group = 1): (B, Q, D) -> (Q, B, C)"""
+        B, Q, D = concept_features.shape
+        x = (concept_features + self.concept_pe).reshape(B * Q, D)
+        logits = F.normalize(x, p=2, dim=-1) @ F.normalize(self.concept_ce.centroids, p=2, dim=-1).t()
+        return logits.reshape(B, Q, -1).transpose(0, 1)
+
+    def _ensure_train_engine(self, device, image_size, batch):
+        from concepthash_amd.training import TrainEngine, adapter_modules
+        if not self.has_adapter:
+            raise NotImplementedError("training on the MI355X path trains the adapters + head (has_adapter=True, the shipped config)")
+        key = (str(device), image_size)
+        eng = getattr(self, "_train_engine", None)
+        if eng is not None and (self._train_engine_key != key or eng.max_batch < batch):
+            eng.close()
+            eng = None
+        if eng is None:
+            eng = TrainEngine(self._projected_state_dict(), adapter_modules(self.backbone.vision_model), heads=self._heads,
+                              upt_heads=self._upt_heads, act=self._act, max_batch=max(batch, getattr(self, "train_max_batch", 0)),
+                              device=device, image_size=image_size)
+            self._train_engine, self._train_engine_key = eng, key
+        return eng
+
+    def _forward_train(self, x):
+        from concepthash_amd.training import EncoderFunction
+        eng = self._ensure_train_engine(x.device, int(x.shape[-1]), int(x.shape[0]))
+        eng.sync_versions()                                      # an optimizer step since the last forward -> re-derive working copies
+        ctx = self.forward_hash_query()
+        hash_features = EncoderFunction.apply(ctx, x, eng, eng.anchor)       # (B, Q, D): HIP forward, HIP backward
+        B = x.shape[0]
+        vision_hash = self.hash_fc(hash_features + self.hash_pe).reshape(B, -1)      # reference :544-553
+        vision_hash = self.hash_bn(vision_hash)                                      # BatchNorm1d on the batch statistics
+        center = self.get_center()
+        v_l2 = F.normalize(vision_hash, dim=-1, p=2)
+        c_l2 = F.normalize(center, dim=-1, p=2)
+        outputs = {"logits_cont": v_l2 @ c_l2.t(), "logits_bin": v_l2 @ (c_l2.sign() / (self.nbit ** 0.5)).t(),
+                   "codes": vision_hash, "image_hidden_states": (), "hash_features": hash_features, "attn_cache": None}
+        if self.concept_reg:
+            outputs["logits_concept"] = self.forward_concept(hash_features)
+        # image_features (pooled CLS -> post-LN -> projection, reference :498-501) feeds no term of the shipped loss
+        # (loss_scales.logits = 0): not computed in training mode
+        return None, outputs
 
     # ---- engine --------------------------------------------------------------------------------------------------
     def _projected_state_dict(self):
@@ -174,12 +232,12 @@ class LGHWithoutText(nn.Module):
         return self._engine
 
     def forward(self, x, y=None, cache=False, update_cache=False):
-        if self.training:
-            raise NotImplementedError("training forward/backward is out of scope for the MI355X path (DESIGN.md section 8)")
         if not x.is_cuda:
             raise RuntimeError("LGHWithFixedPrompt.forward needs a GPU tensor; there is no CPU fallback")
         if x.dim() != 4 or x.shape[-1] != x.shape[-2]:
             raise ValueError("LGHWithFixedPrompt.forward expects square [B, 3, S, S] inputs")
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x)
         eng = self._ensure_engine(x.device, int(x.shape[-1]))
         want = ["codes", "logits_cont", "logits_bin", "hash_features"]
         if self.return_concept_attention:
@@ -223,6 +281,6 @@ class LGHWithFixedPrompt(LGHWithoutText):
 
     def get_center(self):
         """text_projection(center) (reference :624-625) -- small, input independent; evaluated with torch on the
-        parameters' device for callers that ask for it (the encode path folds it inside ch_model_create)."""
-        with torch.no_grad():
-            return self.text_projection(self.center)
+        parameters' device for callers that ask for it (the encode path folds it inside ch_model_create; the training forward
+        differentiates through it)."""
+        return self.text_projection(self.center)

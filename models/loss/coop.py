@@ -1,10 +1,10 @@
-"""`models.loss.coop.LGHLoss` for the evaluation meters only.
+"""`models.loss.coop.LGHLoss`: the training objective (under autograd) and the evaluation meters (callers wrap in no_grad).
 
 The reference's trainer calls the criterion during inference to fill the loss/accuracy meters
 (trainers/coop.py:80-88 -> models/loss/coop.py:120-189).  This restates the terms the shipped config enables
 (`bin_logits`, `cont_logits`, `concept_logits`: margin-cosine cross-entropy with `scale`/`margin`; plus the `quan`
-diagnostic) on the small (B, C) logits the HIP head produces.  It is bookkeeping on a few KB per batch -- not part of the
-encode or retrieve arithmetic -- and it is not a training objective here (no autograd use).  `hash_logits` (mixture of
+diagnostic) on the small (B, C) logits the HIP head produces.  It is a few KB per batch; plain torch ops, differentiable (the training step, trainers/coop.py train_one_batch, backpropagates
+through it into the HIP encoder's backward).  `hash_logits` (mixture of
 softmaxes) is included for completeness; `attn_div_loss` needs attention maps, which the fused path never materialises.
 """
 from __future__ import annotations
@@ -37,7 +37,14 @@ class LGHLoss(nn.Module):
             onehot = F.one_hot(labels, logits.shape[-1]).to(logits.dtype)
             target = labels
         if logits.dim() == 3:
-            onehot = onehot.unsqueeze(0)
+            if labels.dim() == 2:
+                onehot = onehot.unsqueeze(0)
+            else:
+                # reference :55-57: `y_onehot.scatter_(-1, labels[None, :, None], margin)` -- the index has size 1 along the concept
+                # axis, so only concept 0 receives the margin.  Kept as the reference computes it (pinned by tests/golden/train_tiny.npz).
+                first = torch.zeros(logits.shape[0], 1, 1, dtype=logits.dtype, device=logits.device)
+                first[0] = 1
+                onehot = onehot.unsqueeze(0) * first
         return self.scale * (logits - self.margin * onehot), target
 
     def _ce(self, logits, labels, cossim=True):
@@ -62,10 +69,10 @@ class LGHLoss(nn.Module):
         prob = self.lmbd * torch.softmax(l1, -1) + (1 - self.lmbd) * torch.softmax(l2, -1)
         return -(target * torch.log(prob.clamp(min=1e-7))).sum(-1).mean()
 
-    @torch.no_grad()
     def forward(self, outputs, labels):
         codes = outputs["codes"]
-        self.losses["quan"] = 1 - F.cosine_similarity(codes, codes.sign(), dim=-1).mean()
+        with torch.no_grad():
+            self.losses["quan"] = 1 - F.cosine_similarity(codes, codes.sign(), dim=-1).mean()
         total = torch.zeros((), device=codes.device)
         ls = self.loss_scales
         if ls.get("logits", 0) and "logits" in outputs:

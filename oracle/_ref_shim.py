@@ -118,7 +118,7 @@ class FourXEncoderLoop:
 
 
 def build_reference_model(vision_dims, nbit, nclass, ncontext=4, adapter_bottleneck_dim=384, seed=0,
-                          center_dim=512, hidden_act="quick_gelu"):
+                          center_dim=512, hidden_act="quick_gelu", upt_dropout=0.1):
     """Instantiate the reference's LGHWithFixedPrompt around a locally-built (random-init) CLIPModel.
 
     vision_dims: dict(hidden_size, intermediate_size, num_hidden_layers, num_attention_heads,
@@ -152,7 +152,7 @@ def build_reference_model(vision_dims, nbit, nclass, ncontext=4, adapter_bottlen
     bb = _Backbone(clip)
     center = torch.randn(nclass, center_dim).sign()
     text_projection = nn.Sequential(nn.Linear(center_dim, center_dim), nn.ReLU(), nn.Linear(center_dim, nbit))
-    upt = attr_dict(multi=True, num_heads=8, dropout=0.1, ensemble_method="concat", single_hash_fc=True,
+    upt = attr_dict(multi=True, num_heads=8, dropout=upt_dropout, ensemble_method="concat", single_hash_fc=True,
                     hash_pe=True)
     model = ref_coop.LGHWithFixedPrompt(bb, nbit, nclass, ncontext, add_bn=True, use_before_projection=True,
                                         upt_config=upt, fixed_center=center, text_projection=text_projection,

@@ -109,3 +109,40 @@ def test_synthetic_state_dict_roundtrip_through_oracle():
     assert out["codes"].shape == (2, 16) and torch.isfinite(out["codes"]).all()
     d = eo.infer_dims(sd)
     assert (d["D"], d["L"], d["Q"], d["nbit"], d["C"]) == (64, 2, 4, 16, 10)
+
+
+def test_training_step_matches_reference_losses_and_gradients():
+    """train_tiny: one training step of the reference's own model + its own LGHLoss (trainers/coop.py:107-131,
+    models/loss/coop.py:120-189; generated by oracle/gen_train_golden.py with dropout 0).  The restatement in
+    oracle/train_oracle.py must reproduce the loss terms, the train-mode outputs (BatchNorm on batch statistics) and the
+    gradient of EVERY trainable tensor (adapters, concept-token generator, hashing head, text projection)."""
+    from oracle import train_oracle as to
+    sd, z = load_fixture("train_tiny")
+    x = fixture_images(z)
+    labels = torch.from_numpy(z["in/labels"])
+    res = to.train_step_grads(sd, x, labels, heads=int(z["meta/heads"]), upt_heads=int(z["meta/upt_heads"]), act=str(z["meta/act"]))
+    assert abs(float(res["loss"]) - float(z["out/loss"])) < 2e-5
+    for k in ("concept", "cont", "bin"):
+        assert abs(float(res["losses"][k]) - float(z["out/loss_" + k])) < 2e-5, k
+    for k in ("codes", "hash_features", "logits_cont", "logits_bin", "logits_concept"):
+        ref = torch.from_numpy(z["out/" + k])
+        # codes: BatchNorm over a batch of 6 divides by small batch deviations and amplifies fp32 summation-order noise
+        atol = 2e-4 if k == "codes" else ATOL
+        assert torch.allclose(res["out"][k], ref, atol=atol, rtol=0), (k, float((res["out"][k] - ref).abs().max()))
+    gkeys = [k[5:] for k in z.files if k.startswith("grad/")]
+    assert len(gkeys) == 53 and set(gkeys) == set(to.trainable_keys(sd)), set(gkeys) ^ set(to.trainable_keys(sd))
+    for k in gkeys:
+        ref = torch.from_numpy(z["grad/" + k])
+        got = res["grads"][k]
+        assert got.shape == ref.shape, k
+        scale = float(ref.abs().max())
+        # hash_pe: a per-(concept, bit) constant over the batch, removed again by the train-mode BatchNorm -> its true gradient is 0
+        # and both sides hold fp32 noise of ~2e-5
+        # 2e-3 of the tensor's largest gradient: the train-mode BatchNorm over 6 samples divides by small batch deviations; an fp64
+        # run of this oracle sits 3e-4..9e-4 (relative) from BOTH the reference's fp32 gradients and this oracle's fp32 gradients
+        assert float((got - ref).abs().max()) <= 5e-5 + 2e-3 * scale, (k, float((got - ref).abs().max()), scale)
+    # running statistics after the step (BatchNorm1d momentum 0.1, unbiased variance)
+    rm = 0.9 * sd["hash_bn.running_mean"] + 0.1 * res["out"]["bn_batch_mean"]
+    rv = 0.9 * sd["hash_bn.running_var"] + 0.1 * res["out"]["bn_batch_var_unbiased"]
+    assert torch.allclose(rm, torch.from_numpy(z["out/bn_running_mean"]), atol=1e-5)
+    assert torch.allclose(rv, torch.from_numpy(z["out/bn_running_var"]), atol=1e-5)

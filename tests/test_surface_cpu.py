@@ -12,13 +12,13 @@ from concepthash_amd import config as cfglib
 CONFIGS = os.path.join(ROOT, "configs")
 
 
-def _model_like_fixture(z, sd):
+def _model_like_fixture(z, sd, image_size=64):
     from models.arch.coop import LGHWithFixedPrompt
     from models.backbone.clip import CLIP
     D = sd["backbone.vision_model.pre_layrnorm.weight"].shape[0]
     dims = dict(hidden_size=D, num_hidden_layers=2, num_attention_heads=int(z["meta/heads"]),
                 intermediate_size=sd["backbone.vision_model.encoder.layers.0.mlp.fc1.weight"].shape[0],
-                patch_size=sd["backbone.vision_model.embeddings.patch_embedding.weight"].shape[-1], image_size=64,
+                patch_size=sd["backbone.vision_model.embeddings.patch_embedding.weight"].shape[-1], image_size=image_size,
                 projection_dim=sd["hash_queries"].shape[2], hidden_act=str(z["meta/act"]))
     nbit = sd["hash_fc.weight"].shape[0] * 4
     C, cd = sd["center"].shape
