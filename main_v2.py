@@ -4,9 +4,9 @@
     python main_v2.py --config-name val.yaml logdir=<run dir> dataset=cub200 [R=-1] [PRs=[1,5,10]] [batch_size=64] ...
     python main_v2.py exp=extract model=concept_hash_final_v1_nosa_apt dataset=synthetic_cub200 ...
 
-`exp` dispatch: validation -> load <logdir>/config.yaml, overlay the evaluation knobs, RetrievalEvaluation;
-descriptor / extract -> RetrievalEvaluation on the composed config; hashing / general (training) are out of scope for
-the MI355X path and say so.  Uses Hydra when it is installed; otherwise `concepthash_amd.config` composes the same YAML
+`exp` dispatch: hashing -> RetrievalExperiment (train the adapters + hashing head, frozen backbone); validation -> load
+<logdir>/config.yaml, overlay the evaluation knobs, RetrievalEvaluation; descriptor / extract -> RetrievalEvaluation on the
+composed config; general (the reference's train-without-eval variant) is not built.  Uses Hydra when it is installed; otherwise `concepthash_amd.config` composes the same YAML
 tree (hydra-core / omegaconf are absent from the target image).
 """
 from __future__ import annotations
@@ -31,9 +31,14 @@ EVAL_KEYS = ("dataset", "data_dir", "work_dir", "eval_logdir", "R", "PRs", "use_
 
 def run(config):
     from experiments.test_hashing import RetrievalEvaluation
-    if config.exp in ("general", "hashing"):
-        raise NotImplementedError(f"exp='{config.exp}' (training) is outside the MI355X encode-and-retrieve path; "
-                                  "train with the reference, evaluate here (exp=validation)")
+    if config.exp == "general":
+        raise NotImplementedError("exp='general' (train without evaluation, reference experiments/train_no_eval.py) is not built; "
+                                  "use exp=hashing with eval_interval=0")
+    if config.exp == "hashing":                  # reference main_v2.py:17-19
+        from experiments.train_helper import RetrievalExperiment
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise NotImplementedError("exp=hashing is single-process (the reference trains on one GPU); launch one process")
+        return RetrievalExperiment(config).main()
     if config.exp == "validation":
         load_config = cfglib.load(os.path.join(config.logdir, "config.yaml"))
         for k in EVAL_KEYS:                      # reference main_v2.py:23-40

@@ -63,7 +63,7 @@ def test_state_dict_keys_equal_the_reference_models():
     with pytest.raises(RuntimeError):                        # CPU tensor: no silent fallback
         model(torch.zeros(1, 3, 64, 64))
     model.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                        # training mode as well: the HIP trainer or nothing
         model(torch.zeros(1, 3, 64, 64))
 
 
@@ -95,7 +95,7 @@ def test_instantiate_and_torchvision_mapping():
     from trainers.coop import COOPTrainer
     tr = cfglib.instantiate(cfglib._wrap({"_target_": "trainers.coop.COOPTrainer"}), cfglib.DictConfig(device="cpu"))
     assert isinstance(tr, COOPTrainer)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):                      # nothing loaded yet (reference trainers/base.py:346)
         tr.train_one_epoch()
 
 
@@ -143,12 +143,53 @@ def test_loss_meters_match_a_direct_formula():
     crit = LGHLoss(scale=8, margin=0.2, loss_scales={"bin_logits": 1, "cont_logits": 1, "concept_logits": 1}, ncontext=4)
     total = crit(out, y)
     oh = torch.nn.functional.one_hot(y, 5).float()
-    ce = lambda l: torch.nn.functional.cross_entropy(8 * (l - 0.2 * oh), y)
-    concept = torch.stack([ce(out["logits_concept"][q]) for q in range(4)]).mean()
+    ce = lambda l, m=0.2: torch.nn.functional.cross_entropy(8 * (l - m * oh), y)
+    # (Q, B, C) logits with index labels: the reference's scatter gives the margin to concept 0 only (models/loss/coop.py:55-57)
+    concept = torch.stack([ce(out["logits_concept"][q], 0.2 if q == 0 else 0.0) for q in range(4)]).mean()
     assert torch.allclose(total, ce(out["logits_cont"]) + ce(out["logits_bin"]) + concept, atol=1e-6)
     assert set(crit.losses) == {"quan", "concept", "cont", "bin"}
     with pytest.raises(NotImplementedError):
         LGHLoss(loss_scales={"attn_div_loss": 1})
+
+
+def test_loss_equals_the_reference_loss_on_its_own_outputs():
+    """tests/golden/train_tiny.npz: the reference's LGHLoss (shipped settings) evaluated by the reference on its own model's
+    train-mode outputs; the product criterion on the same logits must give the same three terms -- and is differentiable."""
+    from models.loss.coop import LGHLoss
+    _, z = load_fixture("train_tiny")
+    out = {k: torch.from_numpy(z["out/" + k]).clone().requires_grad_(k != "codes")
+           for k in ("codes", "logits_cont", "logits_bin", "logits_concept")}
+    crit = LGHLoss(margin=0.2, scale=8, loss_scales=dict(logits=0, hash_logits=0, bin_logits=1, cont_logits=1, l2=0, attn_div_loss=0,
+                                                         concept_logits=1), avg_before_softmax=False, lmbd=0.5, div_method=1, ncontext=4)
+    total = crit(out, torch.from_numpy(z["in/labels"]))
+    assert abs(float(total.detach()) - float(z["out/loss"])) < 1e-5
+    for k in ("concept", "cont", "bin", "quan"):
+        assert abs(float(crit.losses[k]) - float(z["out/loss_" + k])) < 1e-5, k
+    total.backward()
+    assert all(out[k].grad is not None and float(out[k].grad.abs().sum()) > 0 for k in ("logits_cont", "logits_bin", "logits_concept"))
+
+
+def test_schedulers_and_training_config_compose(tmp_path):
+    from utils.lr_scheduler import cosine_decay_linear_warmup, no_decay
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.SGD(p, lr=1.0)
+    sch = cosine_decay_linear_warmup(opt, epochs=20, warmup_epochs=4)
+    lrs = []
+    for _ in range(20):
+        lrs.append(sch.get_last_lr()[0])
+        opt.step()
+        sch.step()
+    assert lrs[:4] == [0.25, 0.5, 0.75, 1.0] and abs(lrs[4] - 1.0) < 1e-12 and abs(lrs[12] - 0.5) < 1e-12 and lrs[-1] < 0.02
+    assert all(a >= b for a, b in zip(lrs[4:], lrs[5:]))
+    assert no_decay(torch.optim.SGD(p, lr=0.3)).get_last_lr() == [0.3]
+    cfg = cfglib.compose(CONFIGS, "train.yaml", ["dataset=synthetic_cub200", "optim=sgd", "model.nbit=64", "epochs=3", "eval_interval=0",
+                                                 "scheduler=no_decay"], cwd=str(tmp_path))
+    assert cfg.exp == "hashing" and cfg.optim["_target_"] == "torch.optim.sgd.SGD" and cfg.optim.momentum == 0.9
+    assert cfg.optim.lr == 0.001                                  # the model config overrides optim.lr (reference ...apt.yaml:76-77)
+    assert cfg.backbone_lr_scale == 0 and cfg.batch_size == 32 and cfg.dataset.train_dataset["_target_"].endswith("SyntheticHashingDataset")
+    assert cfg.scheduler["_target_"] == "utils.lr_scheduler.no_decay"
+    opt = cfglib.instantiate(cfg.optim, [{"params": p}])
+    assert isinstance(opt, torch.optim.SGD) and opt.defaults["weight_decay"] == 0.0005
 
 
 def test_utils_hashing_rejects_unbuilt_options_before_touching_the_gpu():

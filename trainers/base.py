@@ -1,10 +1,11 @@
-"""`trainers.base.BaseTrainer` -- the trainer protocol the evaluator drives (reference trainers/base.py:17-71,128-131,
-195-197,275-307), inference side only.
+"""`trainers.base.BaseTrainer` -- the trainer protocol the evaluator and the training loop drive (reference
+trainers/base.py:17-71,128-175,195-210,275-307,340-358).
 
 Kept: method names, argument meaning, return shapes -- `inference_one_epoch(datakey, return_codes=True) ->
 (meters, {'codes': FloatTensor[N, nbit] on CPU, 'labels': Tensor[N, C]})`.
 Changed on purpose: per-batch outputs stay on the GPU and are copied to the host once per epoch (the reference does a
-synchronising `.cpu()` per batch, trainers/base.py:291-296).  Training entry points raise: out of scope.
+synchronising `.cpu()` per batch, trainers/base.py:291-296).  Training: the adapters + get_training_modules() with the backbone frozen
+(`backbone_lr_scale: 0`, the shipped ConceptHash config); a trainable backbone is not built.
 """
 from __future__ import annotations
 
@@ -127,8 +128,54 @@ class BaseTrainer:
                 meters[k].avg = meters[k].sum / max(meters[k].count, 1)
         return meters, res
 
-    # ---- training: out of scope ----------------------------------------------------------------------------------
-    def train_one_epoch(self, *a, **k):
-        raise NotImplementedError("training is outside the MI355X encode-and-retrieve path (DESIGN.md section 8)")
+    # ---- training (reference :133-175, :340-358) --------------------------------------------------------------------------
+    def load_optimizer_and_scheduler(self):
+        assert self.model is not None
+        if self.config.get("backbone_lr_scale", 0) != 0:
+            raise NotImplementedError("backbone_lr_scale != 0 (a trainable backbone) is not built on the MI355X path: the shipped "
+                                      "ConceptHash config freezes it (configs/model/concept_hash_final_v1_nosa_apt.yaml)")
+        groups = []
+        if self.config.model.get("has_adapter", False):
+            groups.append({"params": list(self.model.get_adapter().parameters())})
+        groups.append({"params": [p for p in self.model.get_training_modules().parameters() if p is not None]})
+        self.model.requires_grad_(False)          # only what the optimizer holds is trainable (reference :147-152)
+        count = 0
+        for g in groups:
+            for p in g["params"]:
+                p.requires_grad_(True)
+                count += p.numel()
+        logging.info("Number of trainable params: %.3f%s", count / (1e6 if count >= 1e6 else 1e3), "M" if count >= 1e6 else "K")
+        self.optimizer = instantiate(self.config.optim, groups)
+        self.scheduler = instantiate(self.config.scheduler, self.optimizer)
 
-    load_optimizer_and_scheduler = train_one_batch = train_one_epoch
+    def get_learning_rate(self):
+        return [0.0] if self.scheduler is None else self.scheduler.get_last_lr()
+
+    def is_ready_for_training(self):
+        return all(x is not None for x in (self.dataset, self.dataloader, self.model, self.optimizer, self.scheduler, self.criterion))
+
+    def save_training_state(self, fn):
+        os.makedirs(os.path.dirname(fn) or ".", exist_ok=True)
+        torch.save({"optim": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict()}, fn)
+
+    def load_training_state(self, fn):
+        sd = torch.load(fn, map_location="cpu")
+        self.optimizer.load_state_dict(sd["optim"])
+        self.scheduler.load_state_dict(sd["scheduler"])
+
+    def train_one_batch(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def train_one_epoch(self, **kwargs):
+        assert self.is_ready_for_training()
+        self.model.train()
+        self.criterion.train()
+        meters = defaultdict(AverageMeter)
+        loader = self.dataloader["train"]
+        n = len(loader) if hasattr(loader, "__len__") else 0
+        for i, data in enumerate(loader):
+            self.train_one_batch(data, meters, bidx=i, **kwargs)
+            if n and (i + 1) % max(1, n // 5) == 0:
+                logging.info("train: batch %d/%d %s", i + 1, n, {k: round(v.avg, 4) for k, v in meters.items()})
+        self.scheduler.step()
+        return meters

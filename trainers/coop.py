@@ -37,7 +37,8 @@ class COOPTrainer(BaseTrainer):
                 b = shard_bounds(len(ds), self.world_size)
                 sampler = engine.get_sequential_sampler(list(range(b[self.rank], b[self.rank + 1])))
             self.dataloader[k] = engine.dataloader(ds, bs, shuffle=False, drop_last=False, sampler=sampler)
-        self.dataloader["train"] = []
+        train = self.dataset.get("train") or []
+        self.dataloader["train"] = engine.dataloader(train, bs, shuffle=True, drop_last=True) if len(train) else []
 
     def parse_model_output(self, output):
         codes, logits = output
@@ -64,6 +65,30 @@ class COOPTrainer(BaseTrainer):
         output = self.model(image, labels) if self.config.model.get("pass_labels") else self.model(image)
         return (image, labels, index), self.parse_model_output(output)
 
+    def _update_accuracy_meters(self, output, labels, meters, n):
+        for key, val in output.items():      # accuracy per logits tensor, named as the reference names them (:90-101, :140-150)
+            if "logits" in key and torch.is_tensor(val):
+                val = val.detach()
+                pred = val.mean(dim=0).argmax(1) if val.dim() == 3 else val.argmax(1)
+                parts = key.split("_")
+                meters["acc" if len(parts) == 1 else f"acc_{parts[1]}"].update((pred == labels.argmax(1)).float().mean().item(), n)
+
+    def train_one_batch(self, *args, **kwargs):
+        """reference trainers/coop.py:107-154: zero_grad -> forward -> criterion -> backward -> step -> meters.  The encoder's forward
+        and backward (adapter gradients included) run in the HIP library; the head and the loss on torch autograd."""
+        data, meters = args
+        self.optimizer.zero_grad()
+        (image, labels, index), output = self.compute_features_one_batch(data)
+        target = labels if self.config.dataset.get("multiclass") else labels.argmax(1)
+        loss = self.criterion(output, target)
+        loss.backward()
+        self.optimizer.step()
+        n = image.size(0)
+        meters["loss"].update(loss.item(), n)
+        for key, val in self.criterion.losses.items():
+            meters[key].update(val.item(), n)
+        self._update_accuracy_meters(output, labels, meters, n)
+
     def inference_one_batch(self, *args, **kwargs):
         data, meters = args
         with torch.no_grad():
@@ -74,10 +99,5 @@ class COOPTrainer(BaseTrainer):
             meters["loss"].update(loss.item(), n)
             for key, val in self.criterion.losses.items():
                 meters[key].update(val.item(), n)
-            for key, val in output.items():      # accuracy per logits tensor, named as the reference names them (:90-101)
-                if "logits" in key and torch.is_tensor(val):
-                    pred = val.mean(dim=0).argmax(1) if val.dim() == 3 else val.argmax(1)
-                    parts = key.split("_")
-                    meters["acc" if len(parts) == 1 else f"acc_{parts[1]}"].update(
-                        (pred == labels.argmax(1)).float().mean().item(), n)
+            self._update_accuracy_meters(output, labels, meters, n)
         return {"codes": output["codes"], "labels": labels}

@@ -76,3 +76,46 @@ class Compose:
         for t in self.transforms:
             x = t(x)
         return x
+
+
+class RandomResizedCrop:
+    """torchvision.transforms.RandomResizedCrop as the reference's train_dataset uses it (configs/dataset/cub200.yaml:13-19):
+    area fraction U(0.08, 1), log-uniform aspect ratio in (3/4, 4/3), ten tries, then the centre-crop fallback."""
+
+    def __init__(self, size, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), interpolation=Image.BILINEAR):
+        self.size = (size, size) if isinstance(size, int) else tuple(size)
+        self.scale, self.ratio, self.interp = tuple(scale), tuple(ratio), interpolation
+
+    def get_params(self, w, h):
+        import math
+        area = w * h
+        log_ratio = (math.log(self.ratio[0]), math.log(self.ratio[1]))
+        for _ in range(10):
+            target = area * float(torch.empty(1).uniform_(self.scale[0], self.scale[1]))
+            ar = math.exp(float(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])))
+            cw, ch = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
+            if 0 < cw <= w and 0 < ch <= h:
+                top = int(torch.randint(0, h - ch + 1, (1,)))
+                left = int(torch.randint(0, w - cw + 1, (1,)))
+                return top, left, ch, cw
+        in_ratio = w / h
+        if in_ratio < self.ratio[0]:
+            cw, ch = w, int(round(w / self.ratio[0]))
+        elif in_ratio > self.ratio[1]:
+            ch, cw = h, int(round(h * self.ratio[1]))
+        else:
+            cw, ch = w, h
+        return (h - ch) // 2, (w - cw) // 2, ch, cw
+
+    def __call__(self, img):
+        w, h = img.size
+        top, left, ch, cw = self.get_params(w, h)
+        return img.crop((left, top, left + cw, top + ch)).resize((self.size[1], self.size[0]), self.interp)
+
+
+class RandomHorizontalFlip:
+    def __init__(self, p=0.5):
+        self.p = p
+
+    def __call__(self, img):
+        return img.transpose(Image.FLIP_LEFT_RIGHT) if float(torch.rand(1)) < self.p else img
