@@ -212,7 +212,7 @@ int ch_transpose_bf16(const bf16_t *src, int R, int C, int ld_src, bf16_t *dst, 
 // gradients of one adapter's parameters from G = dH^T g [D, bpad], cu = colsum(dH), T = dpre^T x_hat [bpad, D], cd = colsum(dpre);
 // params / grads: one adapter's block of the arena ([ln_w D][ln_b D][down_w b*D][down_b b][up_w D*b][up_b D][scale 1])
 int ch_adapter_grads(const float *G, const float *cu, const float *T, const float *cd, const float *params, int D, int b, int bpad,
-                     float *grads, hipStream_t s);
+                     float *grads, float *ws /* >= 256 floats */, hipStream_t s);
 int ch_concept_rows_sum(const float *dH, int B, int ntok, int Q, int D, float *out, hipStream_t s);
 int ch_scatter_concept_rows(const float *dhf, int B, int ntok, int Q, int D, float *dH, bf16_t *dHb, hipStream_t s);
 int ch_small_ln_bwd(const float *dy, const float *x, const float *gamma, int rows, int D, float eps, float *dx, hipStream_t s);

@@ -345,7 +345,7 @@ extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, fl
         if (int e = ch_normalize_bf16(in, stin, rows, D, 1e-5f, t->tD2, s)) return e;
         if (int e = ch_wgrad_tn(t->tB, bpad, t->tD2, D, rows, t->rows_alloc, bpad, D, t->T, t->ws_wgrad, s)) return e;
         if (int e = ch_colsum(t->tB, 0, bpad, rows, bpad, t->cd, t->ws_colsum, s)) return e;
-        if (int e = ch_adapter_grads(t->G, t->cu, t->T, t->cd, pbase, D, b, bpad, t->grads + (int64_t)(l * 2 + a) * t->ad_numel, s)) return e;
+        if (int e = ch_adapter_grads(t->G, t->cu, t->T, t->cd, pbase, D, b, bpad, t->grads + (int64_t)(l * 2 + a) * t->ad_numel, t->ws_colsum, s)) return e;
         g = GemmCall{D, bpad, t->tB, aw.down_wgT, zero, EPI_BIAS};
         g.out = t->tD; g.ldo = D;
         if (int e = gemm(t, rows, g, s)) return e;

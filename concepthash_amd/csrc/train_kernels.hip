@@ -366,49 +366,73 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T *__restrict__ sr
 // down:  dW_dn = T * gamma + cd (x) beta, db_dn = cd
 // LN:    dgamma[k] = sum_j T[j][k] W_dn[j][k], dbeta[k] = sum_j cd[j] W_dn[j][k]
 // Parameter / gradient arena layout of one adapter (fp32): [ln_w D][ln_b D][down_w b*D][down_b b][up_w D*b][up_b D][scale 1]
-__global__ __launch_bounds__(256) void adapter_grads_kernel(const float *__restrict__ G, const float *__restrict__ cu,
-                                                            const float *__restrict__ T, const float *__restrict__ cd,
-                                                            const float *__restrict__ P, int D, int b, int bpad, float *__restrict__ gr) {
+// kernel 1 (grid of AG_BLOCKS blocks): the elementwise parts + this block's partial of <G, W_up> into part[blockIdx.x]
+constexpr int AG_BLOCKS = 256;
+__global__ __launch_bounds__(256) void adapter_grads_elem_kernel(const float *__restrict__ G, const float *__restrict__ cu,
+                                                                 const float *__restrict__ T, const float *__restrict__ cd,
+                                                                 const float *__restrict__ P, int D, int b, int bpad, float *__restrict__ gr,
+                                                                 float *__restrict__ part) {
     const float *ln_w = P, *ln_b = P + D, *down_w = P + 2 * D, *up_w = down_w + (size_t)b * D + b, *up_b = up_w + (size_t)D * b;
     const float s = up_b[D];
-    float *g_ln_w = gr, *g_ln_b = gr + D, *g_down_w = gr + 2 * D, *g_down_b = g_down_w + (size_t)b * D, *g_up_w = g_down_b + b,
-          *g_up_b = g_up_w + (size_t)D * b, *g_s = g_up_b + D;
+    float *g_down_w = gr + 2 * D, *g_down_b = g_down_w + (size_t)b * D, *g_up_w = g_down_b + b, *g_up_b = g_up_w + (size_t)D * b;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     for (int i = tid; i < b * D; i += nth) {
         const int j = i / D, k = i - j * D;
         g_down_w[i] = T[(size_t)j * D + k] * ln_w[k] + cd[j] * ln_b[k];
     }
     for (int i = tid; i < b; i += nth) g_down_b[i] = cd[i];
+    float a = 0.f;
     for (int i = tid; i < D * b; i += nth) {
         const int n = i / b, j = i - n * b;
-        g_up_w[i] = s * G[(size_t)n * bpad + j];
+        const float g = G[(size_t)n * bpad + j];
+        g_up_w[i] = s * g;
+        a += g * up_w[i];
     }
     for (int i = tid; i < D; i += nth) {
         g_up_b[i] = s * cu[i];
-        float a = 0.f, c = 0.f;
-        for (int j = 0; j < b; ++j) {
-            const float w = down_w[(size_t)j * D + i];
-            a += T[(size_t)j * D + i] * w;
-            c += cd[j] * w;
-        }
-        g_ln_w[i] = a;
-        g_ln_b[i] = c;
+        a += cu[i] * up_b[i];
     }
-    if (blockIdx.x == 0) {  // ds: one block, fp32 tree over D*b + D products (order fixed by the thread mapping: deterministic)
+    __shared__ float red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+// kernel 2: block 0 sums the AG_BLOCKS partials in a fixed order -> d(scale); blocks 1.. : 64 columns k each, 4 row lanes over j:
+// dgamma[k] = sum_j T[j][k] W_dn[j][k], dbeta[k] = sum_j cd[j] W_dn[j][k]
+__global__ __launch_bounds__(256) void adapter_grads_red_kernel(const float *__restrict__ T, const float *__restrict__ cd,
+                                                                const float *__restrict__ P, int D, int b, float *__restrict__ gr,
+                                                                const float *__restrict__ part) {
+    __shared__ float ra[4][64], rc[4][64];
+    if (blockIdx.x == 0) {
         __shared__ float red[256];
-        float a = 0.f;
-        for (int i = threadIdx.x; i < D * b; i += 256) {
-            const int n = i / b, j = i - n * b;
-            a += G[(size_t)n * bpad + j] * up_w[i];
-        }
-        for (int i = threadIdx.x; i < D; i += 256) a += cu[i] * up_b[i];
-        red[threadIdx.x] = a;
+        red[threadIdx.x] = threadIdx.x < AG_BLOCKS ? part[threadIdx.x] : 0.f;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) *g_s = red[0];
+        if (threadIdx.x == 0) gr[2 * D + (size_t)b * D + b + (size_t)D * b + D] = red[0];
+        return;
+    }
+    const float *down_w = P + 2 * D;
+    const int k = (blockIdx.x - 1) * 64 + (threadIdx.x & 63), jl = threadIdx.x >> 6;
+    float a = 0.f, c = 0.f;
+    if (k < D)
+        for (int j = jl; j < b; j += 4) {
+            const float w = down_w[(size_t)j * D + k];
+            a += T[(size_t)j * D + k] * w;
+            c += cd[j] * w;
+        }
+    ra[jl][threadIdx.x & 63] = a;
+    rc[jl][threadIdx.x & 63] = c;
+    __syncthreads();
+    if (jl == 0 && k < D) {
+        gr[k] = ra[0][threadIdx.x] + ra[1][threadIdx.x] + ra[2][threadIdx.x] + ra[3][threadIdx.x];
+        gr[D + k] = rc[0][threadIdx.x] + rc[1][threadIdx.x] + rc[2][threadIdx.x] + rc[3][threadIdx.x];
     }
 }
 
@@ -580,8 +604,10 @@ int ch_transpose_bf16(const bf16_t *src, int R, int C, int ld_src, bf16_t *dst, 
     return 0;
 }
 int ch_adapter_grads(const float *G, const float *cu, const float *T, const float *cd, const float *params, int D, int b, int bpad,
-                     float *grads, hipStream_t s) {
-    hipLaunchKernelGGL(adapter_grads_kernel, dim3(256), dim3(256), 0, s, G, cu, T, cd, params, D, b, bpad, grads);
+                     float *grads, float *ws, hipStream_t s) {
+    hipLaunchKernelGGL(adapter_grads_elem_kernel, dim3(AG_BLOCKS), dim3(256), 0, s, G, cu, T, cd, params, D, b, bpad, grads, ws);
+    CH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adapter_grads_red_kernel, dim3(1 + (D + 63) / 64), dim3(256), 0, s, T, cd, params, D, b, grads, ws);
     CH_LAUNCH_CHECK();
     return 0;
 }

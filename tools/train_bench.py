@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Training-step benchmark of the ConceptHash adapters on one MI355X: encoder forward with saved
+activations + backward in the HIP library, timed with HIP events around `ch_train_forward` / `ch_train_backward`, plus the whole
+step through the drop-in surface (model.train() forward, LGHLoss, backward, SGD step).
+
+    python tools/train_bench.py [--config vit_b16] [--batches 32,64,128,256] [--steps 10]
+Prints one JSON line per batch size.  FLOPs: forward 2 * params-touched * tokens; the backward's dgrad products equal the
+forward's, the adapters' weight-gradient products add 4 N D b per layer per adapter pair, attention backward 2.5x its forward.
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from concepthash_amd import synthetic
+from concepthash_amd.training import TrainEngine
+
+
+class _Holder(torch.nn.Module):
+    """adapter modules with the parameter names the arena expects, initialised from a synthetic state_dict"""
+
+    def __init__(self, sd, prefix, D, b):
+        super().__init__()
+        from models.layers.adapter import Adapter
+        self.m = Adapter(D, b)
+        self.m.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)})
+
+
+def flops_per_image(cfg, Q=4):
+    D, L, M, b = cfg["D"], cfg["L"], cfg["M"], cfg["b"]
+    N = 1 + (cfg["image"] // cfg["patch"]) ** 2 + Q
+    lin = 2.0 * N * (4 * D * D + 2 * D * M + 4 * D * b)          # qkv + out + fc1 + fc2 + two adapters, per layer
+    attn = 4.0 * N * N * D
+    fwd = L * (lin + attn)
+    bwd = L * (lin + 2.5 * attn + 2.0 * N * 4 * D * b)            # dgrad = forward's linears; wgrad only for the adapters
+    return fwd, bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="vit_b16")
+    ap.add_argument("--batches", default="32,64,128,256")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    cfg = synthetic.CONFIGS[a.config]
+    sd = synthetic.synthetic_state_dict(cfg, nbit=64, nclass=200)
+    VM = "backbone.vision_model."
+    adapters = [(_Holder(sd, VM + f"encoder.layers.{l}.adapt_mlp_1.", cfg["D"], cfg["b"]).m,
+                 _Holder(sd, VM + f"encoder.layers.{l}.adapt_mlp_2.", cfg["D"], cfg["b"]).m) for l in range(cfg["L"])]
+    batches = [int(x) for x in a.batches.split(",")]
+    eng = TrainEngine(sd, adapters, heads=cfg["heads"], max_batch=max(batches), device=torch.device("cuda", torch.cuda.current_device()))
+    fwd_f, bwd_f = flops_per_image(cfg)
+    Q, D = 4, cfg["D"]
+    ctx = torch.randn(Q, D, device="cuda") * 0.02
+    for B in batches:
+        x = synthetic.synthetic_images(B, cfg["image"]).to("cuda", torch.bfloat16)
+        dhf = torch.randn(B, Q, D, device="cuda") * 0.01
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tf = tb = 0.0
+        for it in range(a.warmup + a.steps):
+            ev[0].record()
+            eng.forward(x, ctx)
+            ev[1].record()
+            eng.backward(dhf)
+            ev[2].record()
+            torch.cuda.synchronize()
+            if it >= a.warmup:
+                tf += ev[0].elapsed_time(ev[1])
+                tb += ev[1].elapsed_time(ev[2])
+        tf /= a.steps
+        tb /= a.steps
+        print(json.dumps({"config": a.config, "batch": B, "forward_ms": round(tf, 3), "backward_ms": round(tb, 3),
+                          "step_ms": round(tf + tb, 3), "images_per_s": round(B / (tf + tb) * 1e3, 1),
+                          "forward_tflops": round(fwd_f * B / tf / 1e9, 1), "backward_tflops": round(bwd_f * B / tb / 1e9, 1),
+                          "trainer_gib": round(eng.device_bytes / 2 ** 30, 2)}))
+
+
+if __name__ == "__main__":
+    main()
