@@ -58,6 +58,7 @@ def parse_args():
                     help="micro-batch launch chains on separate HIP streams (library default 2; 1 = a single chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming-scan", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step block (SURVEY.md section 8 row f4)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the single-stream profiled pass")
     return ap.parse_args()
 
@@ -236,6 +237,10 @@ def main():
     if rank == 0:
         result["decode_inclusive"] = decode_block(torch, enc, B, dev)
 
+    # ---- training step of the adapters (outside the timed region) -------------------------------
+    if rank == 0 and not args.no_train_step:
+        result["train_step"] = train_block(torch, syn, sd, cfg, B, dev)
+
     # ---- Hamming blocks (outside the timed region) -------------------------------------------------------------------
     if not args.no_hamming_scan:
         hb = hamming_block(torch, np, rt, syn, dist, dev, rank, world)
@@ -389,6 +394,31 @@ def decode_block(torch, enc, B, dev):
             "preprocess_gbs": round((B * h * w * 3 + B * 3 * 224 * 224 * 2) / s_pre / 1e9, 1),
             "note": f"{B} decoded {w}x{h} uint8 RGB images resident in HBM -> ch_preprocess (bit-equal to the PIL chain) -> "
                     f"ch_encode; host-side descriptor planning included; never used for `value`"}
+
+
+def train_block(torch, syn, sd, cfg, B, dev):
+    """Encoder forward (activations saved) + backward of the training step, HIP library only (ch_train_forward /
+    ch_train_backward): the reference's own batch size (32, configs/model/concept_hash_final_v1_nosa_apt.yaml:76) and the bench
+    batch.  The head / loss / optimizer around it are a few hundred microseconds of small launches and are not in these times."""
+    from concepthash_amd.training import TrainEngine, adapters_from_state_dict, encoder_step_flops
+    eng = TrainEngine(sd, adapters_from_state_dict(sd, cfg["L"], cfg["D"], cfg["b"]), heads=cfg["heads"], max_batch=B, device=dev)
+    fwd_f, bwd_f = encoder_step_flops(eng.cfg)
+    ctx = torch.randn(4, cfg["D"], device=dev) * 0.02
+    out = {}
+    for b in sorted({min(32, B), B}):
+        x = syn.synthetic_images(b, cfg["image"]).to(dev, torch.bfloat16)
+        dhf = torch.randn(b, 4, cfg["D"], device=dev) * 0.01
+        s_f, _ = _ev_time(torch, lambda: eng.forward(x, ctx), 5)
+        s_all, _ = _ev_time(torch, lambda: (eng.forward(x, ctx), eng.backward(dhf)), 5)
+        s_b = s_all - s_f
+        out[f"batch_{b}"] = {"images_per_s": round(b / s_all, 1), "ms_per_step": round(s_all * 1e3, 3), "forward_ms": round(s_f * 1e3, 3),
+                             "backward_ms": round(s_b * 1e3, 3), "tflops": round((fwd_f + bwd_f) * b / s_all / 1e12, 1),
+                             "mfma_frac": round((fwd_f + bwd_f) * b / s_all / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    out["trainer_gib"] = round(eng.device_bytes / 2 ** 30, 2)
+    out["note"] = ("adapters + concept tokens trained, backbone frozen; bf16 operands, fp32 accumulation / residual gradient / "
+                   "parameter gradients; never used for `value`")
+    eng.close()
+    return out
 
 
 def _ev_time(torch, fn, reps):

@@ -165,6 +165,10 @@ int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s) {
         case EPI_FOLD_BIAS: return launch<EPI_FOLD_BIAS>(p, s);
         case EPI_FOLD_QUICKGELU: return launch<EPI_FOLD_QUICKGELU>(p, s);
         case EPI_FOLD_GELU: return launch<EPI_FOLD_GELU>(p, s);
+        case EPI_BIAS_DACT_QUICK: return launch<EPI_BIAS_DACT_QUICK>(p, s);
+        case EPI_BIAS_DACT_GELU: return launch<EPI_BIAS_DACT_GELU>(p, s);
+        case EPI_FOLD_ACT2_QUICK: return launch<EPI_FOLD_ACT2_QUICK>(p, s);
+        case EPI_FOLD_ACT2_GELU: return launch<EPI_FOLD_ACT2_GELU>(p, s);
     }
     ch_set_error("gemm: unknown epilogue");
     return 2;
@@ -197,7 +201,9 @@ static std::atomic<int64_t> g_dispatch_count[2];
 static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128 two-phase), 2 force pp (256x256 ping-pong), 3 force dp
 void ch_gemm_set_variant(int v) { g_gemm_variant = v; }
 int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
-    if (epi == EPI_FOLD_BIAS || epi == EPI_FOLD_QUICKGELU || epi == EPI_FOLD_GELU)
+    if (epi == EPI_BIAS_DACT_QUICK || epi == EPI_BIAS_DACT_GELU) CH_REQUIRE(p.aux != nullptr, "gemm: derivative epilogue needs aux (the pre-activation)");
+    if (epi == EPI_FOLD_ACT2_QUICK || epi == EPI_FOLD_ACT2_GELU) CH_REQUIRE(p.hb_out != nullptr, "gemm: two-output epilogue needs hb_out");
+    if (epi == EPI_FOLD_BIAS || epi == EPI_FOLD_QUICKGELU || epi == EPI_FOLD_GELU || epi == EPI_FOLD_ACT2_QUICK || epi == EPI_FOLD_ACT2_GELU)
         CH_REQUIRE(p.stats_in && p.fold_c && p.K % 128 == 0 && p.K <= 1280 && p.ln_eps > 0.f,
                    "gemm: LN-folded epilogue needs stats_in, fold_c, ln_eps and K % 128 == 0, K <= 1280");
     if (epi == EPI_BIAS_STATS || epi == EPI_SCALE_RESID_STATS)

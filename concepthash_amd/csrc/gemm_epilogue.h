@@ -32,12 +32,29 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// derivatives of the two activations (training step): d/dx x*sigmoid(1.702 x) = s (1 + 1.702 x (1 - s));
+// d/dx 0.5 x (1 + erf(x / sqrt 2)) = Phi(x) + x phi(x), erf by the same A&S 7.1.26 polynomial as gelu_erf_f
+__device__ __forceinline__ float dquick_gelu_f(float x) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+}
+__device__ __forceinline__ float dgelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);  // exp(-x^2 / 2)
+    const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+    return cdf + x * 0.3989422804014327f * e;
+}
+
 template <int EPI>
 struct traits {
-    static constexpr bool fold = (EPI == EPI_FOLD_BIAS || EPI == EPI_FOLD_QUICKGELU || EPI == EPI_FOLD_GELU);
+    static constexpr bool dact = (EPI == EPI_BIAS_DACT_QUICK || EPI == EPI_BIAS_DACT_GELU);
+    static constexpr bool act2 = (EPI == EPI_FOLD_ACT2_QUICK || EPI == EPI_FOLD_ACT2_GELU);
+    static constexpr bool fold = (EPI == EPI_FOLD_BIAS || EPI == EPI_FOLD_QUICKGELU || EPI == EPI_FOLD_GELU || act2);
     static constexpr bool quick = (EPI == EPI_BIAS_QUICKGELU || EPI == EPI_FOLD_QUICKGELU);
     static constexpr bool erf = (EPI == EPI_BIAS_GELU || EPI == EPI_FOLD_GELU);
-    static constexpr bool bf16_only = (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS || quick || erf || fold);
+    static constexpr bool bf16_only = (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS || quick || erf || fold || dact);
     static constexpr bool scale_resid = (EPI == EPI_SCALE_RESID || EPI == EPI_SCALE_RESID_STATS);
     static constexpr bool stats = (EPI == EPI_BIAS_STATS || EPI == EPI_SCALE_RESID_STATS);
 };
@@ -187,7 +204,33 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
             uint4 v = *(const uint4 *)(wave_lds + row * 128 + pos * 16);
             if (i & 1) v = make_uint4(v.z, v.w, v.x, v.y);  // rows with bit 3 set (row = 8 i + lrow) hold their 8-byte halves swapped
             const int m = m_base + row;
+            if constexpr (T::dact) {  // training: times the activation's derivative at the saved pre-activation (and the adapter scale)
+                const int mc = m < p.M ? m : p.M - 1;
+                const uint4 a = *(const uint4 *)(p.aux + (size_t)mc * p.ldo + n_base + chunk * 8);
+                const float sc = (EPI == EPI_BIAS_DACT_GELU && p.scale_ptr) ? *p.scale_ptr : 1.0f;
+                const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, aw[4] = {a.x, a.y, a.z, a.w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = bf2f((bf16_t)(aw[j] & 0xffff)), x1 = bf2f((bf16_t)(aw[j] >> 16));
+                    const float d0 = EPI == EPI_BIAS_DACT_QUICK ? dquick_gelu_f(x0) : dgelu_erf_f(x0);
+                    const float d1 = EPI == EPI_BIAS_DACT_QUICK ? dquick_gelu_f(x1) : dgelu_erf_f(x1);
+                    ow[j] = pack_bf16x2(sc * bf2f((bf16_t)(vw[j] & 0xffff)) * d0, sc * bf2f((bf16_t)(vw[j] >> 16)) * d1);
+                }
+                v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            }
             if (m < p.M) *(uint4 *)(p.out_bf16 + (size_t)m * p.ldo + n_base + chunk * 8) = v;
+            if constexpr (T::act2) {  // training: the activation of the (bf16-rounded) pre-activation as a second output
+                const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = bf2f((bf16_t)(vw[j] & 0xffff)), x1 = bf2f((bf16_t)(vw[j] >> 16));
+                    ow[j] = EPI == EPI_FOLD_ACT2_QUICK ? pack_bf16x2(quick_gelu_f(x0), quick_gelu_f(x1))
+                                                       : pack_bf16x2(gelu_erf_f(x0), gelu_erf_f(x1));
+                }
+                if (m < p.M) *(uint4 *)(p.hb_out + (size_t)m * p.ld_hb + n_base + chunk * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            }
             if constexpr (T::stats) {  // partial (sum, sumsq) of this row's 64 rounded outputs: 8 lanes x 8 values
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
                 float sm = 0.f, sq = 0.f;

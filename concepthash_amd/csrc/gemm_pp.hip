@@ -552,6 +552,10 @@ int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s) {
         case EPI_FOLD_BIAS: return launch_pp<EPI_FOLD_BIAS>(p, s);
         case EPI_FOLD_QUICKGELU: return launch_pp<EPI_FOLD_QUICKGELU>(p, s);
         case EPI_FOLD_GELU: return launch_pp<EPI_FOLD_GELU>(p, s);
+        case EPI_BIAS_DACT_QUICK: return launch_pp<EPI_BIAS_DACT_QUICK>(p, s);
+        case EPI_BIAS_DACT_GELU: return launch_pp<EPI_BIAS_DACT_GELU>(p, s);
+        case EPI_FOLD_ACT2_QUICK: return launch_pp<EPI_FOLD_ACT2_QUICK>(p, s);
+        case EPI_FOLD_ACT2_GELU: return launch_pp<EPI_FOLD_ACT2_GELU>(p, s);
     }
     ch_set_error("gemm: unknown epilogue");
     return 2;

@@ -19,7 +19,12 @@ enum GemmEpilogue {
     EPI_FOLD_BIAS = 8,          // out_bf16 = LN-folded linear (bias = d, fold_c = c, stats_in)
     EPI_FOLD_QUICKGELU = 9,     // ... then quick_gelu
     EPI_FOLD_GELU = 10,         // ... then gelu_erf
-    EPI_COUNT = 11,
+    // ---- training step (train.hip): activations applied / differentiated on a bf16 PRE-activation tensor in the epilogue
+    EPI_BIAS_DACT_QUICK = 11,   // out_bf16 = bf16(acc + bias) * quick_gelu'(aux)                     (fc2 input-gradient GEMM)
+    EPI_BIAS_DACT_GELU = 12,    // out_bf16 = *scale_ptr * bf16(acc + bias) * gelu_erf'(aux)          (adapter up-projection dgrad)
+    EPI_FOLD_ACT2_QUICK = 13,   // out_bf16 = pre = LN-folded linear; hb_out = quick_gelu(pre)        (fc1 forward, pre kept for backward)
+    EPI_FOLD_ACT2_GELU = 14,    // ... hb_out = gelu_erf(pre)                                          (adapter down-projection forward)
+    EPI_COUNT = 15,
 };
 
 struct GemmParams {
@@ -46,6 +51,7 @@ struct GemmParams {
     const float *stats_in;   // [rows, K/64, 2] partials of this GEMM's input rows (written by the producer)
     const float *fold_c;     // [N]
     float ln_eps;
+    const bf16_t *aux;       // EPI_BIAS_DACT_*: saved pre-activation [M, ldo] (same layout as out_bf16)
     // split-K tail of the 256x256 kernel (gemm_pp.hip): fp32 slabs [<= 256 units][256*256] + one counter per split tile;
     // nullptr = every tile is computed by one workgroup.  split_full / split_s are set by the launcher.
     float *splitk_ws;

@@ -12,7 +12,8 @@
 // Forward = the LN-fold chain of model.hip, one chain, with every layer's operands kept: bf16(H) + row statistics (the
 // LayerNorm inputs), qkv, attention output, a / m (sub-block outputs) + statistics, adapter pre-activations and activations,
 // fc1 pre-activation.  Pre-activations are saved instead of activations, so the activations are applied by a separate
-// elementwise launch in training (act_fwd) rather than in the GEMM epilogue.
+// epilogue mode in training: the GEMM writes the pre-activation AND its activation (EPI_FOLD_ACT2_*); backward multiplies by the
+// activation's derivative in the dgrad GEMM's epilogue (EPI_BIAS_DACT_*).
 // Backward per layer, dH = gradient of the residual stream (fp32, bf16 copy dHb as the GEMM operand):
 //   adapter:  G = dHb^T g, cu = colsum(dH)                                [weight-gradient products, up]
 //             dpre = s (dHb W_up) o gelu'(pre)                            [dgrad GEMM + act_bwd]
@@ -111,6 +112,8 @@ struct GemmCall {
     float eps = 0.f;
     float *stats_out = nullptr;
     bf16_t *hb_out = nullptr;
+    int ld_hb = 0;              // 0 = D
+    const bf16_t *aux = nullptr;
 };
 int gemm(ch_trainer *t, int rows, const GemmCall &g, hipStream_t s) {
     const int D = t->m->cfg.dim;
@@ -118,7 +121,7 @@ int gemm(ch_trainer *t, int rows, const GemmCall &g, hipStream_t s) {
     p.X = g.X; p.W = g.W; p.M = rows; p.N = g.N; p.K = g.K; p.X_rows_alloc = t->rows_alloc;
     p.bias = g.bias; p.out_bf16 = g.out; p.ldo = g.ldo; p.resid = g.resid; p.ldr = D; p.scale_ptr = g.scale; p.addend = g.addend;
     p.ld_addend = D; p.stats_in = g.stats_in; p.fold_c = g.fold_c; p.ln_eps = g.eps; p.stats_out = g.stats_out; p.hb_out = g.hb_out;
-    p.ld_hb = D; p.pp_min_k = t->m->pp_min_k;
+    p.ld_hb = g.ld_hb ? g.ld_hb : D; p.aux = g.aux; p.pp_min_k = t->m->pp_min_k;
     return ch_gemm_bf16(p, g.epi, s);
 }
 
@@ -281,10 +284,10 @@ extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image
             const bf16_t *in = a == 0 ? v.A : v.A2;
             const float *stin = a == 0 ? v.stA : v.stA2;
             bf16_t *P = a == 0 ? v.P1 : v.P2, *G = a == 0 ? v.G1 : v.G2;
-            g = GemmCall{bpad, D, in, aw.down_wf, aw.fold_d, EPI_FOLD_BIAS};
-            g.out = P; g.ldo = bpad; g.stats_in = stin; g.fold_c = aw.fold_c; g.eps = 1e-5f;
+            // pre-activation kept for backward, nn.GELU() (models/layers/adapter.py:36) of it as the second output
+            g = GemmCall{bpad, D, in, aw.down_wf, aw.fold_d, EPI_FOLD_ACT2_GELU};
+            g.out = P; g.ldo = bpad; g.stats_in = stin; g.fold_c = aw.fold_c; g.eps = 1e-5f; g.hb_out = G; g.ld_hb = bpad;
             if (int e = gemm(t, rows, g, s)) return e;
-            if (int e = ch_act_fwd(P, (int64_t)rows * bpad, 1, G, s)) return e;   // nn.GELU() (models/layers/adapter.py:36)
             g = GemmCall{D, bpad, G, aw.up_w, ap.up_b, EPI_SCALE_RESID_STATS};
             g.resid = t->H; g.scale = ap.scale; g.addend = in;
             if (a == 0) {
@@ -295,10 +298,9 @@ extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image
             }
             if (int e = gemm(t, rows, g, s)) return e;
             if (a == 0) {  // MLP
-                g = GemmCall{M, D, v.Xn2, w.fc1_wf, w.fc1_d, EPI_FOLD_BIAS};
-                g.out = v.F1pre; g.ldo = M; g.stats_in = v.st2; g.fold_c = w.fc1_c; g.eps = c.ln_eps;
+                g = GemmCall{M, D, v.Xn2, w.fc1_wf, w.fc1_d, c.act == 0 ? EPI_FOLD_ACT2_QUICK : EPI_FOLD_ACT2_GELU};
+                g.out = v.F1pre; g.ldo = M; g.stats_in = v.st2; g.fold_c = w.fc1_c; g.eps = c.ln_eps; g.hb_out = t->F1act; g.ld_hb = M;
                 if (int e = gemm(t, rows, g, s)) return e;
-                if (int e = ch_act_fwd(v.F1pre, (int64_t)rows * M, c.act, t->F1act, s)) return e;
                 g = GemmCall{D, M, t->F1act, w.fc2_w, w.fc2_b, EPI_BIAS_STATS};
                 g.out = v.A2; g.ldo = D; g.stats_out = v.stA2;
                 if (int e = gemm(t, rows, g, s)) return e;
@@ -336,11 +338,10 @@ extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, fl
         const float *stin = a == 0 ? v.stA : v.stA2;
         // up projection: weight-gradient products (unscaled) and dgrad
         if (int e = ch_wgrad_tn(t->dHb, D, G, bpad, rows, t->rows_alloc, D, bpad, t->G, t->ws_wgrad, s)) return e;
-        if (int e = ch_colsum(t->dH, 1, D, rows, D, t->cu, t->ws_colsum, s)) return e;
-        GemmCall g{bpad, D, t->dHb, aw.up_wT, zero, EPI_BIAS};
-        g.out = t->tB; g.ldo = bpad;
+        if (int e = ch_colsum(t->dHb, 0, D, rows, D, t->cu, t->ws_colsum, s)) return e;   // of the bf16 operand, like G
+        GemmCall g{bpad, D, t->dHb, aw.up_wT, zero, EPI_BIAS_DACT_GELU};   // dpre = s (dH W_up) o gelu'(pre), in the epilogue
+        g.out = t->tB; g.ldo = bpad; g.aux = P; g.scale = ap.scale;
         if (int e = gemm(t, rows, g, s)) return e;
-        if (int e = ch_act_bwd(t->tB, P, (int64_t)rows * bpad, 1, ap.scale, t->tB, s)) return e;   // dpre, in place
         // down projection + adapter LayerNorm
         if (int e = ch_normalize_bf16(in, stin, rows, D, 1e-5f, t->tD2, s)) return e;
         if (int e = ch_wgrad_tn(t->tB, bpad, t->tD2, D, rows, t->rows_alloc, bpad, D, t->T, t->ws_wgrad, s)) return e;
@@ -357,10 +358,9 @@ extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, fl
         const LayerT &x = t->lt[l];
         // ---- x_out = x_mid + m + adapter_2(m),  m = fc2(act(fc1(LN2(x_mid))))
         if (int e = adapter_bwd(l, 1)) return e;
-        GemmCall g{M, D, t->dMb, x.fc2_wT, zero, EPI_BIAS};
-        g.out = t->tM; g.ldo = M;
+        GemmCall g{M, D, t->dMb, x.fc2_wT, zero, c.act == 0 ? EPI_BIAS_DACT_QUICK : EPI_BIAS_DACT_GELU};
+        g.out = t->tM; g.ldo = M; g.aux = v.F1pre;
         if (int e = gemm(t, rows, g, s)) return e;
-        if (int e = ch_act_bwd(t->tM, v.F1pre, (int64_t)rows * M, c.act, nullptr, t->tM, s)) return e;
         g = GemmCall{D, M, t->tM, x.fc1_wgT, zero, EPI_BIAS};
         g.out = t->tD; g.ldo = D;
         if (int e = gemm(t, rows, g, s)) return e;

@@ -70,20 +70,7 @@ __global__ __launch_bounds__(256) void hb_stats_kernel(const float *__restrict__
 
 // ---- activations on saved pre-activations ------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_f(float x, int act) { return act == 0 ? ch_epi::quick_gelu_f(x) : ch_epi::gelu_erf_f(x); }
-__device__ __forceinline__ float dact_f(float x, int act) {
-    if (act == 0) {  // d/dx x*sigmoid(1.702 x) = s * (1 + 1.702 x (1 - s))
-        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
-        return s * (1.0f + 1.702f * x * (1.0f - s));
-    }
-    // d/dx 0.5 x (1 + erf(x / sqrt 2)) = Phi(x) + x phi(x)
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);  // exp(-x^2 / 2)
-    const float erf_abs = 1.0f - poly * e;
-    const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
-    return cdf + x * 0.3989422804014327f * e;
-}
+__device__ __forceinline__ float dact_f(float x, int act) { return act == 0 ? ch_epi::dquick_gelu_f(x) : ch_epi::dgelu_erf_f(x); }
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void act_kernel(const bf16_t *__restrict__ g, const bf16_t *__restrict__ pre, int64_t n8, int act,
@@ -401,15 +388,15 @@ __global__ __launch_bounds__(256) void adapter_grads_elem_kernel(const float *__
     }
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
-// kernel 2: block 0 sums the AG_BLOCKS partials in a fixed order -> d(scale); blocks 1.. : 64 columns k each, 4 row lanes over j:
+// kernel 2: block 0 sums the AG_BLOCKS partials in a fixed order -> d(scale); blocks 1.. : 64 columns k each, 16 row lanes over j:
 // dgamma[k] = sum_j T[j][k] W_dn[j][k], dbeta[k] = sum_j cd[j] W_dn[j][k]
-__global__ __launch_bounds__(256) void adapter_grads_red_kernel(const float *__restrict__ T, const float *__restrict__ cd,
-                                                                const float *__restrict__ P, int D, int b, float *__restrict__ gr,
-                                                                const float *__restrict__ part) {
-    __shared__ float ra[4][64], rc[4][64];
+__global__ __launch_bounds__(1024) void adapter_grads_red_kernel(const float *__restrict__ T, const float *__restrict__ cd,
+                                                                 const float *__restrict__ P, int D, int b, float *__restrict__ gr,
+                                                                 const float *__restrict__ part) {
+    __shared__ float ra[16][64], rc[16][64];
     if (blockIdx.x == 0) {
         __shared__ float red[256];
-        red[threadIdx.x] = threadIdx.x < AG_BLOCKS ? part[threadIdx.x] : 0.f;
+        if (threadIdx.x < 256) red[threadIdx.x] = threadIdx.x < AG_BLOCKS ? part[threadIdx.x] : 0.f;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
@@ -419,20 +406,27 @@ __global__ __launch_bounds__(256) void adapter_grads_red_kernel(const float *__r
         return;
     }
     const float *down_w = P + 2 * D;
-    const int k = (blockIdx.x - 1) * 64 + (threadIdx.x & 63), jl = threadIdx.x >> 6;
+    const int kl = threadIdx.x & 63, jl = threadIdx.x >> 6;
+    const int k = (blockIdx.x - 1) * 64 + kl;
     float a = 0.f, c = 0.f;
     if (k < D)
-        for (int j = jl; j < b; j += 4) {
+        for (int j = jl; j < b; j += 16) {
             const float w = down_w[(size_t)j * D + k];
             a += T[(size_t)j * D + k] * w;
             c += cd[j] * w;
         }
-    ra[jl][threadIdx.x & 63] = a;
-    rc[jl][threadIdx.x & 63] = c;
+    ra[jl][kl] = a;
+    rc[jl][kl] = c;
     __syncthreads();
     if (jl == 0 && k < D) {
-        gr[k] = ra[0][threadIdx.x] + ra[1][threadIdx.x] + ra[2][threadIdx.x] + ra[3][threadIdx.x];
-        gr[D + k] = rc[0][threadIdx.x] + rc[1][threadIdx.x] + rc[2][threadIdx.x] + rc[3][threadIdx.x];
+        float sa = 0.f, sc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            sa += ra[j][kl];
+            sc += rc[j][kl];
+        }
+        gr[k] = sa;
+        gr[D + k] = sc;
     }
 }
 
@@ -607,7 +601,7 @@ int ch_adapter_grads(const float *G, const float *cu, const float *T, const floa
                      float *grads, float *ws, hipStream_t s) {
     hipLaunchKernelGGL(adapter_grads_elem_kernel, dim3(AG_BLOCKS), dim3(256), 0, s, G, cu, T, cd, params, D, b, bpad, grads, ws);
     CH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(adapter_grads_red_kernel, dim3(1 + (D + 63) / 64), dim3(256), 0, s, T, cd, params, D, b, grads, ws);
+    hipLaunchKernelGGL(adapter_grads_red_kernel, dim3(1 + (D + 63) / 64), dim3(1024), 0, s, T, cd, params, D, b, grads, ws);
     CH_LAUNCH_CHECK();
     return 0;
 }

@@ -158,5 +158,31 @@ class EncoderFunction(torch.autograd.Function):
         return dct.view(ctx.ct_shape), None, None, None
 
 
+def adapters_from_state_dict(state_dict, layers: int, dim: int, bottleneck: int) -> list:
+    """Stand-alone adapter modules (parameter holders) initialised from a reference-layout state_dict: what TrainEngine needs when
+    there is no model object around it (benchmarks)."""
+    from models.layers.adapter import Adapter
+    out = []
+    for l in range(layers):
+        pair = []
+        for a in (1, 2):
+            prefix = VM + f"encoder.layers.{l}.adapt_mlp_{a}."
+            m = Adapter(dim, bottleneck)
+            m.load_state_dict({k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)})
+            pair.append(m)
+        out.append(tuple(pair))
+    return out
+
+
+def encoder_step_flops(cfg: dict) -> tuple:
+    """(forward, backward) algorithmic FLOPs per image of the encoder's training step: the backward's input-gradient products
+    equal the forward's linears, the adapters add their weight-gradient products, attention backward is 2.5x its forward."""
+    D, L, M, b = cfg["dim"], cfg["layers"], cfg["ffn"], cfg["adapter_dim"]
+    N = 1 + (cfg["image_size"] // cfg["patch"]) ** 2 + cfg["ncontext"]
+    lin = 2.0 * N * (4 * D * D + 2 * D * M + 4 * D * b)
+    attn = 4.0 * N * N * D
+    return L * (lin + attn), L * (lin + 2.5 * attn + 2.0 * N * 4 * D * b)
+
+
 def adapter_modules(vision_model) -> list:
     return [(layer.adapt_mlp_1, layer.adapt_mlp_2) for layer in vision_model.encoder.layers]

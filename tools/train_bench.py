@@ -16,27 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from concepthash_amd import synthetic
-from concepthash_amd.training import TrainEngine
-
-
-class _Holder(torch.nn.Module):
-    """adapter modules with the parameter names the arena expects, initialised from a synthetic state_dict"""
-
-    def __init__(self, sd, prefix, D, b):
-        super().__init__()
-        from models.layers.adapter import Adapter
-        self.m = Adapter(D, b)
-        self.m.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)})
-
-
-def flops_per_image(cfg, Q=4):
-    D, L, M, b = cfg["D"], cfg["L"], cfg["M"], cfg["b"]
-    N = 1 + (cfg["image"] // cfg["patch"]) ** 2 + Q
-    lin = 2.0 * N * (4 * D * D + 2 * D * M + 4 * D * b)          # qkv + out + fc1 + fc2 + two adapters, per layer
-    attn = 4.0 * N * N * D
-    fwd = L * (lin + attn)
-    bwd = L * (lin + 2.5 * attn + 2.0 * N * 4 * D * b)            # dgrad = forward's linears; wgrad only for the adapters
-    return fwd, bwd
+from concepthash_amd.training import TrainEngine, adapters_from_state_dict, encoder_step_flops
 
 
 def main():
@@ -48,12 +28,10 @@ def main():
     a = ap.parse_args()
     cfg = synthetic.CONFIGS[a.config]
     sd = synthetic.synthetic_state_dict(cfg, nbit=64, nclass=200)
-    VM = "backbone.vision_model."
-    adapters = [(_Holder(sd, VM + f"encoder.layers.{l}.adapt_mlp_1.", cfg["D"], cfg["b"]).m,
-                 _Holder(sd, VM + f"encoder.layers.{l}.adapt_mlp_2.", cfg["D"], cfg["b"]).m) for l in range(cfg["L"])]
+    adapters = adapters_from_state_dict(sd, cfg["L"], cfg["D"], cfg["b"])
     batches = [int(x) for x in a.batches.split(",")]
     eng = TrainEngine(sd, adapters, heads=cfg["heads"], max_batch=max(batches), device=torch.device("cuda", torch.cuda.current_device()))
-    fwd_f, bwd_f = flops_per_image(cfg)
+    fwd_f, bwd_f = encoder_step_flops(eng.cfg)
     Q, D = 4, cfg["D"]
     ctx = torch.randn(Q, D, device="cuda") * 0.02
     for B in batches:
