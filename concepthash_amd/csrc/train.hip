@@ -338,7 +338,8 @@ extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, fl
         const float *stin = a == 0 ? v.stA : v.stA2;
         // up projection: weight-gradient products (unscaled) and dgrad
         if (int e = ch_wgrad_tn(t->dHb, D, G, bpad, rows, t->rows_alloc, D, bpad, t->G, t->ws_wgrad, s)) return e;
-        if (int e = ch_colsum(t->dHb, 0, D, rows, D, t->cu, t->ws_colsum, s)) return e;   // of the bf16 operand, like G
+        // of the fp32 gradient: a bias gradient is a sum over rows that largely cancels, the bf16 copy costs 1e-1 relative there
+        if (int e = ch_colsum(t->dH, 1, D, rows, D, t->cu, t->ws_colsum, s)) return e;
         GemmCall g{bpad, D, t->dHb, aw.up_wT, zero, EPI_BIAS_DACT_GELU};   // dpre = s (dH W_up) o gelu'(pre), in the epilogue
         g.out = t->tB; g.ldo = bpad; g.aux = P; g.scale = ap.scale;
         if (int e = gemm(t, rows, g, s)) return e;

@@ -546,9 +546,11 @@ int ch_ln_bwd(const bf16_t *dyg, const bf16_t *x, const float *stats, int64_t ro
 // number of row chunks of the two-stage reductions and the workspace they need (floats)
 int ch_wgrad_chunks(int64_t rows, int N, int K) {
     const int tiles = (N / WG_TILE) * (K / WG_TILE);
-    int chunks = std::max(1, 512 / std::max(tiles, 1));
+    int chunks = std::max(1, 512 / std::max(tiles, 1));          // ~2 workgroups per CU at the most
     const int64_t steps = ceil_div64(rows, WG_KSTEP);
-    chunks = (int)std::min<int64_t>(chunks, steps);
+    // at least 32 K-steps (1024 rows) per chunk: below that the fp32 partial slabs (chunks * N * K * 4 bytes, written and re-read)
+    // cost more than the idle CUs -- at batch 32 the slab reduction was 1.6 ms of an 11 ms step
+    chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, steps / 32));
     return chunks;
 }
 size_t ch_wgrad_ws_floats(int64_t rows, int N, int K) { return (size_t)ch_wgrad_chunks(rows, N, K) * N * K; }
