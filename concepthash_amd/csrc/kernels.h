@@ -205,8 +205,8 @@ int ch_normalize_bf16(const bf16_t *x, const float *stats, int64_t rows, int D, 
 int ch_ln_bwd(const bf16_t *dyg, const bf16_t *x, const float *stats, int64_t rows, int D, float eps, const float *dres_in,
               float *dres_out, bf16_t *out_b, hipStream_t s);
 // out[n][k] = sum_m A[m][n] * B[m][k]  (A [rows, N] ld lda, B [rows, K] ld ldb, bf16; out [N, K] fp32); ws: ch_wgrad_ws_floats floats.
-// Rows up to the next multiple of 32 are read: they must be allocated and zero in A.
-int ch_wgrad_tn(const bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int64_t rows_alloc, int N, int K, float *out,
+// Rows up to the next multiple of 32 are read: they must be allocated; A's are zeroed by the call, B's must be finite.
+int ch_wgrad_tn(bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int64_t rows_alloc, int N, int K, float *out,
                 float *ws, hipStream_t s);
 size_t ch_wgrad_ws_floats(int64_t rows, int N, int K);
 // out[n] = sum_m A[m][n]; A bf16 (is_f32 = 0) or fp32 (1); ws: ch_colsum_ws_floats(N) floats

@@ -392,7 +392,7 @@ extern "C" int ch_debug_wgrad(const void *A, int32_t lda, const void *Bm, int32_
     CH_REQUIRE(A && Bm && out, "debug_wgrad: null argument");
     float *ws = nullptr;
     CH_CHECK_HIP(hipMalloc((void **)&ws, sizeof(float) * ch_wgrad_ws_floats(rows, N, K)));
-    const int e = ch_wgrad_tn((const bf16_t *)A, lda, (const bf16_t *)Bm, ldb, rows, rows_alloc, N, K, out, ws, (hipStream_t)stream);
+    const int e = ch_wgrad_tn((bf16_t *)A, lda, (const bf16_t *)Bm, ldb, rows, rows_alloc, N, K, out, ws, (hipStream_t)stream);
     (void)hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(ws);
     return e;

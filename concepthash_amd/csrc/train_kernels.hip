@@ -555,15 +555,18 @@ int ch_wgrad_chunks(int64_t rows, int N, int K) {
 }
 size_t ch_wgrad_ws_floats(int64_t rows, int N, int K) { return (size_t)ch_wgrad_chunks(rows, N, K) * N * K; }
 
-int ch_wgrad_tn(const bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int64_t rows_alloc, int N, int K, float *out,
+int ch_wgrad_tn(bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int64_t rows_alloc, int N, int K, float *out,
                 float *ws, hipStream_t s) {
     CH_REQUIRE(N % WG_TILE == 0 && K % WG_TILE == 0, "wgrad: N and K must be multiples of 128");
     CH_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "wgrad: leading dimensions must be multiples of 8");
     const int chunks = ch_wgrad_chunks(rows, N, K);
     const int total_steps = (int)ceil_div64(rows, WG_KSTEP);
     const int spc = (total_steps + chunks - 1) / chunks;
-    // rows past `rows` are read up to the next multiple of 32: the gradient operand's padding rows are zero (never written)
-    CH_REQUIRE((int64_t)total_steps * WG_KSTEP <= rows_alloc, "wgrad: operands must be allocated (zero padded) to a multiple of 32 rows");
+    // rows past `rows` are read up to the next multiple of 32: A's padding rows are zeroed here (they may hold a LARGER earlier
+    // batch's values: the buffers are reused across calls), B's only need to be finite, which any earlier contents are
+    CH_REQUIRE((int64_t)total_steps * WG_KSTEP <= rows_alloc, "wgrad: operands must be allocated to a multiple of 32 rows");
+    if ((int64_t)total_steps * WG_KSTEP > rows)
+        CH_CHECK_HIP(hipMemsetAsync(A + rows * lda, 0, sizeof(bf16_t) * ((int64_t)total_steps * WG_KSTEP - rows) * lda, s));
     hipLaunchKernelGGL(wgrad_tn_kernel, dim3((N / WG_TILE) * (K / WG_TILE), chunks), dim3(256), 0, s, A, lda, B, ldb, N, K, spc,
                        total_steps, ws);
     CH_LAUNCH_CHECK();

@@ -25,7 +25,10 @@ def _crit():
                                                          concept_logits=1), avg_before_softmax=False, lmbd=0.5, div_method=1, ncontext=4)
 
 
-def _train_model(sd, z, image_size=64):
+def _train_model(sd, z, image_size=64, act=None):
+    if act is not None:
+        z = dict(z.items())
+        z["meta/act"] = np.array(act)
     model = _model_like_fixture(z, sd, image_size)
     model.load_state_dict(sd)
     for m in model.modules():            # the fixture was generated with dropout off
@@ -102,11 +105,12 @@ def test_training_step_matches_the_reference_gradients():
     assert torch.allclose(model.hash_bn.running_var.cpu(), torch.from_numpy(z["out/bn_running_var"]), atol=5e-3, rtol=2e-2)
 
 
-def _vjp_against_oracle(sd, z, x, cot, size=64, strict=()):
+def _vjp_against_oracle(sd, z, x, cot, size=64, strict=(), act=None):
     """d(hash_features) = cot through the HIP backward vs fp32 autograd of the oracle: the encoder's part of the step alone (the
     head's train-mode BatchNorm over a handful of samples would amplify the forward's 1e-3 differences into 1e-1 gradient ones)."""
     from oracle import train_oracle as to
-    model = _train_model(sd, z, size)
+    model = _train_model(sd, z, size, act)
+    act = act or str(z["meta/act"])
     _, out = model(x.cuda())
     out["hash_features"].backward(cot.cuda())
     torch.cuda.synchronize()
@@ -114,11 +118,20 @@ def _vjp_against_oracle(sd, z, x, cot, size=64, strict=()):
     keys = [k for k in to.trainable_keys(sdg) if ".adapt_mlp_" in k or k.startswith("hash_attention") or k == "hash_queries"]
     for k in keys:
         sdg[k] = sdg[k].float().requires_grad_(True)
-    hf = to.forward_train(sdg, x, heads=int(z["meta/heads"]), upt_heads=8, act=str(z["meta/act"]))["hash_features"]
+    hf = to.forward_train(sdg, x, heads=int(z["meta/heads"]), upt_heads=8, act=act)["hash_features"]
     hf.backward(cot)
     rel = float((out["hash_features"].detach().cpu() - hf.detach()).norm() / hf.detach().norm())
     assert rel < 5e-3, rel
     _check_grads(_named_grads(model), {k: sdg[k].grad for k in keys}, floor_keys=(), strict=strict)
+
+
+def test_encoder_vjp_with_an_exact_gelu_backbone():
+    """`hidden_act: gelu` backbones (LAION CLIP): the MLP's two-output and derivative epilogues in their erf form."""
+    from oracle import encoder_oracle as eo
+    sd, z = load_fixture("encode_hd64")
+    x = eo.synthetic_images(4, 64, seed=8).to(torch.bfloat16).float()
+    cot = torch.randn(4, 4, sd["hash_pe"].shape[-1], generator=torch.Generator().manual_seed(8))
+    _vjp_against_oracle(sd, z, x, cot, act="gelu")
 
 
 @pytest.mark.parametrize("name,batch,seed", [("encode_hd64", 5, 3), ("encode_n201", 3, 4)])
@@ -221,3 +234,26 @@ def test_main_v2_exp_hashing_trains_end_to_end(tmp_path):
                     "eval_logdir=" + ev] + common, check=True, env=env, cwd=str(tmp_path))
     hist = json.load(open(os.path.join(ev, "history.json")))
     assert abs(hist["mAP"] - te[0]["mAP"]) < 1e-12          # best.pth == the only evaluated epoch: same codes, same score
+
+
+def test_a_smaller_batch_after_a_larger_one_sees_no_stale_rows():
+    """The trainer's buffers are sized for max_batch and reused: after a batch of 6, a batch of 4 must give exactly the gradients a
+    fresh trainer gives for it (the weight-gradient kernel reads whole 32-row steps; rows past the batch must not contribute)."""
+    sd, z = load_fixture("train_tiny")
+    x = fixture_images(z).cuda()
+    crit = _crit()
+    labels = torch.from_numpy(z["in/labels"]).cuda()
+
+    def grads_of(model, n):
+        model.zero_grad()
+        crit(model(x[:n])[1], labels[:n]).backward()
+        torch.cuda.synchronize()
+        return model._train_engine.grads.clone()
+
+    used = _train_model(sd, z)
+    grads_of(used, 6)
+    g_used = grads_of(used, 4)
+    fresh = _train_model(sd, z)
+    fresh.train_max_batch = 6
+    g_fresh = grads_of(fresh, 4)
+    assert torch.equal(g_used, g_fresh)
