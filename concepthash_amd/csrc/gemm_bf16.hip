@@ -220,7 +220,11 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
     // read-modify-write epilogue with the other's K loop and win there (measured: 152 -> 97 us per launch in the pipeline);
     // the 256x256 ping-pong kernel wins from K = 512 up.
     const int min_k = p.pp_min_k > 0 ? p.pp_min_k : 512;  // per model (CH_GEMM_PP_MIN_K at ch_model_create), not per process
-    const bool pp = ch_gemm_pp_supported(p) && p.K >= min_k;
+    // Small grids: fewer than 128 tiles of 256x256 leave more than half of the 256 CUs idle; 128x128 tiles (4x as many, two
+    // workgroups per CU) win there -- measured at 6,432 rows (batch 32): out 28 vs 36 us, fc2 57 vs 73 us; at 12,864 rows and
+    // N = 768 (153 tiles) the two tie.  Not applied when CH_GEMM_PP_MIN_K pins the choice (parity tests on small fixtures).
+    const int64_t tiles_pp = ceil_div64(p.M, 256) * (p.N / 256);
+    const bool pp = ch_gemm_pp_supported(p) && p.K >= min_k && (p.pp_min_k > 0 || tiles_pp >= 128);
     g_dispatch_count[pp ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
     if (pp) return ch_gemm_bf16_pp(p, epi, s);
     const bool ring = (p.small_kernel == 2 || g_gemm_variant == 7) && ch_gemm_r4_supported(p);

@@ -254,14 +254,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const bf16_t *__restri
         }
 }
 
-// out[i] = sum over chunks (in chunk order) of partial[c][i]; n4 = elements / 4
+// out[i] = sum over chunks of partial[c][i]; n4 = elements / 4.  256 threads = 32 float4 columns x 8 chunk lanes: lane l sums
+// chunks l, l + 8, ... in order, the 8 lane sums are added in lane order -- a fixed association, so run-to-run identical -- and the
+// serial chain is chunks / 8 loads instead of chunks (the one-block column-sum reduction was a 15 us latency chain of 101 loads)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int nchunks, int64_t n4,
                                                               float *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 s = *(const f32x4 *)(partial + i * 4);
-    for (int c = 1; c < nchunks; ++c) s += *(const f32x4 *)(partial + ((size_t)c * n4 + i) * 4);
-    *(f32x4 *)(out + i * 4) = s;
+    __shared__ f32x4 red[8][32];
+    const int col = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + col;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int c = cl; c < nchunks; c += 8) s += *(const f32x4 *)(partial + ((size_t)c * n4 + i) * 4);
+    red[cl][col] = s;
+    __syncthreads();
+    if (cl == 0 && i < n4) {
+        f32x4 t = red[0][col];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t += red[j][col];
+        *(f32x4 *)(out + i * 4) = t;
+    }
 }
 
 // column sums of a bf16 [rows, N] matrix over a chunk of rows -> partial[chunk][N]; block = 256 threads = 4 row lanes x 64 column pairs
@@ -548,9 +559,9 @@ int ch_wgrad_chunks(int64_t rows, int N, int K) {
     const int tiles = (N / WG_TILE) * (K / WG_TILE);
     int chunks = std::max(1, 512 / std::max(tiles, 1));          // ~2 workgroups per CU at the most
     const int64_t steps = ceil_div64(rows, WG_KSTEP);
-    // at least 32 K-steps (1024 rows) per chunk: below that the fp32 partial slabs (chunks * N * K * 4 bytes, written and re-read)
-    // cost more than the idle CUs -- at batch 32 the slab reduction was 1.6 ms of an 11 ms step
-    chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, steps / 32));
+    // at least 16 K-steps (512 rows) per chunk: below that the fp32 partial slabs (chunks * N * K * 4 bytes, written and re-read)
+    // cost more than the idle CUs
+    chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunks, steps / 16));
     return chunks;
 }
 size_t ch_wgrad_ws_floats(int64_t rows, int N, int K) { return (size_t)ch_wgrad_chunks(rows, N, K) * N * K; }
@@ -571,7 +582,7 @@ int ch_wgrad_tn(bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int6
                        total_steps, ws);
     CH_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)N * K / 4;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(n4, 256)), dim3(256), 0, s, ws, chunks, n4, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(n4, 32)), dim3(256), 0, s, ws, chunks, n4, out);
     CH_LAUNCH_CHECK();
     return 0;
 }
@@ -585,7 +596,7 @@ int ch_colsum(const void *A, int is_f32, int lda, int64_t rows, int N, float *ou
     else
         hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, (const bf16_t *)A, lda, rows, N, chunk_rows, ws);
     CH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(N / 4, 256)), dim3(256), 0, s, ws, chunks, (int64_t)N / 4, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(N / 4, 32)), dim3(256), 0, s, ws, chunks, (int64_t)N / 4, out);
     CH_LAUNCH_CHECK();
     return 0;
 }
