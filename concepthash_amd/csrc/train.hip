@@ -42,22 +42,35 @@ struct Saved {
 };
 }  // namespace
 
+constexpr int TR_CHAINS = 2;
+
 struct ch_trainer {
     ch_model *m = nullptr;
     int max_batch = 0, B = 0;
-    int64_t rows_alloc = 0, prow_alloc = 0;
-    float *params = nullptr, *grads = nullptr;
+    // Two micro-batch chains on two streams (as ch_encode does), CH_TRAIN_STREAMS=2: chain 1 owns its own row
+    // region of every activation buffer (so that padding rows never alias the other chain's data), its own weight-gradient
+    // scratch and its own gradient arena; the two arenas are added once at the end (the assembly is linear in the weight-gradient
+    // products).  Correct (tests run both), but MEASURED SLOWER than one chain for training -- 47.2 vs 42.5 ms at batch 256, 27.0
+    // vs 23.6 ms at batch 128: the half-size GEMMs lose more than the overlap of the HBM-bound launches returns, and the
+    // per-adapter reductions have fixed costs that double -- so one chain is the default.
+    int nchains = 1, nc = 1, Bc[TR_CHAINS] = {0, 0};
+    int64_t chain_min_rows = 12000;
+    int64_t row_off[TR_CHAINS] = {0, 0}, prow_off[TR_CHAINS] = {0, 0}, region_rows[TR_CHAINS] = {0, 0}, region_prows[TR_CHAINS] = {0, 0};
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float *params = nullptr, *grads = nullptr, *grads1 = nullptr;
     int64_t ad_numel = 0;
     std::vector<void *> allocs;
     size_t bytes = 0;
     std::vector<AdWork> ad;     // [L * 2]
     std::vector<LayerT> lt;     // [L]
     std::vector<Saved> sv;      // [L]
-    float *H = nullptr, *dH = nullptr, *ctx = nullptr, *dctx_sum = nullptr;
+    float *H = nullptr, *dH = nullptr, *ctx = nullptr;
     bf16_t *dHb = nullptr, *dMb = nullptr, *tD = nullptr, *tD2 = nullptr, *tB = nullptr, *tM = nullptr, *tQKV = nullptr, *F1act = nullptr,
            *PATCH = nullptr, *XnDummy = nullptr;
     float *stDummy = nullptr;
-    float *ws_wgrad = nullptr, *ws_colsum = nullptr, *G = nullptr, *T = nullptr, *cu = nullptr, *cd = nullptr;
+    float *ws_wgrad[TR_CHAINS] = {}, *ws_colsum[TR_CHAINS] = {}, *G[TR_CHAINS] = {}, *T[TR_CHAINS] = {}, *cu[TR_CHAINS] = {},
+          *cd[TR_CHAINS] = {}, *dctx_sum[TR_CHAINS] = {};
     bool forward_done = false;
 };
 
@@ -115,14 +128,171 @@ struct GemmCall {
     int ld_hb = 0;              // 0 = D
     const bf16_t *aux = nullptr;
 };
-int gemm(ch_trainer *t, int rows, const GemmCall &g, hipStream_t s) {
+int gemm(ch_trainer *t, int chain, int rows, const GemmCall &g, hipStream_t s) {
     const int D = t->m->cfg.dim;
     GemmParams p{};
-    p.X = g.X; p.W = g.W; p.M = rows; p.N = g.N; p.K = g.K; p.X_rows_alloc = t->rows_alloc;
+    p.X = g.X; p.W = g.W; p.M = rows; p.N = g.N; p.K = g.K; p.X_rows_alloc = t->region_rows[chain];
     p.bias = g.bias; p.out_bf16 = g.out; p.ldo = g.ldo; p.resid = g.resid; p.ldr = D; p.scale_ptr = g.scale; p.addend = g.addend;
     p.ld_addend = D; p.stats_in = g.stats_in; p.fold_c = g.fold_c; p.ln_eps = g.eps; p.stats_out = g.stats_out; p.hb_out = g.hb_out;
     p.ld_hb = g.ld_hb ? g.ld_hb : D; p.aux = g.aux; p.pp_min_k = t->m->pp_min_k;
     return ch_gemm_bf16(p, g.epi, s);
+}
+
+// the row region of chain `ch`: every activation buffer is addressed through these
+struct Rows {
+    int64_t r0;
+    int D, M, bpad;
+    template <typename T>
+    T *d(T *p) const { return p + r0 * D; }
+    template <typename T>
+    T *d3(T *p) const { return p + r0 * 3 * D; }
+    template <typename T>
+    T *m(T *p) const { return p + r0 * M; }
+    template <typename T>
+    T *b(T *p) const { return p + r0 * bpad; }
+    float *st(float *p) const { return p + r0 * (D / 64) * 2; }
+};
+
+int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype, int img0, int B, float *out_hf_all, float *out_cls_all,
+                  hipStream_t s) {
+    ch_model *m = t->m;
+    const ch_model_config &c = m->cfg;
+    const int D = c.dim, M = c.ffn, ntok = m->ntok, np = m->np, bpad = m->bpad, Q = c.ncontext, L = c.layers;
+    const int rows = B * ntok;
+    const Rows R{t->row_off[ch], D, M, bpad};
+    float *H = R.d(t->H);
+    bf16_t *PATCH = t->PATCH + t->prow_off[ch] * m->Kp;
+    const size_t img_elems = (size_t)3 * c.image_size * c.image_size;
+    const void *images = (const char *)images_all + (size_t)img0 * img_elems * (image_dtype == 0 ? 4 : 2);
+    // ---- embeddings (models/arch/coop.py:452-472): im2col + patch GEMM, CLS / position / concept tokens, pre-LN
+    if (int e = ch_im2col(images, image_dtype, B, c.image_size, c.patch, m->Kp, PATCH, s)) return e;
+    {
+        GemmParams p{};
+        p.X = PATCH; p.W = m->patch_w; p.M = B * np; p.N = D; p.K = m->Kp; p.X_rows_alloc = t->region_prows[ch];
+        p.resid = H; p.ldr = D; p.pos = m->pos; p.tokens_per_img = ntok; p.patches_per_img = np; p.pp_min_k = m->pp_min_k;
+        if (int e = ch_gemm_bf16(p, EPI_PATCH, s)) return e;
+    }
+    const LayerW &w0 = m->layers[0];
+    if (int e = ch_assemble_preln(H, B, ntok, np, D, m->cls_pos0, t->ctx, m->pre_w, m->pre_b, w0.ln1_w, w0.ln1_b, c.ln_eps,
+                                  R.d(t->XnDummy), s))
+        return e;
+    if (int e = ch_hb_stats(H, rows, D, R.d(t->sv[0].Xn1), R.st(t->sv[0].st1), s)) return e;
+    for (int l = 0; l < L; ++l) {
+        const LayerW &w = m->layers[l];
+        Saved &v = t->sv[l];
+        GemmCall g;
+        // attention block
+        g = GemmCall{3 * D, D, R.d(v.Xn1), w.qkv_wf, w.qkv_d, EPI_FOLD_BIAS};
+        g.out = R.d3(v.QKV); g.ldo = 3 * D; g.stats_in = R.st(v.st1); g.fold_c = w.qkv_c; g.eps = c.ln_eps;
+        if (int e = gemm(t, ch, rows, g, s)) return e;
+        if (int e = ch_attention(R.d3(v.QKV), B, ntok, c.heads, R.d(v.AO), s)) return e;
+        g = GemmCall{D, D, R.d(v.AO), w.out_w, w.out_b, EPI_BIAS_STATS};
+        g.out = R.d(v.A); g.ldo = D; g.stats_out = R.st(v.stA);
+        if (int e = gemm(t, ch, rows, g, s)) return e;
+        for (int a = 0; a < 2; ++a) {
+            const AdWork &aw = t->ad[l * 2 + a];
+            const AdPtr ap = ad_ptrs(t->params + (int64_t)(l * 2 + a) * t->ad_numel, c);
+            const bf16_t *in = R.d(a == 0 ? v.A : v.A2);
+            const float *stin = R.st(a == 0 ? v.stA : v.stA2);
+            bf16_t *P = R.b(a == 0 ? v.P1 : v.P2), *G = R.b(a == 0 ? v.G1 : v.G2);
+            // pre-activation kept for backward, nn.GELU() (models/layers/adapter.py:36) of it as the second output
+            g = GemmCall{bpad, D, in, aw.down_wf, aw.fold_d, EPI_FOLD_ACT2_GELU};
+            g.out = P; g.ldo = bpad; g.stats_in = stin; g.fold_c = aw.fold_c; g.eps = 1e-5f; g.hb_out = G; g.ld_hb = bpad;
+            if (int e = gemm(t, ch, rows, g, s)) return e;
+            g = GemmCall{D, bpad, G, aw.up_w, ap.up_b, EPI_SCALE_RESID_STATS};
+            g.resid = H; g.scale = ap.scale; g.addend = in;
+            if (a == 0) {
+                g.stats_out = R.st(v.st2); g.hb_out = R.d(v.Xn2);
+            } else {
+                g.stats_out = R.st(l + 1 < L ? t->sv[l + 1].st1 : t->stDummy);
+                g.hb_out = R.d(l + 1 < L ? t->sv[l + 1].Xn1 : t->XnDummy);
+            }
+            if (int e = gemm(t, ch, rows, g, s)) return e;
+            if (a == 0) {  // MLP
+                g = GemmCall{M, D, R.d(v.Xn2), w.fc1_wf, w.fc1_d, c.act == 0 ? EPI_FOLD_ACT2_QUICK : EPI_FOLD_ACT2_GELU};
+                g.out = R.m(v.F1pre); g.ldo = M; g.stats_in = R.st(v.st2); g.fold_c = w.fc1_c; g.eps = c.ln_eps; g.hb_out = R.m(t->F1act); g.ld_hb = M;
+                if (int e = gemm(t, ch, rows, g, s)) return e;
+                g = GemmCall{D, M, R.m(t->F1act), w.fc2_w, w.fc2_b, EPI_BIAS_STATS};
+                g.out = R.d(v.A2); g.ldo = D; g.stats_out = R.st(v.stA2);
+                if (int e = gemm(t, ch, rows, g, s)) return e;
+            }
+        }
+    }
+    if (int e = ch_gather_concept_rows(H, B, ntok, Q, D, out_hf_all + (size_t)img0 * Q * D, s)) return e;
+    if (out_cls_all) {  // CLS rows of the final residual (the pooled branch, models/arch/coop.py:484-499, is not part of the loss)
+        CH_CHECK_HIP(hipMemcpy2DAsync(out_cls_all + (size_t)img0 * D, sizeof(float) * D, H, sizeof(float) * (size_t)ntok * D, sizeof(float) * D, B,
+                                      hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+int backward_chain(ch_trainer *t, int ch, const float *dhf_all, int img0, int B, hipStream_t s) {
+    ch_model *m = t->m;
+    const ch_model_config &c = m->cfg;
+    const int D = c.dim, M = c.ffn, ntok = m->ntok, bpad = m->bpad, Q = c.ncontext, L = c.layers, b = c.adapter_dim;
+    const int rows = B * ntok;
+    const Rows R{t->row_off[ch], D, M, bpad};
+    const float *zero = m->zero_bias;
+    float *dH = R.d(t->dH), *grads = ch == 0 ? t->grads : t->grads1;
+    bf16_t *dHb = R.d(t->dHb), *dMb = R.d(t->dMb), *tD = R.d(t->tD), *tD2 = R.d(t->tD2), *tB = R.b(t->tB), *tM = R.m(t->tM),
+           *tQKV = R.d3(t->tQKV);
+    const int64_t ralloc = t->region_rows[ch];
+    // the loss reads only hash_features = H[:, -Q:, :] (models/arch/coop.py:484-486): dH is zero elsewhere
+    if (int e = ch_scatter_concept_rows(dhf_all + (size_t)img0 * Q * D, B, ntok, Q, D, dH, dHb, s)) return e;
+
+    // gradient of the block output arrives in dH / dHb; leaves d(branch input) = dH + adapter path in dMb (bf16 only)
+    auto adapter_bwd = [&](int l, int a) -> int {
+        const AdWork &aw = t->ad[l * 2 + a];
+        const Saved &v = t->sv[l];
+        float *pbase = t->params + (int64_t)(l * 2 + a) * t->ad_numel;
+        const AdPtr ap = ad_ptrs(pbase, c);
+        const bf16_t *in = R.d(a == 0 ? v.A : v.A2), *P = R.b(a == 0 ? v.P1 : v.P2), *G = R.b(a == 0 ? v.G1 : v.G2);
+        const float *stin = R.st(a == 0 ? v.stA : v.stA2);
+        // up projection: weight-gradient products (unscaled) and dgrad
+        if (int e = ch_wgrad_tn(dHb, D, G, bpad, rows, ralloc, D, bpad, t->G[ch], t->ws_wgrad[ch], s)) return e;
+        // of the fp32 gradient: a bias gradient is a sum over rows that largely cancels, the bf16 copy costs 1e-1 relative there
+        if (int e = ch_colsum(dH, 1, D, rows, D, t->cu[ch], t->ws_colsum[ch], s)) return e;
+        GemmCall g{bpad, D, dHb, aw.up_wT, zero, EPI_BIAS_DACT_GELU};   // dpre = s (dH W_up) o gelu'(pre), in the epilogue
+        g.out = tB; g.ldo = bpad; g.aux = P; g.scale = ap.scale;
+        if (int e = gemm(t, ch, rows, g, s)) return e;
+        // down projection + adapter LayerNorm
+        if (int e = ch_normalize_bf16(in, stin, rows, D, 1e-5f, tD2, s)) return e;
+        if (int e = ch_wgrad_tn(tB, bpad, tD2, D, rows, ralloc, bpad, D, t->T[ch], t->ws_wgrad[ch], s)) return e;
+        if (int e = ch_colsum(tB, 0, bpad, rows, bpad, t->cd[ch], t->ws_colsum[ch], s)) return e;
+        if (int e = ch_adapter_grads(t->G[ch], t->cu[ch], t->T[ch], t->cd[ch], pbase, D, b, bpad, grads + (int64_t)(l * 2 + a) * t->ad_numel,
+                                     t->ws_colsum[ch], s))
+            return e;
+        g = GemmCall{D, bpad, tB, aw.down_wgT, zero, EPI_BIAS};
+        g.out = tD; g.ldo = D;
+        if (int e = gemm(t, ch, rows, g, s)) return e;
+        return ch_ln_bwd(tD, in, stin, rows, D, 1e-5f, dH, nullptr, dMb, s);
+    };
+
+    for (int l = L - 1; l >= 0; --l) {
+        const Saved &v = t->sv[l];
+        const LayerT &x = t->lt[l];
+        // ---- x_out = x_mid + m + adapter_2(m),  m = fc2(act(fc1(LN2(x_mid))))
+        if (int e = adapter_bwd(l, 1)) return e;
+        GemmCall g{M, D, dMb, x.fc2_wT, zero, c.act == 0 ? EPI_BIAS_DACT_QUICK : EPI_BIAS_DACT_GELU};
+        g.out = tM; g.ldo = M; g.aux = R.m(v.F1pre);
+        if (int e = gemm(t, ch, rows, g, s)) return e;
+        g = GemmCall{D, M, tM, x.fc1_wgT, zero, EPI_BIAS};
+        g.out = tD; g.ldo = D;
+        if (int e = gemm(t, ch, rows, g, s)) return e;
+        if (int e = ch_ln_bwd(tD, R.d(v.Xn2), R.st(v.st2), rows, D, c.ln_eps, dH, dH, dHb, s)) return e;
+        // ---- x_mid = x_in + a + adapter_1(a),  a = out_proj(attention(qkv(LN1(x_in))))
+        if (int e = adapter_bwd(l, 0)) return e;
+        g = GemmCall{D, D, dMb, x.out_wT, zero, EPI_BIAS};
+        g.out = tD; g.ldo = D;
+        if (int e = gemm(t, ch, rows, g, s)) return e;
+        if (int e = ch_attention_bwd(R.d3(v.QKV), tD, B, ntok, c.heads, tQKV, s)) return e;
+        g = GemmCall{D, 3 * D, tQKV, x.qkv_wgT, zero, EPI_BIAS};
+        g.out = tD; g.ldo = D;
+        if (int e = gemm(t, ch, rows, g, s)) return e;
+        if (int e = ch_ln_bwd(tD, R.d(v.Xn1), R.st(v.st1), rows, D, c.ln_eps, dH, dH, dHb, s)) return e;
+    }
+    // ---- concept tokens: rows ntok-Q.. of every image are pre_layrnorm(ctx[q]) (models/arch/coop.py:470-472)
+    return ch_concept_rows_sum(dH, B, ntok, Q, D, t->dctx_sum[ch], s);
 }
 
 }  // namespace
@@ -135,6 +305,9 @@ extern "C" int64_t ch_adapter_arena_numel(const ch_model *m) {
 extern "C" void ch_trainer_destroy(ch_trainer *t) {
     if (!t) return;
     for (void *p : t->allocs) (void)hipFree(p);
+    if (t->aux) (void)hipStreamDestroy(t->aux);
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+    if (t->ev_join) (void)hipEventDestroy(t->ev_join);
     delete t;
 }
 
@@ -169,12 +342,25 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
     t->params = params;
     t->grads = grads;
     t->ad_numel = adapter_numel(c);
-    const int D = c.dim, L = c.layers, M = c.ffn, b = c.adapter_dim, bpad = m->bpad, Q = c.ncontext;
-    const int64_t rows = round_up64((int64_t)max_batch * m->ntok, 256) + 256;
-    const int64_t prows = round_up64((int64_t)max_batch * m->np, 256) + 256;
-    t->rows_alloc = rows;
-    t->prow_alloc = prows;
+    if (const char *e = getenv("CH_TRAIN_STREAMS")) t->nchains = std::max(1, std::min(atoi(e), TR_CHAINS));
+    if (const char *e = getenv("CH_TRAIN_CHAIN_MIN_ROWS")) t->chain_min_rows = std::max(1, atoi(e));
+    const int D = c.dim, L = c.layers, M = c.ffn, bpad = m->bpad, Q = c.ncontext;
+    // region 0 holds a whole batch (one chain) or the first half (two chains); region 1 the second half
+    const int half = (max_batch + 1) / 2;
+    t->region_rows[0] = round_up64((int64_t)max_batch * m->ntok, 256) + 256;
+    t->region_prows[0] = round_up64((int64_t)max_batch * m->np, 256) + 256;
+    t->region_rows[1] = t->nchains > 1 ? round_up64((int64_t)half * m->ntok, 256) + 256 : 0;
+    t->region_prows[1] = t->nchains > 1 ? round_up64((int64_t)half * m->np, 256) + 256 : 0;
+    t->row_off[1] = t->region_rows[0];
+    t->prow_off[1] = t->region_prows[0];
+    const int64_t rows = t->region_rows[0] + t->region_rows[1], prows = t->region_prows[0] + t->region_prows[1];
     bool ok = true;
+    if (t->nchains > 1) {
+        ok = hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) == hipSuccess;
+        if (!ok) ch_set_error("trainer: cannot create the auxiliary stream / events");
+    }
     auto bf = [&](int64_t cols) { return (bf16_t *)talloc(t, sizeof(bf16_t) * rows * cols, ok); };
     auto st = [&]() { return (float *)talloc(t, sizeof(float) * rows * (D / 64) * 2, ok); };
     t->ad.resize(L * 2);
@@ -216,15 +402,17 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
     t->stDummy = st();
     t->PATCH = (bf16_t *)talloc(t, sizeof(bf16_t) * prows * m->Kp, ok);
     t->ctx = (float *)talloc(t, sizeof(float) * Q * D, ok);
-    t->dctx_sum = (float *)talloc(t, sizeof(float) * Q * D, ok);
     const int64_t max_rows = (int64_t)max_batch * m->ntok;
-    t->ws_wgrad = (float *)talloc(t, sizeof(float) * std::max(ch_wgrad_ws_floats(max_rows, D, bpad), ch_wgrad_ws_floats(max_rows, bpad, D)), ok);
-    t->ws_colsum = (float *)talloc(t, sizeof(float) * ch_colsum_ws_floats(std::max(D, bpad)), ok);
-    t->G = (float *)talloc(t, sizeof(float) * (size_t)D * bpad, ok);
-    t->T = (float *)talloc(t, sizeof(float) * (size_t)bpad * D, ok);
-    t->cu = (float *)talloc(t, sizeof(float) * D, ok);
-    t->cd = (float *)talloc(t, sizeof(float) * bpad, ok);
-    (void)b;
+    for (int ch = 0; ch < t->nchains; ++ch) {
+        t->ws_wgrad[ch] = (float *)talloc(t, sizeof(float) * std::max(ch_wgrad_ws_floats(max_rows, D, bpad), ch_wgrad_ws_floats(max_rows, bpad, D)), ok);
+        t->ws_colsum[ch] = (float *)talloc(t, sizeof(float) * ch_colsum_ws_floats(std::max(D, bpad)), ok);
+        t->G[ch] = (float *)talloc(t, sizeof(float) * (size_t)D * bpad, ok);
+        t->T[ch] = (float *)talloc(t, sizeof(float) * (size_t)bpad * D, ok);
+        t->cu[ch] = (float *)talloc(t, sizeof(float) * D, ok);
+        t->cd[ch] = (float *)talloc(t, sizeof(float) * bpad, ok);
+        t->dctx_sum[ch] = (float *)talloc(t, sizeof(float) * Q * D, ok);
+    }
+    if (t->nchains > 1) t->grads1 = (float *)talloc(t, sizeof(float) * t->ad_numel * L * 2, ok);
     if (ok && ch_trainer_refresh(t, nullptr) != 0) ok = false;
     if (ok && hipDeviceSynchronize() != hipSuccess) {
         ch_set_error("trainer: device error while preparing the working copies");
@@ -246,71 +434,22 @@ extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image
     CH_REQUIRE(B >= 1 && B <= t->max_batch, "train_forward: batch outside [1, max_batch]");
     CH_REQUIRE(image_dtype == 0 || image_dtype == 1, "train_forward: image_dtype must be 0 (fp32) or 1 (bf16)");
     hipStream_t s = (hipStream_t)stream;
-    ch_model *m = t->m;
-    const ch_model_config &c = m->cfg;
-    const int D = c.dim, M = c.ffn, ntok = m->ntok, np = m->np, bpad = m->bpad, Q = c.ncontext, L = c.layers;
-    const int rows = B * ntok;
+    const ch_model_config &c = t->m->cfg;
     t->B = B;
     t->forward_done = false;
-    CH_CHECK_HIP(hipMemcpyAsync(t->ctx, concept_tokens, sizeof(float) * Q * D, hipMemcpyDeviceToDevice, s));
-    // ---- embeddings (models/arch/coop.py:452-472): im2col + patch GEMM, CLS / position / concept tokens, pre-LN
-    if (int e = ch_im2col(images, image_dtype, B, c.image_size, c.patch, m->Kp, t->PATCH, s)) return e;
-    {
-        GemmParams p{};
-        p.X = t->PATCH; p.W = m->patch_w; p.M = B * np; p.N = D; p.K = m->Kp; p.X_rows_alloc = t->prow_alloc;
-        p.resid = t->H; p.ldr = D; p.pos = m->pos; p.tokens_per_img = ntok; p.patches_per_img = np; p.pp_min_k = m->pp_min_k;
-        if (int e = ch_gemm_bf16(p, EPI_PATCH, s)) return e;
-    }
-    const LayerW &w0 = m->layers[0];
-    if (int e = ch_assemble_preln(t->H, B, ntok, np, D, m->cls_pos0, t->ctx, m->pre_w, m->pre_b, w0.ln1_w, w0.ln1_b, c.ln_eps,
-                                  t->XnDummy, s))
-        return e;
-    if (int e = ch_hb_stats(t->H, rows, D, t->sv[0].Xn1, t->sv[0].st1, s)) return e;
-    for (int l = 0; l < L; ++l) {
-        const LayerW &w = m->layers[l];
-        Saved &v = t->sv[l];
-        GemmCall g;
-        // attention block
-        g = GemmCall{3 * D, D, v.Xn1, w.qkv_wf, w.qkv_d, EPI_FOLD_BIAS};
-        g.out = v.QKV; g.ldo = 3 * D; g.stats_in = v.st1; g.fold_c = w.qkv_c; g.eps = c.ln_eps;
-        if (int e = gemm(t, rows, g, s)) return e;
-        if (int e = ch_attention(v.QKV, B, ntok, c.heads, v.AO, s)) return e;
-        g = GemmCall{D, D, v.AO, w.out_w, w.out_b, EPI_BIAS_STATS};
-        g.out = v.A; g.ldo = D; g.stats_out = v.stA;
-        if (int e = gemm(t, rows, g, s)) return e;
-        for (int a = 0; a < 2; ++a) {
-            const AdWork &aw = t->ad[l * 2 + a];
-            const AdPtr ap = ad_ptrs(t->params + (int64_t)(l * 2 + a) * t->ad_numel, c);
-            const bf16_t *in = a == 0 ? v.A : v.A2;
-            const float *stin = a == 0 ? v.stA : v.stA2;
-            bf16_t *P = a == 0 ? v.P1 : v.P2, *G = a == 0 ? v.G1 : v.G2;
-            // pre-activation kept for backward, nn.GELU() (models/layers/adapter.py:36) of it as the second output
-            g = GemmCall{bpad, D, in, aw.down_wf, aw.fold_d, EPI_FOLD_ACT2_GELU};
-            g.out = P; g.ldo = bpad; g.stats_in = stin; g.fold_c = aw.fold_c; g.eps = 1e-5f; g.hb_out = G; g.ld_hb = bpad;
-            if (int e = gemm(t, rows, g, s)) return e;
-            g = GemmCall{D, bpad, G, aw.up_w, ap.up_b, EPI_SCALE_RESID_STATS};
-            g.resid = t->H; g.scale = ap.scale; g.addend = in;
-            if (a == 0) {
-                g.stats_out = v.st2; g.hb_out = v.Xn2;
-            } else {
-                g.stats_out = l + 1 < L ? t->sv[l + 1].st1 : t->stDummy;
-                g.hb_out = l + 1 < L ? t->sv[l + 1].Xn1 : t->XnDummy;
-            }
-            if (int e = gemm(t, rows, g, s)) return e;
-            if (a == 0) {  // MLP
-                g = GemmCall{M, D, v.Xn2, w.fc1_wf, w.fc1_d, c.act == 0 ? EPI_FOLD_ACT2_QUICK : EPI_FOLD_ACT2_GELU};
-                g.out = v.F1pre; g.ldo = M; g.stats_in = v.st2; g.fold_c = w.fc1_c; g.eps = c.ln_eps; g.hb_out = t->F1act; g.ld_hb = M;
-                if (int e = gemm(t, rows, g, s)) return e;
-                g = GemmCall{D, M, t->F1act, w.fc2_w, w.fc2_b, EPI_BIAS_STATS};
-                g.out = v.A2; g.ldo = D; g.stats_out = v.stA2;
-                if (int e = gemm(t, rows, g, s)) return e;
-            }
-        }
-    }
-    if (int e = ch_gather_concept_rows(t->H, B, ntok, Q, D, out_hash_features, s)) return e;
-    if (out_cls) {  // CLS rows of the final residual (the pooled branch, models/arch/coop.py:484-499, is not part of the loss)
-        CH_CHECK_HIP(hipMemcpy2DAsync(out_cls, sizeof(float) * D, t->H, sizeof(float) * (size_t)ntok * D, sizeof(float) * D, B,
-                                      hipMemcpyDeviceToDevice, s));
+    CH_CHECK_HIP(hipMemcpyAsync(t->ctx, concept_tokens, sizeof(float) * c.ncontext * c.dim, hipMemcpyDeviceToDevice, s));
+    t->nc = (t->nchains > 1 && (int64_t)(B / 2) * t->m->ntok >= t->chain_min_rows) ? 2 : 1;
+    if (t->nc == 1) {
+        t->Bc[0] = B; t->Bc[1] = 0;
+        if (int e = forward_chain(t, 0, images, image_dtype, 0, B, out_hash_features, out_cls, s)) return e;
+    } else {
+        t->Bc[0] = B - B / 2; t->Bc[1] = B / 2;      // chain 1 <= ceil(max_batch / 2) images: fits its region
+        CH_CHECK_HIP(hipEventRecord(t->ev_fork, s));
+        CH_CHECK_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
+        if (int e = forward_chain(t, 0, images, image_dtype, 0, t->Bc[0], out_hash_features, out_cls, s)) return e;
+        if (int e = forward_chain(t, 1, images, image_dtype, t->Bc[0], t->Bc[1], out_hash_features, out_cls, t->aux)) return e;
+        CH_CHECK_HIP(hipEventRecord(t->ev_join, t->aux));
+        CH_CHECK_HIP(hipStreamWaitEvent(s, t->ev_join, 0));
     }
     t->forward_done = true;
     return 0;
@@ -320,66 +459,22 @@ extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, fl
     CH_REQUIRE(t != nullptr && d_hash_features != nullptr && d_concept_tokens != nullptr, "train_backward: null argument");
     CH_REQUIRE(t->forward_done, "train_backward: call ch_train_forward first (its saved activations are what backward reads)");
     hipStream_t s = (hipStream_t)stream;
-    ch_model *m = t->m;
-    const ch_model_config &c = m->cfg;
-    const int D = c.dim, M = c.ffn, ntok = m->ntok, bpad = m->bpad, Q = c.ncontext, L = c.layers, b = c.adapter_dim, B = t->B;
-    const int rows = B * ntok;
-    const float *zero = m->zero_bias;
-    // the loss reads only hash_features = H[:, -Q:, :] (models/arch/coop.py:484-486): dH is zero elsewhere
-    if (int e = ch_scatter_concept_rows(d_hash_features, B, ntok, Q, D, t->dH, t->dHb, s)) return e;
-
-    // gradient of the block output arrives in dH / dHb; leaves d(branch input) = dH + adapter path in dMb (bf16 only)
-    auto adapter_bwd = [&](int l, int a) -> int {
-        const AdWork &aw = t->ad[l * 2 + a];
-        const Saved &v = t->sv[l];
-        float *pbase = t->params + (int64_t)(l * 2 + a) * t->ad_numel;
-        const AdPtr ap = ad_ptrs(pbase, c);
-        const bf16_t *in = a == 0 ? v.A : v.A2, *P = a == 0 ? v.P1 : v.P2, *G = a == 0 ? v.G1 : v.G2;
-        const float *stin = a == 0 ? v.stA : v.stA2;
-        // up projection: weight-gradient products (unscaled) and dgrad
-        if (int e = ch_wgrad_tn(t->dHb, D, G, bpad, rows, t->rows_alloc, D, bpad, t->G, t->ws_wgrad, s)) return e;
-        // of the fp32 gradient: a bias gradient is a sum over rows that largely cancels, the bf16 copy costs 1e-1 relative there
-        if (int e = ch_colsum(t->dH, 1, D, rows, D, t->cu, t->ws_colsum, s)) return e;
-        GemmCall g{bpad, D, t->dHb, aw.up_wT, zero, EPI_BIAS_DACT_GELU};   // dpre = s (dH W_up) o gelu'(pre), in the epilogue
-        g.out = t->tB; g.ldo = bpad; g.aux = P; g.scale = ap.scale;
-        if (int e = gemm(t, rows, g, s)) return e;
-        // down projection + adapter LayerNorm
-        if (int e = ch_normalize_bf16(in, stin, rows, D, 1e-5f, t->tD2, s)) return e;
-        if (int e = ch_wgrad_tn(t->tB, bpad, t->tD2, D, rows, t->rows_alloc, bpad, D, t->T, t->ws_wgrad, s)) return e;
-        if (int e = ch_colsum(t->tB, 0, bpad, rows, bpad, t->cd, t->ws_colsum, s)) return e;
-        if (int e = ch_adapter_grads(t->G, t->cu, t->T, t->cd, pbase, D, b, bpad, t->grads + (int64_t)(l * 2 + a) * t->ad_numel, t->ws_colsum, s)) return e;
-        g = GemmCall{D, bpad, t->tB, aw.down_wgT, zero, EPI_BIAS};
-        g.out = t->tD; g.ldo = D;
-        if (int e = gemm(t, rows, g, s)) return e;
-        return ch_ln_bwd(t->tD, in, stin, rows, D, 1e-5f, t->dH, nullptr, t->dMb, s);
-    };
-
-    for (int l = L - 1; l >= 0; --l) {
-        const Saved &v = t->sv[l];
-        const LayerT &x = t->lt[l];
-        // ---- x_out = x_mid + m + adapter_2(m),  m = fc2(act(fc1(LN2(x_mid))))
-        if (int e = adapter_bwd(l, 1)) return e;
-        GemmCall g{M, D, t->dMb, x.fc2_wT, zero, c.act == 0 ? EPI_BIAS_DACT_QUICK : EPI_BIAS_DACT_GELU};
-        g.out = t->tM; g.ldo = M; g.aux = v.F1pre;
-        if (int e = gemm(t, rows, g, s)) return e;
-        g = GemmCall{D, M, t->tM, x.fc1_wgT, zero, EPI_BIAS};
-        g.out = t->tD; g.ldo = D;
-        if (int e = gemm(t, rows, g, s)) return e;
-        if (int e = ch_ln_bwd(t->tD, v.Xn2, v.st2, rows, D, c.ln_eps, t->dH, t->dH, t->dHb, s)) return e;
-        // ---- x_mid = x_in + a + adapter_1(a),  a = out_proj(attention(qkv(LN1(x_in))))
-        if (int e = adapter_bwd(l, 0)) return e;
-        g = GemmCall{D, D, t->dMb, x.out_wT, zero, EPI_BIAS};
-        g.out = t->tD; g.ldo = D;
-        if (int e = gemm(t, rows, g, s)) return e;
-        if (int e = ch_attention_bwd(v.QKV, t->tD, B, ntok, c.heads, t->tQKV, s)) return e;
-        g = GemmCall{D, 3 * D, t->tQKV, x.qkv_wgT, zero, EPI_BIAS};
-        g.out = t->tD; g.ldo = D;
-        if (int e = gemm(t, rows, g, s)) return e;
-        if (int e = ch_ln_bwd(t->tD, v.Xn1, v.st1, rows, D, c.ln_eps, t->dH, t->dH, t->dHb, s)) return e;
+    const ch_model_config &c = t->m->cfg;
+    const int Q = c.ncontext, D = c.dim;
+    if (t->nc == 1) {
+        if (int e = backward_chain(t, 0, d_hash_features, 0, t->Bc[0], s)) return e;
+    } else {
+        CH_CHECK_HIP(hipEventRecord(t->ev_fork, s));
+        CH_CHECK_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
+        if (int e = backward_chain(t, 0, d_hash_features, 0, t->Bc[0], s)) return e;
+        if (int e = backward_chain(t, 1, d_hash_features, t->Bc[0], t->Bc[1], t->aux)) return e;
+        CH_CHECK_HIP(hipEventRecord(t->ev_join, t->aux));
+        CH_CHECK_HIP(hipStreamWaitEvent(s, t->ev_join, 0));
+        // the two chains' contributions: parameter gradients and concept-token rows (both linear in the per-row products)
+        if (int e = ch_small_add(t->grads, t->grads1, t->ad_numel * c.layers * 2, t->grads, s)) return e;
+        if (int e = ch_small_add(t->dctx_sum[0], t->dctx_sum[1], (int64_t)Q * D, t->dctx_sum[0], s)) return e;
     }
-    // ---- concept tokens: rows ntok-Q.. of every image are pre_layrnorm(ctx[q]) (models/arch/coop.py:470-472)
-    if (int e = ch_concept_rows_sum(t->dH, B, ntok, Q, D, t->dctx_sum, s)) return e;
-    return ch_small_ln_bwd(t->dctx_sum, t->ctx, m->pre_w, Q, D, c.ln_eps, d_concept_tokens, s);
+    return ch_small_ln_bwd(t->dctx_sum[0], t->ctx, t->m->pre_w, Q, D, c.ln_eps, d_concept_tokens, s);
 }
 
 // ---- kernel taps for the tests -------------------------------------------------------------------------------------------------

@@ -82,7 +82,12 @@ def _check_grads(got, want, floor_keys=("hash_pe",), strict=()):
     print("worst relative L2 gradient error: %.3e (%s); worst sibling-scaled error among small tensors: %.3e (%s)" % (worst + worst_abs))
 
 
-def test_training_step_matches_the_reference_gradients():
+@pytest.mark.parametrize("chains", [1, 2])
+def test_training_step_matches_the_reference_gradients(chains, monkeypatch):
+    """chains = 2: the batch split into two micro-batch chains on two streams (the default above ~12k rows per chain, forced here
+    with CH_TRAIN_CHAIN_MIN_ROWS=1): own row regions, own weight-gradient scratch, gradient arenas added at the end."""
+    monkeypatch.setenv("CH_TRAIN_STREAMS", str(chains))
+    monkeypatch.setenv("CH_TRAIN_CHAIN_MIN_ROWS", "1")
     sd, z = load_fixture("train_tiny")
     model = _train_model(sd, z)
     crit = _crit()
@@ -141,6 +146,7 @@ def test_encoder_vjp_matches_the_oracle_on_other_shapes(name, batch, seed, monke
     from oracle import encoder_oracle as eo
     if name == "encode_n201":
         monkeypatch.setenv("CH_GEMM_PP_MIN_K", "256")
+    monkeypatch.setenv("CH_TRAIN_CHAIN_MIN_ROWS", "1")         # two chains (3 + 2 images, 2 + 1 images)
     sd, z = load_fixture(name)
     size = 224 if name == "encode_n201" else 64
     x = eo.synthetic_images(batch, size, seed=seed).to(torch.bfloat16).float()
@@ -181,7 +187,10 @@ def test_optimizer_steps_reduce_the_loss_and_reach_the_eval_path():
     assert float((codes1 - codes0).abs().max()) > 1e-2                            # the eval engine was rebuilt from the new weights
 
 
-def test_gradients_are_deterministic_run_to_run():
+@pytest.mark.parametrize("chains", [1, 2])
+def test_gradients_are_deterministic_run_to_run(chains, monkeypatch):
+    monkeypatch.setenv("CH_TRAIN_STREAMS", str(chains))
+    monkeypatch.setenv("CH_TRAIN_CHAIN_MIN_ROWS", "1")
     sd, z = load_fixture("train_tiny")
     model = _train_model(sd, z)
     crit = _crit()
@@ -236,9 +245,12 @@ def test_main_v2_exp_hashing_trains_end_to_end(tmp_path):
     assert abs(hist["mAP"] - te[0]["mAP"]) < 1e-12          # best.pth == the only evaluated epoch: same codes, same score
 
 
-def test_a_smaller_batch_after_a_larger_one_sees_no_stale_rows():
+@pytest.mark.parametrize("chains", [1, 2])
+def test_a_smaller_batch_after_a_larger_one_sees_no_stale_rows(chains, monkeypatch):
     """The trainer's buffers are sized for max_batch and reused: after a batch of 6, a batch of 4 must give exactly the gradients a
     fresh trainer gives for it (the weight-gradient kernel reads whole 32-row steps; rows past the batch must not contribute)."""
+    monkeypatch.setenv("CH_TRAIN_STREAMS", str(chains))
+    monkeypatch.setenv("CH_TRAIN_CHAIN_MIN_ROWS", "1")
     sd, z = load_fixture("train_tiny")
     x = fixture_images(z).cuda()
     crit = _crit()
