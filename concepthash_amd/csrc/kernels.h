@@ -221,6 +221,8 @@ int ch_adapter_grads(const float *G, const float *cu, const float *T, const floa
                      float *grads, float *ws /* >= 256 floats */, hipStream_t s);
 int ch_concept_rows_sum(const float *dH, int B, int ntok, int Q, int D, float *out, hipStream_t s);
 int ch_scatter_concept_rows(const float *dhf, int B, int ntok, int Q, int D, float *dH, bf16_t *dHb, hipStream_t s);
+// compact head rows [B*(1+Q), D] (CLS, concept tokens) -> full token rows [B*ntok, D], zeros elsewhere; fp32 (is_f32) or bf16
+int ch_expand_head_rows(const void *src, int is_f32, int B, int ntok, int Q, int D, void *dst, hipStream_t s);
 int ch_small_ln_bwd(const float *dy, const float *x, const float *gamma, int rows, int D, float eps, float *dx, hipStream_t s);
 int ch_gather_concept_rows(const float *H, int B, int ntok, int Q, int D, float *out, hipStream_t s);
 // qkv [B*ntok, 3D] (q | k | v), dO [B*ntok, D] -> dqkv [B*ntok, 3D]; head_dim 64

@@ -66,6 +66,12 @@ struct ch_trainer {
     std::vector<LayerT> lt;     // [L]
     std::vector<Saved> sv;      // [L]
     float *H = nullptr, *dH = nullptr, *ctx = nullptr;
+    // final-layer row pruning (as ch_encode): past the last attention only CLS + the Q concept tokens of
+    // every image are carried, forward and backward -- the loss reads nothing else, so every other row's gradient is zero there
+    bool prune_last = true;
+    int64_t hc_rows = 0;
+    float *Hc = nullptr, *dHc = nullptr;
+    bf16_t *dHcb = nullptr;
     bf16_t *dHb = nullptr, *dMb = nullptr, *tD = nullptr, *tD2 = nullptr, *tB = nullptr, *tM = nullptr, *tQKV = nullptr, *F1act = nullptr,
            *PATCH = nullptr, *XnDummy = nullptr;
     float *stDummy = nullptr;
@@ -128,10 +134,10 @@ struct GemmCall {
     int ld_hb = 0;              // 0 = D
     const bf16_t *aux = nullptr;
 };
-int gemm(ch_trainer *t, int chain, int rows, const GemmCall &g, hipStream_t s) {
+int gemm(ch_trainer *t, int chain, int rows, const GemmCall &g, hipStream_t s, int64_t x_rows_alloc = 0) {
     const int D = t->m->cfg.dim;
     GemmParams p{};
-    p.X = g.X; p.W = g.W; p.M = rows; p.N = g.N; p.K = g.K; p.X_rows_alloc = t->region_rows[chain];
+    p.X = g.X; p.W = g.W; p.M = rows; p.N = g.N; p.K = g.K; p.X_rows_alloc = x_rows_alloc ? x_rows_alloc : t->region_rows[chain];
     p.bias = g.bias; p.out_bf16 = g.out; p.ldo = g.ldo; p.resid = g.resid; p.ldr = D; p.scale_ptr = g.scale; p.addend = g.addend;
     p.ld_addend = D; p.stats_in = g.stats_in; p.fold_c = g.fold_c; p.ln_eps = g.eps; p.stats_out = g.stats_out; p.hb_out = g.hb_out;
     p.ld_hb = g.ld_hb ? g.ld_hb : D; p.aux = g.aux; p.pp_min_k = t->m->pp_min_k;
@@ -160,7 +166,7 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
     const int D = c.dim, M = c.ffn, ntok = m->ntok, np = m->np, bpad = m->bpad, Q = c.ncontext, L = c.layers;
     const int rows = B * ntok;
     const Rows R{t->row_off[ch], D, M, bpad};
-    float *H = R.d(t->H);
+    float *H = R.d(t->H);   // the residual stream; re-pointed at the compact copy past the last layer's attention
     bf16_t *PATCH = t->PATCH + t->prow_off[ch] * m->Kp;
     const size_t img_elems = (size_t)3 * c.image_size * c.image_size;
     const void *images = (const char *)images_all + (size_t)img0 * img_elems * (image_dtype == 0 ? 4 : 2);
@@ -177,6 +183,9 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
                                   R.d(t->XnDummy), s))
         return e;
     if (int e = ch_hb_stats(H, rows, D, R.d(t->sv[0].Xn1), R.st(t->sv[0].st1), s)) return e;
+    const int nq = 1 + Q;
+    float *Hc = t->Hc + (size_t)ch * t->hc_rows * D;
+    int cur = rows;          // rows carried: all tokens, or B * (1 + Q) past the last layer's attention
     for (int l = 0; l < L; ++l) {
         const LayerW &w = m->layers[l];
         Saved &v = t->sv[l];
@@ -185,10 +194,16 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
         g = GemmCall{3 * D, D, R.d(v.Xn1), w.qkv_wf, w.qkv_d, EPI_FOLD_BIAS};
         g.out = R.d3(v.QKV); g.ldo = 3 * D; g.stats_in = R.st(v.st1); g.fold_c = w.qkv_c; g.eps = c.ln_eps;
         if (int e = gemm(t, ch, rows, g, s)) return e;
-        if (int e = ch_attention(R.d3(v.QKV), B, ntok, c.heads, R.d(v.AO), s)) return e;
+        const bool pruned = t->prune_last && l == L - 1;
+        if (int e = ch_attention(R.d3(v.QKV), B, ntok, c.heads, R.d(v.AO), s, nullptr, Q, pruned)) return e;
+        if (pruned) {      // from here on every buffer of this layer holds B * (1 + Q) compact rows (CLS, then the concept tokens)
+            cur = B * nq;
+            if (int e = ch_gather_head_rows(H, B, ntok, Q, D, Hc, s)) return e;
+            H = Hc;
+        }
         g = GemmCall{D, D, R.d(v.AO), w.out_w, w.out_b, EPI_BIAS_STATS};
         g.out = R.d(v.A); g.ldo = D; g.stats_out = R.st(v.stA);
-        if (int e = gemm(t, ch, rows, g, s)) return e;
+        if (int e = gemm(t, ch, cur, g, s)) return e;
         for (int a = 0; a < 2; ++a) {
             const AdWork &aw = t->ad[l * 2 + a];
             const AdPtr ap = ad_ptrs(t->params + (int64_t)(l * 2 + a) * t->ad_numel, c);
@@ -198,7 +213,7 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
             // pre-activation kept for backward, nn.GELU() (models/layers/adapter.py:36) of it as the second output
             g = GemmCall{bpad, D, in, aw.down_wf, aw.fold_d, EPI_FOLD_ACT2_GELU};
             g.out = P; g.ldo = bpad; g.stats_in = stin; g.fold_c = aw.fold_c; g.eps = 1e-5f; g.hb_out = G; g.ld_hb = bpad;
-            if (int e = gemm(t, ch, rows, g, s)) return e;
+            if (int e = gemm(t, ch, cur, g, s)) return e;
             g = GemmCall{D, bpad, G, aw.up_w, ap.up_b, EPI_SCALE_RESID_STATS};
             g.resid = H; g.scale = ap.scale; g.addend = in;
             if (a == 0) {
@@ -207,20 +222,21 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
                 g.stats_out = R.st(l + 1 < L ? t->sv[l + 1].st1 : t->stDummy);
                 g.hb_out = R.d(l + 1 < L ? t->sv[l + 1].Xn1 : t->XnDummy);
             }
-            if (int e = gemm(t, ch, rows, g, s)) return e;
+            if (int e = gemm(t, ch, cur, g, s)) return e;
             if (a == 0) {  // MLP
                 g = GemmCall{M, D, R.d(v.Xn2), w.fc1_wf, w.fc1_d, c.act == 0 ? EPI_FOLD_ACT2_QUICK : EPI_FOLD_ACT2_GELU};
                 g.out = R.m(v.F1pre); g.ldo = M; g.stats_in = R.st(v.st2); g.fold_c = w.fc1_c; g.eps = c.ln_eps; g.hb_out = R.m(t->F1act); g.ld_hb = M;
-                if (int e = gemm(t, ch, rows, g, s)) return e;
+                if (int e = gemm(t, ch, cur, g, s)) return e;
                 g = GemmCall{D, M, R.m(t->F1act), w.fc2_w, w.fc2_b, EPI_BIAS_STATS};
                 g.out = R.d(v.A2); g.ldo = D; g.stats_out = R.st(v.stA2);
-                if (int e = gemm(t, ch, rows, g, s)) return e;
+                if (int e = gemm(t, ch, cur, g, s)) return e;
             }
         }
     }
-    if (int e = ch_gather_concept_rows(H, B, ntok, Q, D, out_hf_all + (size_t)img0 * Q * D, s)) return e;
+    const int tok_out = cur == rows ? ntok : nq;   // row layout of the final residual: all tokens, or (CLS, concept tokens) per image
+    if (int e = ch_gather_concept_rows(H, B, tok_out, Q, D, out_hf_all + (size_t)img0 * Q * D, s)) return e;
     if (out_cls_all) {  // CLS rows of the final residual (the pooled branch, models/arch/coop.py:484-499, is not part of the loss)
-        CH_CHECK_HIP(hipMemcpy2DAsync(out_cls_all + (size_t)img0 * D, sizeof(float) * D, H, sizeof(float) * (size_t)ntok * D, sizeof(float) * D, B,
+        CH_CHECK_HIP(hipMemcpy2DAsync(out_cls_all + (size_t)img0 * D, sizeof(float) * D, H, sizeof(float) * (size_t)tok_out * D, sizeof(float) * D, B,
                                       hipMemcpyDeviceToDevice, s));
     }
     return 0;
@@ -229,16 +245,23 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
 int backward_chain(ch_trainer *t, int ch, const float *dhf_all, int img0, int B, hipStream_t s) {
     ch_model *m = t->m;
     const ch_model_config &c = m->cfg;
-    const int D = c.dim, M = c.ffn, ntok = m->ntok, bpad = m->bpad, Q = c.ncontext, L = c.layers, b = c.adapter_dim;
+    const int D = c.dim, M = c.ffn, ntok = m->ntok, bpad = m->bpad, Q = c.ncontext, L = c.layers, b = c.adapter_dim, nq = 1 + Q;
     const int rows = B * ntok;
     const Rows R{t->row_off[ch], D, M, bpad};
     const float *zero = m->zero_bias;
-    float *dH = R.d(t->dH), *grads = ch == 0 ? t->grads : t->grads1;
-    bf16_t *dHb = R.d(t->dHb), *dMb = R.d(t->dMb), *tD = R.d(t->tD), *tD2 = R.d(t->tD2), *tB = R.b(t->tB), *tM = R.m(t->tM),
-           *tQKV = R.d3(t->tQKV);
+    float *grads = ch == 0 ? t->grads : t->grads1;
+    bf16_t *dMb = R.d(t->dMb), *tD = R.d(t->tD), *tD2 = R.d(t->tD2), *tB = R.b(t->tB), *tM = R.m(t->tM), *tQKV = R.d3(t->tQKV);
     const int64_t ralloc = t->region_rows[ch];
+    // gradient of the residual stream: fp32 + its bf16 copy.  Full token rows, or -- inside the pruned last layer -- the compact
+    // (CLS, concept tokens) rows of every image
+    float *dHfull = R.d(t->dH), *dHc = t->dHc + (size_t)ch * t->hc_rows * D;
+    bf16_t *dHbfull = R.d(t->dHb), *dHcb = t->dHcb + (size_t)ch * t->hc_rows * D;
+    const bool prune = t->prune_last;
+    float *dH = prune ? dHc : dHfull;
+    bf16_t *dHb = prune ? dHcb : dHbfull;
+    int cur = prune ? B * nq : rows;
     // the loss reads only hash_features = H[:, -Q:, :] (models/arch/coop.py:484-486): dH is zero elsewhere
-    if (int e = ch_scatter_concept_rows(dhf_all + (size_t)img0 * Q * D, B, ntok, Q, D, dH, dHb, s)) return e;
+    if (int e = ch_scatter_concept_rows(dhf_all + (size_t)img0 * Q * D, B, prune ? nq : ntok, Q, D, dH, dHb, s)) return e;
 
     // gradient of the block output arrives in dH / dHb; leaves d(branch input) = dH + adapter path in dMb (bf16 only)
     auto adapter_bwd = [&](int l, int a) -> int {
@@ -248,24 +271,25 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, int img0, int B,
         const AdPtr ap = ad_ptrs(pbase, c);
         const bf16_t *in = R.d(a == 0 ? v.A : v.A2), *P = R.b(a == 0 ? v.P1 : v.P2), *G = R.b(a == 0 ? v.G1 : v.G2);
         const float *stin = R.st(a == 0 ? v.stA : v.stA2);
+        const int64_t dalloc = dHb == dHcb ? t->hc_rows : ralloc;
         // up projection: weight-gradient products (unscaled) and dgrad
-        if (int e = ch_wgrad_tn(dHb, D, G, bpad, rows, ralloc, D, bpad, t->G[ch], t->ws_wgrad[ch], s)) return e;
+        if (int e = ch_wgrad_tn(dHb, D, G, bpad, cur, dalloc, D, bpad, t->G[ch], t->ws_wgrad[ch], s)) return e;
         // of the fp32 gradient: a bias gradient is a sum over rows that largely cancels, the bf16 copy costs 1e-1 relative there
-        if (int e = ch_colsum(dH, 1, D, rows, D, t->cu[ch], t->ws_colsum[ch], s)) return e;
+        if (int e = ch_colsum(dH, 1, D, cur, D, t->cu[ch], t->ws_colsum[ch], s)) return e;
         GemmCall g{bpad, D, dHb, aw.up_wT, zero, EPI_BIAS_DACT_GELU};   // dpre = s (dH W_up) o gelu'(pre), in the epilogue
         g.out = tB; g.ldo = bpad; g.aux = P; g.scale = ap.scale;
-        if (int e = gemm(t, ch, rows, g, s)) return e;
+        if (int e = gemm(t, ch, cur, g, s, dalloc)) return e;
         // down projection + adapter LayerNorm
-        if (int e = ch_normalize_bf16(in, stin, rows, D, 1e-5f, tD2, s)) return e;
-        if (int e = ch_wgrad_tn(tB, bpad, tD2, D, rows, ralloc, bpad, D, t->T[ch], t->ws_wgrad[ch], s)) return e;
-        if (int e = ch_colsum(tB, 0, bpad, rows, bpad, t->cd[ch], t->ws_colsum[ch], s)) return e;
+        if (int e = ch_normalize_bf16(in, stin, cur, D, 1e-5f, tD2, s)) return e;
+        if (int e = ch_wgrad_tn(tB, bpad, tD2, D, cur, ralloc, bpad, D, t->T[ch], t->ws_wgrad[ch], s)) return e;
+        if (int e = ch_colsum(tB, 0, bpad, cur, bpad, t->cd[ch], t->ws_colsum[ch], s)) return e;
         if (int e = ch_adapter_grads(t->G[ch], t->cu[ch], t->T[ch], t->cd[ch], pbase, D, b, bpad, grads + (int64_t)(l * 2 + a) * t->ad_numel,
                                      t->ws_colsum[ch], s))
             return e;
         g = GemmCall{D, bpad, tB, aw.down_wgT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;
-        if (int e = gemm(t, ch, rows, g, s)) return e;
-        return ch_ln_bwd(tD, in, stin, rows, D, 1e-5f, dH, nullptr, dMb, s);
+        if (int e = gemm(t, ch, cur, g, s)) return e;
+        return ch_ln_bwd(tD, in, stin, cur, D, 1e-5f, dH, nullptr, dMb, s);
     };
 
     for (int l = L - 1; l >= 0; --l) {
@@ -275,21 +299,32 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, int img0, int B,
         if (int e = adapter_bwd(l, 1)) return e;
         GemmCall g{M, D, dMb, x.fc2_wT, zero, c.act == 0 ? EPI_BIAS_DACT_QUICK : EPI_BIAS_DACT_GELU};
         g.out = tM; g.ldo = M; g.aux = R.m(v.F1pre);
-        if (int e = gemm(t, ch, rows, g, s)) return e;
+        if (int e = gemm(t, ch, cur, g, s)) return e;
         g = GemmCall{D, M, tM, x.fc1_wgT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;
-        if (int e = gemm(t, ch, rows, g, s)) return e;
-        if (int e = ch_ln_bwd(tD, R.d(v.Xn2), R.st(v.st2), rows, D, c.ln_eps, dH, dH, dHb, s)) return e;
+        if (int e = gemm(t, ch, cur, g, s)) return e;
+        if (int e = ch_ln_bwd(tD, R.d(v.Xn2), R.st(v.st2), cur, D, c.ln_eps, dH, dH, dHb, s)) return e;
         // ---- x_mid = x_in + a + adapter_1(a),  a = out_proj(attention(qkv(LN1(x_in))))
         if (int e = adapter_bwd(l, 0)) return e;
         g = GemmCall{D, D, dMb, x.out_wT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;
-        if (int e = gemm(t, ch, rows, g, s)) return e;
-        if (int e = ch_attention_bwd(R.d3(v.QKV), tD, B, ntok, c.heads, tQKV, s)) return e;
+        if (int e = gemm(t, ch, cur, g, s)) return e;
+        const bf16_t *dctx = tD;
+        if (cur != rows) {
+            // leaving the pruned part of the last layer: the compact gradients go back to their token rows (zeros elsewhere) --
+            // attention's keys / values cover every token, so from here on all rows carry gradient
+            if (int e = ch_expand_head_rows(tD, 0, B, ntok, Q, D, tD2, s)) return e;
+            if (int e = ch_expand_head_rows(dH, 1, B, ntok, Q, D, dHfull, s)) return e;
+            dctx = tD2;
+            dH = dHfull;
+            dHb = dHbfull;
+            cur = rows;
+        }
+        if (int e = ch_attention_bwd(R.d3(v.QKV), dctx, B, ntok, c.heads, tQKV, s)) return e;
         g = GemmCall{D, 3 * D, tQKV, x.qkv_wgT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;
-        if (int e = gemm(t, ch, rows, g, s)) return e;
-        if (int e = ch_ln_bwd(tD, R.d(v.Xn1), R.st(v.st1), rows, D, c.ln_eps, dH, dH, dHb, s)) return e;
+        if (int e = gemm(t, ch, cur, g, s)) return e;
+        if (int e = ch_ln_bwd(tD, R.d(v.Xn1), R.st(v.st1), cur, D, c.ln_eps, dH, dH, dHb, s)) return e;
     }
     // ---- concept tokens: rows ntok-Q.. of every image are pre_layrnorm(ctx[q]) (models/arch/coop.py:470-472)
     return ch_concept_rows_sum(dH, B, ntok, Q, D, t->dctx_sum[ch], s);
@@ -344,6 +379,7 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
     t->ad_numel = adapter_numel(c);
     if (const char *e = getenv("CH_TRAIN_STREAMS")) t->nchains = std::max(1, std::min(atoi(e), TR_CHAINS));
     if (const char *e = getenv("CH_TRAIN_CHAIN_MIN_ROWS")) t->chain_min_rows = std::max(1, atoi(e));
+    if (const char *e = getenv("CH_TRAIN_PRUNE_LAST")) t->prune_last = atoi(e) != 0;
     const int D = c.dim, L = c.layers, M = c.ffn, bpad = m->bpad, Q = c.ncontext;
     // region 0 holds a whole batch (one chain) or the first half (two chains); region 1 the second half
     const int half = (max_batch + 1) / 2;
@@ -402,6 +438,10 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
     t->stDummy = st();
     t->PATCH = (bf16_t *)talloc(t, sizeof(bf16_t) * prows * m->Kp, ok);
     t->ctx = (float *)talloc(t, sizeof(float) * Q * D, ok);
+    t->hc_rows = round_up64((int64_t)max_batch * (1 + Q), 256) + 256;
+    t->Hc = (float *)talloc(t, sizeof(float) * t->hc_rows * TR_CHAINS * D, ok);
+    t->dHc = (float *)talloc(t, sizeof(float) * t->hc_rows * TR_CHAINS * D, ok);
+    t->dHcb = (bf16_t *)talloc(t, sizeof(bf16_t) * t->hc_rows * TR_CHAINS * D, ok);
     const int64_t max_rows = (int64_t)max_batch * m->ntok;
     for (int ch = 0; ch < t->nchains; ++ch) {
         t->ws_wgrad[ch] = (float *)talloc(t, sizeof(float) * std::max(ch_wgrad_ws_floats(max_rows, D, bpad), ch_wgrad_ws_floats(max_rows, bpad, D)), ok);

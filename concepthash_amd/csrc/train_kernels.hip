@@ -462,6 +462,14 @@ __global__ __launch_bounds__(256) void scatter_concept_rows_kernel(const float *
         dHb[row * D + k] = f2bf(v);
     }
 }
+// compact head rows [B * (1 + Q), D] (slot 0 = CLS, slots 1.. = the concept tokens) -> full token rows [B * ntok, D], zero elsewhere
+template <typename T>
+__global__ __launch_bounds__(256) void expand_head_rows_kernel(const T *__restrict__ src, int ntok, int Q, int D, T *__restrict__ dst) {
+    const int64_t row = blockIdx.x;
+    const int t = (int)(row % ntok), bimg = (int)(row / ntok);
+    const int slot = t == 0 ? 0 : (t >= ntok - Q ? 1 + t - (ntok - Q) : -1);
+    for (int k = threadIdx.x; k < D; k += 256) dst[row * D + k] = slot >= 0 ? src[((size_t)bimg * (1 + Q) + slot) * D + k] : (T)0;
+}
 // LayerNorm backward of fp32 rows (the pre_layrnorm of the concept-token rows): dx = rstd * (dy*g - mean(dy*g) - x_hat * mean(dy*g*x_hat))
 __global__ __launch_bounds__(256) void small_ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                            const float *__restrict__ gamma, int D, float eps, float *__restrict__ dx) {
@@ -628,6 +636,15 @@ int ch_concept_rows_sum(const float *dH, int B, int ntok, int Q, int D, float *o
 }
 int ch_scatter_concept_rows(const float *dhf, int B, int ntok, int Q, int D, float *dH, bf16_t *dHb, hipStream_t s) {
     hipLaunchKernelGGL(scatter_concept_rows_kernel, dim3((unsigned)((int64_t)B * ntok)), dim3(256), 0, s, dhf, B, ntok, Q, D, dH, dHb);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+int ch_expand_head_rows(const void *src, int is_f32, int B, int ntok, int Q, int D, void *dst, hipStream_t s) {
+    if (is_f32)
+        hipLaunchKernelGGL(expand_head_rows_kernel<float>, dim3((unsigned)((int64_t)B * ntok)), dim3(256), 0, s, (const float *)src, ntok, Q, D, (float *)dst);
+    else
+        hipLaunchKernelGGL(expand_head_rows_kernel<bf16_t>, dim3((unsigned)((int64_t)B * ntok)), dim3(256), 0, s, (const bf16_t *)src, ntok, Q, D,
+                           (bf16_t *)dst);
     CH_LAUNCH_CHECK();
     return 0;
 }

@@ -139,14 +139,17 @@ def test_encoder_vjp_with_an_exact_gelu_backbone():
     _vjp_against_oracle(sd, z, x, cot, act="gelu")
 
 
+@pytest.mark.parametrize("prune", [1, 0])
 @pytest.mark.parametrize("name,batch,seed", [("encode_hd64", 5, 3), ("encode_n201", 3, 4)])
-def test_encoder_vjp_matches_the_oracle_on_other_shapes(name, batch, seed, monkeypatch):
+def test_encoder_vjp_matches_the_oracle_on_other_shapes(name, batch, seed, prune, monkeypatch):
     """encode_hd64: 21 tokens; encode_n201: 201 tokens, D = 256 (the sequence length of the real configs: masked key tail of the
     attention backward, the 256x256 GEMM for the dgrad products with CH_GEMM_PP_MIN_K = 256).  Random cotangent per row."""
     from oracle import encoder_oracle as eo
     if name == "encode_n201":
         monkeypatch.setenv("CH_GEMM_PP_MIN_K", "256")
+    monkeypatch.setenv("CH_TRAIN_STREAMS", "2")
     monkeypatch.setenv("CH_TRAIN_CHAIN_MIN_ROWS", "1")         # two chains (3 + 2 images, 2 + 1 images)
+    monkeypatch.setenv("CH_TRAIN_PRUNE_LAST", str(prune))      # 1 (default): the last layer past its attention on (CLS, concept) rows only
     sd, z = load_fixture(name)
     size = 224 if name == "encode_n201" else 64
     x = eo.synthetic_images(batch, size, seed=seed).to(torch.bfloat16).float()
