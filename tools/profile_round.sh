@@ -18,7 +18,10 @@ rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES GRBM_GU
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ham_trace -o ham -- python3 $R/tools/hamming_scan_bench.py --mode both --reps 3 > $O/ham_1m_timing.txt 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS --output-format csv -d $O/ham_pmc -o ham -- python3 $R/tools/hamming_scan_bench.py --mode both --reps 1 > /dev/null 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ham_nab -o ham -- python3 $R/tools/hamming_scan_bench.py --mode both --queries 24633 --rows 23929 --nbit 64 --classes 555 --reps 3 > $O/ham_nabirds_timing.txt 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -o tr -- python3 $R/tools/train_bench.py --batches 256 --steps 5 --warmup 2 > $O/train_trace.json 2> $O/train_trace.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace32 -o tr -- python3 $R/tools/train_bench.py --batches 32 --steps 20 --warmup 5 > $O/train_trace32.json 2> $O/train_trace32.err || exit 1
 cd $R
+python tools/train_bench.py > $O/train_bench.txt 2>&1
 python tools/make_traffic_json.py $O/enc_fetch/enc_counter_collection.csv $O/enc_write/enc_counter_collection.csv $O/gemm_traffic.json
 python tools/pmc_summary.py $O/enc_mfma/enc_counter_collection.csv > $O/enc_mfma_summary.txt
 python tools/pmc_summary.py $O/enc_lds/enc_counter_collection.csv > $O/enc_lds_summary.txt
