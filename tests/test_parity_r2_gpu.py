@@ -46,9 +46,10 @@ def _encoder(sd, heads, **kw):
 @pytest.mark.parametrize("pp_min_k", [None, 256])
 def test_reference_golden_at_201_tokens(dev, monkeypatch, pp_min_k):
     """tests/golden/encode_n201.npz = the reference's LGHWithFixedPrompt (models/arch/coop.py:524-598) at image 224 /
-    patch 16, D = 256, 4 heads, 2 layers, bf16-representable weights and images.  Default dispatch: patch-embed and fc2 on
-    the 256x256 ping-pong kernel, the K = 256 GEMMs on the 128x128 kernel; CH_GEMM_PP_MIN_K=256: every GEMM of the chain on
-    the ping-pong kernel (qkv / fc1 / down with the LN-fold epilogues, up with the residual + statistics epilogue)."""
+    patch 16, D = 256, 4 heads, 2 layers, bf16-representable weights and images.  Default dispatch: 402 rows are a small
+    grid (fewer than 128 tiles of 256x256), so every GEMM runs on the 128x128 kernel; CH_GEMM_PP_MIN_K=256 pins the choice by K
+    alone: every GEMM of the chain on the ping-pong kernel (qkv / fc1 / down with the LN-fold epilogues, up with the residual +
+    statistics epilogue)."""
     from concepthash_amd import _lib
     sd, z = load_fixture("encode_n201")
     heads = int(z["meta/heads"])
@@ -68,7 +69,7 @@ def test_reference_golden_at_201_tokens(dev, monkeypatch, pp_min_k):
     if pp_min_k:
         assert n_small == 0                      # the whole chain ran on the ping-pong kernel
     else:
-        assert n_pp == 1 + 2 and n_small == 14   # patch (K = 768) + fc2 (K = 512) of both layers
+        assert n_pp == 0 and n_small == 17       # small grid: the dispatcher prefers 128x128 tiles (gemm_bf16.hip)
     for key, tol in (("codes", 2e-2), ("hash_features", 2e-2), ("logits_cont", 2e-2), ("logits_bin", 3e-2),
                      ("logits_concept", 2e-2), ("image_features", 2e-2)):
         got, ref = out[key].cpu(), torch.from_numpy(z["out/" + key])
