@@ -219,6 +219,9 @@ int ch_transpose_bf16(const bf16_t *src, int R, int C, int ld_src, bf16_t *dst, 
 // params / grads: one adapter's block of the arena ([ln_w D][ln_b D][down_w b*D][down_b b][up_w D*b][up_b D][scale 1])
 int ch_adapter_grads(const float *G, const float *cu, const float *T, const float *cd, const float *params, int D, int b, int bpad,
                      float *grads, float *ws /* >= 256 floats */, hipStream_t s);
+// bf16 / LayerNorm-folded / transposed working copies of `nad` adapters from the parameter arena (slot arrays, one slot per adapter)
+int ch_adapter_refresh(const float *params, int64_t stride, int nad, int D, int b, int bpad, bf16_t *down_wf, float *fold_c, float *fold_d,
+                       bf16_t *up_w, bf16_t *up_wT, bf16_t *down_wgT, hipStream_t s);
 int ch_concept_rows_sum(const float *dH, int B, int ntok, int Q, int D, float *out, hipStream_t s);
 int ch_scatter_concept_rows(const float *dhf, int B, int ntok, int Q, int D, float *dH, bf16_t *dHb, hipStream_t s);
 // compact head rows [B*(1+Q), D] (CLS, concept tokens) -> full token rows [B*ntok, D], zeros elsewhere; fp32 (is_f32) or bf16

@@ -348,19 +348,10 @@ extern "C" void ch_trainer_destroy(ch_trainer *t) {
 
 extern "C" int ch_trainer_refresh(ch_trainer *t, void *stream) {
     CH_REQUIRE(t != nullptr, "null trainer");
-    hipStream_t s = (hipStream_t)stream;
     const ch_model_config &c = t->m->cfg;
-    const int D = c.dim, b = c.adapter_dim, bpad = t->m->bpad;
-    for (int l = 0; l < c.layers; ++l)
-        for (int a = 0; a < 2; ++a) {
-            AdWork &w = t->ad[l * 2 + a];
-            const AdPtr p = ad_ptrs(t->params + (int64_t)(l * 2 + a) * t->ad_numel, c);
-            if (int e = ch_fold_ln(p.down_w, p.down_b, p.ln_w, p.ln_b, b, bpad, D, w.down_wf, w.fold_c, w.fold_d, s)) return e;
-            if (int e = ch_convert_bf16(p.up_w, D, b, bpad, w.up_w, s)) return e;
-            if (int e = ch_transpose_f32_to_bf16(p.up_w, D, b, b, nullptr, w.up_wT, D, s)) return e;          // [b (pad bpad), D]
-            if (int e = ch_transpose_f32_to_bf16(p.down_w, b, D, D, p.ln_w, w.down_wgT, bpad, s)) return e;  // [D, bpad]
-        }
-    return 0;
+    const AdWork &w = t->ad[0];   // slot 0 of the contiguous per-field arrays
+    return ch_adapter_refresh(t->params, t->ad_numel, c.layers * 2, c.dim, c.adapter_dim, t->m->bpad, w.down_wf, w.fold_c, w.fold_d, w.up_w,
+                              w.up_wT, w.down_wgT, (hipStream_t)stream);
 }
 
 extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, float *grads, ch_trainer **out) {
@@ -402,14 +393,17 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
     t->ad.resize(L * 2);
     t->lt.resize(L);
     t->sv.resize(L);
-    for (int i = 0; i < L * 2 && ok; ++i) {
-        AdWork &w = t->ad[i];
-        w.down_wf = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)bpad * D, ok);
-        w.fold_c = (float *)talloc(t, sizeof(float) * bpad, ok);
-        w.fold_d = (float *)talloc(t, sizeof(float) * bpad, ok);
-        w.up_w = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)D * bpad, ok);
-        w.up_wT = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)bpad * D, ok);
-        w.down_wgT = (bf16_t *)talloc(t, sizeof(bf16_t) * (size_t)D * bpad, ok);
+    {   // one contiguous array per field, one slot per adapter (ch_adapter_refresh fills all slots in one launch per field);
+        // zero-initialised: the padding rows / columns (bottleneck b -> bpad) are never written again
+        const size_t nad = (size_t)L * 2, mat = (size_t)bpad * D;
+        bf16_t *dwf = (bf16_t *)talloc(t, sizeof(bf16_t) * nad * mat, ok), *uw = (bf16_t *)talloc(t, sizeof(bf16_t) * nad * mat, ok),
+               *uwT = (bf16_t *)talloc(t, sizeof(bf16_t) * nad * mat, ok), *dwT = (bf16_t *)talloc(t, sizeof(bf16_t) * nad * mat, ok);
+        float *fc = (float *)talloc(t, sizeof(float) * nad * bpad, ok), *fd = (float *)talloc(t, sizeof(float) * nad * bpad, ok);
+        for (size_t i = 0; i < nad && ok; ++i) {
+            AdWork &w = t->ad[i];
+            w.down_wf = dwf + i * mat; w.up_w = uw + i * mat; w.up_wT = uwT + i * mat; w.down_wgT = dwT + i * mat;
+            w.fold_c = fc + i * bpad; w.fold_d = fd + i * bpad;
+        }
     }
     hipStream_t s = nullptr;
     for (int l = 0; l < L && ok; ++l) {

@@ -355,6 +355,68 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T *__restrict__ sr
     }
 }
 
+// ---- working copies of ALL adapters from the parameter arena in four launches (blockIdx.y = adapter): the per-adapter form
+// (fold_ln + convert + two transposes, 96 launches for B/16) was 0.5 ms of every optimizer step.
+// Arena block of one adapter: [ln_w D][ln_b D][down_w b*D][down_b b][up_w D*b][up_b D][scale 1], `stride` floats apart.
+// (1) LayerNorm fold of the down projection: Wdf = bf16(W * gamma) [bpad, D] (rows >= b zero), c[n] = sum_k Wdf[n][k], d[n] = b[n] + sum_k W[n][k] beta[k]
+__global__ __launch_bounds__(256) void refresh_fold_kernel(const float *__restrict__ P, int64_t stride, int D, int b, int bpad,
+                                                           bf16_t *__restrict__ Wdf, float *__restrict__ c, float *__restrict__ d) {
+    const float *base = P + blockIdx.y * stride, *gamma = base, *beta = base + D, *W = base + 2 * D, *bd = W + (size_t)b * D;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= bpad) return;
+    bf16_t *out = Wdf + ((size_t)blockIdx.y * bpad + n) * D;
+    float cs = 0.f, ds = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const float w = n < b ? W[(size_t)n * D + k] : 0.f;
+        const bf16_t wb = f2bf(w * gamma[k]);
+        out[k] = wb;
+        cs += bf2f(wb);
+        ds += beta[k] * w;
+    }
+    cs = wave_sum(cs);
+    ds = wave_sum(ds);
+    if (lane == 0) {
+        c[(size_t)blockIdx.y * bpad + n] = cs;
+        d[(size_t)blockIdx.y * bpad + n] = ds + (n < b ? bd[n] : 0.f);
+    }
+}
+// (2) up_w [D, b] fp32 -> bf16 [D, bpad] (columns >= b zero)
+__global__ __launch_bounds__(256) void refresh_convert_kernel(const float *__restrict__ P, int64_t stride, int D, int b, int bpad,
+                                                              bf16_t *__restrict__ out) {
+    const float *up_w = P + blockIdx.y * stride + 2 * D + (size_t)b * D + b;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D * bpad) return;
+    const int r = i / bpad, cc = i - r * bpad;
+    out[(size_t)blockIdx.y * D * bpad + i] = cc < b ? f2bf(up_w[(size_t)r * b + cc]) : (bf16_t)0;
+}
+// (3, 4) transposes through LDS: which = 0: up_w [D, b] -> up_wT [bpad, D] (rows >= b stay zero); which = 1: down_w [b, D] * gamma ->
+// down_wgT [D, bpad] (columns >= b stay zero)
+__global__ __launch_bounds__(256) void refresh_transpose_kernel(const float *__restrict__ P, int64_t stride, int D, int b, int bpad, int which,
+                                                                bf16_t *__restrict__ dst_all) {
+    __shared__ float tile[32][33];
+    const float *base = P + blockIdx.z * stride;
+    const float *src = which == 0 ? base + 2 * D + (size_t)b * D + b : base + 2 * D;
+    const float *colscale = which == 0 ? nullptr : base;
+    const int R = which == 0 ? D : b, C = which == 0 ? b : D, ld_src = C, ld_dst = which == 0 ? D : bpad;
+    bf16_t *dst = dst_all + (size_t)blockIdx.z * bpad * D;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, cc = c0 + tx;
+        float v = 0.f;
+        if (r < R && cc < C) {
+            v = src[(size_t)r * ld_src + cc];
+            if (colscale) v *= colscale[cc];
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int cc = c0 + j, r = r0 + tx;
+        if (cc < C && r < R) dst[(size_t)cc * ld_dst + r] = f2bf(tile[tx][j]);
+    }
+}
+
 // ---- gradients of one adapter's parameters (models/layers/adapter.py:46-60) from the two weight-gradient products -------------
 //   G [D, bpad]  = dH^T g            (dH: gradient of the block output, g = GELU(down(LN(a))); unscaled)
 //   cu [D]       = column sums of dH
@@ -618,6 +680,20 @@ int ch_transpose_f32_to_bf16(const float *src, int R, int C, int ld_src, const f
 int ch_transpose_bf16(const bf16_t *src, int R, int C, int ld_src, bf16_t *dst, int ld_dst, hipStream_t s) {
     hipLaunchKernelGGL(transpose_kernel<bf16_t>, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, R, C, ld_src,
                        (const float *)nullptr, dst, ld_dst);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+// working copies of `nad` adapters (contiguous arrays, one slot per adapter): down_wf [bpad, D], fold_c / fold_d [bpad], up_w [D, bpad],
+// up_wT [bpad, D], down_wgT [D, bpad]
+int ch_adapter_refresh(const float *params, int64_t stride, int nad, int D, int b, int bpad, bf16_t *down_wf, float *fold_c, float *fold_d,
+                       bf16_t *up_w, bf16_t *up_wT, bf16_t *down_wgT, hipStream_t s) {
+    hipLaunchKernelGGL(refresh_fold_kernel, dim3((bpad + 3) / 4, nad), dim3(256), 0, s, params, stride, D, b, bpad, down_wf, fold_c, fold_d);
+    CH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(refresh_convert_kernel, dim3((D * bpad + 255) / 256, nad), dim3(256), 0, s, params, stride, D, b, bpad, up_w);
+    CH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(refresh_transpose_kernel, dim3((b + 31) / 32, (D + 31) / 32, nad), dim3(256), 0, s, params, stride, D, b, bpad, 0, up_wT);
+    CH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(refresh_transpose_kernel, dim3((D + 31) / 32, (b + 31) / 32, nad), dim3(256), 0, s, params, stride, D, b, bpad, 1, down_wgT);
     CH_LAUNCH_CHECK();
     return 0;
 }
