@@ -75,6 +75,7 @@ class TrainEngine:
         # makes autograd call EncoderFunction.backward (which produces the adapters' gradients) even when nothing upstream of the
         # concept tokens requires a gradient
         self.anchor = torch.zeros((), device=self.device, requires_grad=True)
+        self.generation = 0          # forwards so far: the saved activations belong to the LAST one only
 
     def close(self):
         if getattr(self, "_t", None) is not None and self._t.value:
@@ -128,6 +129,7 @@ class TrainEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ch_train_forward(self._t, _lib.ptr(images), 0 if images.dtype == torch.float32 else 1, B,
                                                  _lib.ptr(ct), _lib.ptr(hf), _lib.ptr(cls), _lib.stream_ptr()), "ch_train_forward")
+        self.generation += 1
         return hf, cls
 
     def backward(self, d_hash_features: torch.Tensor) -> torch.Tensor:
@@ -149,11 +151,15 @@ class EncoderFunction(torch.autograd.Function):
     def forward(ctx, concept_tokens, images, engine: TrainEngine, anchor):
         hf, _ = engine.forward(images, concept_tokens)
         ctx.engine = engine
+        ctx.generation = engine.generation
         ctx.ct_shape = concept_tokens.shape
         return hf
 
     @staticmethod
     def backward(ctx, d_hf):
+        if ctx.generation != ctx.engine.generation:
+            raise RuntimeError("EncoderFunction.backward: another training forward ran on this engine since this graph was built; the "
+                               "library keeps the saved activations of the last forward only (one forward -> one backward)")
         dct = ctx.engine.backward(d_hf)
         return dct.view(ctx.ct_shape), None, None, None
 

@@ -272,3 +272,15 @@ def test_a_smaller_batch_after_a_larger_one_sees_no_stale_rows(chains, monkeypat
     fresh.train_max_batch = 6
     g_fresh = grads_of(fresh, 4)
     assert torch.equal(g_used, g_fresh)
+
+
+def test_backward_of_a_stale_graph_is_refused():
+    """The library keeps the saved activations of the LAST training forward only: backpropagating an older graph must raise, not
+    silently use the newer forward's activations."""
+    sd, z = load_fixture("train_tiny")
+    model = _train_model(sd, z)
+    x = fixture_images(z).cuda()
+    first = model(x[:3])[1]["hash_features"].sum()
+    model(x[3:])[1]["hash_features"].sum().backward()          # a second forward + its own backward: fine
+    with pytest.raises(RuntimeError, match="one forward -> one backward"):
+        first.backward()
