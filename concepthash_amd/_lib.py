@@ -75,9 +75,9 @@ SIGNATURES = {
     "ch_trainer_destroy": (None, [c_void_p]),
     "ch_trainer_bytes": (c_int64, [c_void_p]),
     "ch_trainer_refresh": (c_int, [c_void_p, c_void_p]),
-    "ch_train_forward": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ch_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ch_debug_attention_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "ch_train_forward": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_debug_attention_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "ch_debug_wgrad": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ch_debug_ln_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_debug_act": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),

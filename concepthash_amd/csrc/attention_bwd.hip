@@ -26,9 +26,13 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s lds_v4s;
 
-template <int KB>
+// EXT: an extra cotangent on the probabilities themselves -- dpext [B, heads, ncon, ntok - ncon - 1] fp32, the gradient of the
+// concept-token attention rows the forward can tap (attention.hip TAP; consumer: the attention-diversity term of the loss,
+// models/loss/coop.py:164-189) -- is added to dP = dO V^T on those (query, key) pairs, in both phases.
+template <int KB, bool EXT>
 __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dO, int ntok,
-                                                               int heads, float scale_log2e, bf16_t *__restrict__ dqkv) {
+                                                               int heads, float scale_log2e, bf16_t *__restrict__ dqkv,
+                                                               const float *__restrict__ dpext, int ncon) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = KB * 2;   // 16-row tiles
     constexpr int KP = KB * 32;  // padded rows (keys and queries)
@@ -62,6 +66,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__
 
     const int fr = lane & 15, fq = lane >> 4;
     const int QT = (ntok + 15) >> 4;  // tiles holding at least one valid row
+    const int npatch = ntok - ncon - 1, q_con0 = ntok - ncon;   // EXT: keys 1 .. npatch, queries q_con0 .. ntok - 1
+    const float *ext = EXT ? dpext + (size_t)blockIdx.x * ncon * npatch : nullptr;
     // b128 fragment of row (tile*16 + fr): d = 8*fq .. +8 (off0) and 32 + 8*fq .. (off1)
     const int off0 = fr * 128 + ((fq ^ (fr & 7)) << 4), off1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
     // transpose read: lane 4*tq + tp of group fq addresses row 4*fq + tq of a 16-row tile, features 4*tp.. of feature tile dt
@@ -89,6 +95,18 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, gf1, c, 0, 0, 0);
             st[kt] = a;   // S^T[key = kt*16 + 4*fq + r][query fr]
             dp[kt] = c;   // dP^T, same layout
+        }
+        if constexpr (EXT) {
+            if (qt * 16 + 15 >= q_con0 && q >= q_con0 && qvalid) {
+                const float *row = ext + (size_t)(q - q_con0) * npatch;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + fq * 4 + r;
+                        if (key >= 1 && key <= npatch) dp[kt][r] += row[key - 1];
+                    }
+            }
         }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -177,6 +195,15 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__
             s4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf1, k1, s4, 0, 0, 0);
             d4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf0, v0, d4, 0, 0, 0);  // dP, same layout
             d4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf1, v1, d4, 0, 0, 0);
+            if constexpr (EXT) {
+                if (qt * 16 + 15 >= q_con0 && key >= 1 && key <= npatch) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qq = qt * 16 + fq * 4 + r;
+                        if (qq >= q_con0 && qq < ntok) d4[r] += ext[(size_t)(qq - q_con0) * npatch + key - 1];
+                    }
+                }
+            }
             float p[4], ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -217,35 +244,44 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__
     }
 }
 
-template <int KB>
-int launch_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s) {
+template <int KB, bool EXT>
+int launch_bwd_inst(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, const float *dpext, int ncon, hipStream_t s) {
     constexpr int KP = KB * 32;
     const size_t lds = (size_t)KP * 128 * 4 + (size_t)KP * 16;
     CH_REQUIRE(lds <= 160 * 1024, "attention backward: sequence too long for the LDS-resident kernel");
     static ch_once_per_device lds_once;
-    if (int e = ch_func_max_lds((const void *)attention_bwd_kernel<KB>, (int)lds, lds_once)) return e;
+    if (int e = ch_func_max_lds((const void *)attention_bwd_kernel<KB, EXT>, (int)lds, lds_once)) return e;
     const float scale_log2e = 0.125f * 1.4426950408889634f;
-    hipLaunchKernelGGL((attention_bwd_kernel<KB>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, dO, ntok, heads, scale_log2e, dqkv);
+    hipLaunchKernelGGL((attention_bwd_kernel<KB, EXT>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, dO, ntok, heads, scale_log2e, dqkv, dpext,
+                       ncon);
     CH_LAUNCH_CHECK();
     return 0;
+}
+template <int KB>
+int launch_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, const float *dpext, int ncon, hipStream_t s) {
+    return dpext ? launch_bwd_inst<KB, true>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s)
+                 : launch_bwd_inst<KB, false>(qkv, dO, B, ntok, heads, dqkv, nullptr, 0, s);
 }
 
 }  // namespace
 
 // qkv [B*ntok, 3D] bf16 (q | k | v), dO [B*ntok, D] bf16 -> dqkv [B*ntok, 3D] bf16 (dq | dk | dv); head_dim 64
-int ch_attention_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s) {
+// dpext (optional): [B, heads, ncon, ntok - ncon - 1] fp32 cotangent of the concept tokens' attention rows over the patch tokens
+int ch_attention_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s, const float *dpext,
+                     int ncon) {
     CH_REQUIRE(B > 0 && ntok > 0 && heads > 0, "attention backward: empty problem");
+    CH_REQUIRE(!dpext || (ncon >= 1 && ncon < ntok - 1), "attention backward: the probability cotangent needs 1 <= ncon < ntok - 1");
     const int KB = (ntok + 31) / 32;
     switch (KB) {
-        case 1: return launch_bwd<1>(qkv, dO, B, ntok, heads, dqkv, s);
-        case 2: return launch_bwd<2>(qkv, dO, B, ntok, heads, dqkv, s);
-        case 3: return launch_bwd<3>(qkv, dO, B, ntok, heads, dqkv, s);
-        case 4: return launch_bwd<4>(qkv, dO, B, ntok, heads, dqkv, s);
-        case 5: return launch_bwd<5>(qkv, dO, B, ntok, heads, dqkv, s);
-        case 6: return launch_bwd<6>(qkv, dO, B, ntok, heads, dqkv, s);
-        case 7: return launch_bwd<7>(qkv, dO, B, ntok, heads, dqkv, s);
-        case 8: return launch_bwd<8>(qkv, dO, B, ntok, heads, dqkv, s);
-        case 9: return launch_bwd<9>(qkv, dO, B, ntok, heads, dqkv, s);
+        case 1: return launch_bwd<1>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 2: return launch_bwd<2>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 3: return launch_bwd<3>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 4: return launch_bwd<4>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 5: return launch_bwd<5>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 6: return launch_bwd<6>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 7: return launch_bwd<7>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 8: return launch_bwd<8>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 9: return launch_bwd<9>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
     }
     ch_set_error("attention backward: more than 288 tokens per image is not built (LDS-resident Q/K/V/dO)");
     return 2;

@@ -229,4 +229,6 @@ int ch_expand_head_rows(const void *src, int is_f32, int B, int ntok, int Q, int
 int ch_small_ln_bwd(const float *dy, const float *x, const float *gamma, int rows, int D, float eps, float *dx, hipStream_t s);
 int ch_gather_concept_rows(const float *H, int B, int ntok, int Q, int D, float *out, hipStream_t s);
 // qkv [B*ntok, 3D] (q | k | v), dO [B*ntok, D] -> dqkv [B*ntok, 3D]; head_dim 64
-int ch_attention_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s);
+// dpext (optional): [B, heads, ncon, ntok - ncon - 1] fp32 cotangent of the last `ncon` tokens' attention rows over tokens 1 .. ntok-ncon-1
+int ch_attention_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s,
+                     const float *dpext = nullptr, int ncon = 0);

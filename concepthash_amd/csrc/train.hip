@@ -160,7 +160,7 @@ struct Rows {
 };
 
 int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype, int img0, int B, float *out_hf_all, float *out_cls_all,
-                  hipStream_t s) {
+                  float *out_cattn_all, hipStream_t s) {
     ch_model *m = t->m;
     const ch_model_config &c = m->cfg;
     const int D = c.dim, M = c.ffn, ntok = m->ntok, np = m->np, bpad = m->bpad, Q = c.ncontext, L = c.layers;
@@ -195,7 +195,9 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
         g.out = R.d3(v.QKV); g.ldo = 3 * D; g.stats_in = R.st(v.st1); g.fold_c = w.qkv_c; g.eps = c.ln_eps;
         if (int e = gemm(t, ch, rows, g, s)) return e;
         const bool pruned = t->prune_last && l == L - 1;
-        if (int e = ch_attention(R.d3(v.QKV), B, ntok, c.heads, R.d(v.AO), s, nullptr, Q, pruned)) return e;
+        // last layer: optionally tap the concept tokens' attention rows over the patch tokens (attn_cache[-1][:, :, -Q:, 1:-Q])
+        float *cattn = (l == L - 1 && out_cattn_all) ? out_cattn_all + (size_t)img0 * c.heads * Q * np : nullptr;
+        if (int e = ch_attention(R.d3(v.QKV), B, ntok, c.heads, R.d(v.AO), s, cattn, Q, pruned)) return e;
         if (pruned) {      // from here on every buffer of this layer holds B * (1 + Q) compact rows (CLS, then the concept tokens)
             cur = B * nq;
             if (int e = ch_gather_head_rows(H, B, ntok, Q, D, Hc, s)) return e;
@@ -242,7 +244,7 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
     return 0;
 }
 
-int backward_chain(ch_trainer *t, int ch, const float *dhf_all, int img0, int B, hipStream_t s) {
+int backward_chain(ch_trainer *t, int ch, const float *dhf_all, const float *dcattn_all, int img0, int B, hipStream_t s) {
     ch_model *m = t->m;
     const ch_model_config &c = m->cfg;
     const int D = c.dim, M = c.ffn, ntok = m->ntok, bpad = m->bpad, Q = c.ncontext, L = c.layers, b = c.adapter_dim, nq = 1 + Q;
@@ -320,7 +322,8 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, int img0, int B,
             dHb = dHbfull;
             cur = rows;
         }
-        if (int e = ch_attention_bwd(R.d3(v.QKV), dctx, B, ntok, c.heads, tQKV, s)) return e;
+        const float *dpext = (l == L - 1 && dcattn_all) ? dcattn_all + (size_t)img0 * c.heads * Q * (ntok - Q - 1) : nullptr;
+        if (int e = ch_attention_bwd(R.d3(v.QKV), dctx, B, ntok, c.heads, tQKV, s, dpext, Q)) return e;
         g = GemmCall{D, 3 * D, tQKV, x.qkv_wgT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;
         if (int e = gemm(t, ch, cur, g, s)) return e;
@@ -463,7 +466,7 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
 extern "C" int64_t ch_trainer_bytes(const ch_trainer *t) { return t ? (int64_t)t->bytes : 0; }
 
 extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image_dtype, int32_t B, const float *concept_tokens,
-                                float *out_hash_features, float *out_cls, void *stream) {
+                                float *out_hash_features, float *out_cls, float *out_concept_attn, void *stream) {
     CH_REQUIRE(t != nullptr && images != nullptr && concept_tokens != nullptr && out_hash_features != nullptr, "train_forward: null argument");
     CH_REQUIRE(B >= 1 && B <= t->max_batch, "train_forward: batch outside [1, max_batch]");
     CH_REQUIRE(image_dtype == 0 || image_dtype == 1, "train_forward: image_dtype must be 0 (fp32) or 1 (bf16)");
@@ -475,13 +478,13 @@ extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image
     t->nc = (t->nchains > 1 && (int64_t)(B / 2) * t->m->ntok >= t->chain_min_rows) ? 2 : 1;
     if (t->nc == 1) {
         t->Bc[0] = B; t->Bc[1] = 0;
-        if (int e = forward_chain(t, 0, images, image_dtype, 0, B, out_hash_features, out_cls, s)) return e;
+        if (int e = forward_chain(t, 0, images, image_dtype, 0, B, out_hash_features, out_cls, out_concept_attn, s)) return e;
     } else {
         t->Bc[0] = B - B / 2; t->Bc[1] = B / 2;      // chain 1 <= ceil(max_batch / 2) images: fits its region
         CH_CHECK_HIP(hipEventRecord(t->ev_fork, s));
         CH_CHECK_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
-        if (int e = forward_chain(t, 0, images, image_dtype, 0, t->Bc[0], out_hash_features, out_cls, s)) return e;
-        if (int e = forward_chain(t, 1, images, image_dtype, t->Bc[0], t->Bc[1], out_hash_features, out_cls, t->aux)) return e;
+        if (int e = forward_chain(t, 0, images, image_dtype, 0, t->Bc[0], out_hash_features, out_cls, out_concept_attn, s)) return e;
+        if (int e = forward_chain(t, 1, images, image_dtype, t->Bc[0], t->Bc[1], out_hash_features, out_cls, out_concept_attn, t->aux)) return e;
         CH_CHECK_HIP(hipEventRecord(t->ev_join, t->aux));
         CH_CHECK_HIP(hipStreamWaitEvent(s, t->ev_join, 0));
     }
@@ -489,19 +492,20 @@ extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image
     return 0;
 }
 
-extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, float *d_concept_tokens, void *stream) {
+extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, const float *d_concept_attn, float *d_concept_tokens,
+                                 void *stream) {
     CH_REQUIRE(t != nullptr && d_hash_features != nullptr && d_concept_tokens != nullptr, "train_backward: null argument");
     CH_REQUIRE(t->forward_done, "train_backward: call ch_train_forward first (its saved activations are what backward reads)");
     hipStream_t s = (hipStream_t)stream;
     const ch_model_config &c = t->m->cfg;
     const int Q = c.ncontext, D = c.dim;
     if (t->nc == 1) {
-        if (int e = backward_chain(t, 0, d_hash_features, 0, t->Bc[0], s)) return e;
+        if (int e = backward_chain(t, 0, d_hash_features, d_concept_attn, 0, t->Bc[0], s)) return e;
     } else {
         CH_CHECK_HIP(hipEventRecord(t->ev_fork, s));
         CH_CHECK_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
-        if (int e = backward_chain(t, 0, d_hash_features, 0, t->Bc[0], s)) return e;
-        if (int e = backward_chain(t, 1, d_hash_features, t->Bc[0], t->Bc[1], t->aux)) return e;
+        if (int e = backward_chain(t, 0, d_hash_features, d_concept_attn, 0, t->Bc[0], s)) return e;
+        if (int e = backward_chain(t, 1, d_hash_features, d_concept_attn, t->Bc[0], t->Bc[1], t->aux)) return e;
         CH_CHECK_HIP(hipEventRecord(t->ev_join, t->aux));
         CH_CHECK_HIP(hipStreamWaitEvent(s, t->ev_join, 0));
         // the two chains' contributions: parameter gradients and concept-token rows (both linear in the per-row products)
@@ -512,9 +516,10 @@ extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, fl
 }
 
 // ---- kernel taps for the tests -------------------------------------------------------------------------------------------------
-extern "C" int ch_debug_attention_bwd(const void *qkv, const void *dO, int32_t B, int32_t ntok, int32_t heads, void *dqkv, void *stream) {
+extern "C" int ch_debug_attention_bwd(const void *qkv, const void *dO, int32_t B, int32_t ntok, int32_t heads, void *dqkv, const float *dpext,
+                                      int32_t ncon, void *stream) {
     CH_REQUIRE(qkv && dO && dqkv, "debug_attention_bwd: null argument");
-    return ch_attention_bwd((const bf16_t *)qkv, (const bf16_t *)dO, B, ntok, heads, (bf16_t *)dqkv, (hipStream_t)stream);
+    return ch_attention_bwd((const bf16_t *)qkv, (const bf16_t *)dO, B, ntok, heads, (bf16_t *)dqkv, (hipStream_t)stream, dpext, ncon);
 }
 extern "C" int ch_debug_wgrad(const void *A, int32_t lda, const void *Bm, int32_t ldb, int64_t rows, int64_t rows_alloc, int32_t N,
                               int32_t K, float *out, void *stream) {

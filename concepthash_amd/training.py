@@ -114,7 +114,7 @@ class TrainEngine:
             _lib.check(self.lib.ch_trainer_refresh(self._t, _lib.stream_ptr(stream)), "ch_trainer_refresh")
         self._stale = False
 
-    def forward(self, images: torch.Tensor, concept_tokens: torch.Tensor, want_cls: bool = False):
+    def forward(self, images: torch.Tensor, concept_tokens: torch.Tensor, want_cls: bool = False, want_attn: bool = False):
         self.encoder._check_images(images)
         B = images.shape[0]
         if B > self.max_batch:
@@ -126,18 +126,23 @@ class TrainEngine:
         images = images.contiguous()
         hf = torch.empty(B, c["ncontext"], c["dim"], dtype=torch.float32, device=self.device)
         cls = torch.empty(B, c["dim"], dtype=torch.float32, device=self.device) if want_cls else None
+        npatch = (c["image_size"] // c["patch"]) ** 2
+        attn = torch.empty(B, c["heads"], c["ncontext"], npatch, dtype=torch.float32, device=self.device) if want_attn else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ch_train_forward(self._t, _lib.ptr(images), 0 if images.dtype == torch.float32 else 1, B,
-                                                 _lib.ptr(ct), _lib.ptr(hf), _lib.ptr(cls), _lib.stream_ptr()), "ch_train_forward")
+                                                 _lib.ptr(ct), _lib.ptr(hf), _lib.ptr(cls), _lib.ptr(attn), _lib.stream_ptr()),
+                       "ch_train_forward")
         self.generation += 1
-        return hf, cls
+        return (hf, cls, attn) if want_attn else (hf, cls)
 
-    def backward(self, d_hash_features: torch.Tensor) -> torch.Tensor:
+    def backward(self, d_hash_features: torch.Tensor, d_concept_attn: torch.Tensor = None) -> torch.Tensor:
         c = self.cfg
         g = d_hash_features.detach().to(self.device, torch.float32).contiguous()
+        ga = d_concept_attn.detach().to(self.device, torch.float32).contiguous() if d_concept_attn is not None else None
         dct = torch.empty(c["ncontext"], c["dim"], dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ch_train_backward(self._t, _lib.ptr(g), _lib.ptr(dct), _lib.stream_ptr()), "ch_train_backward")
+            _lib.check(self.lib.ch_train_backward(self._t, _lib.ptr(g), _lib.ptr(ga), _lib.ptr(dct), _lib.stream_ptr()),
+                       "ch_train_backward")
         for p, gview in self._views:      # optimizer.zero_grad(set_to_none=True) drops the views: put them back
             p.grad = gview
         return dct
@@ -148,20 +153,23 @@ class EncoderFunction(torch.autograd.Function):
     gradients do not travel through autograd -- backward writes them into the parameters' `.grad` views (TrainEngine)."""
 
     @staticmethod
-    def forward(ctx, concept_tokens, images, engine: TrainEngine, anchor):
-        hf, _ = engine.forward(images, concept_tokens)
+    def forward(ctx, concept_tokens, images, engine: TrainEngine, anchor, want_attn=False):
+        """-> hash_features [B, Q, D], or (hash_features, concept_attention [B, heads, Q, Np]) with want_attn: the last layer's
+        attention rows of the concept tokens over the patch tokens, differentiable as well."""
+        out = engine.forward(images, concept_tokens, want_attn=want_attn)
         ctx.engine = engine
         ctx.generation = engine.generation
         ctx.ct_shape = concept_tokens.shape
-        return hf
+        ctx.want_attn = want_attn
+        return (out[0], out[2]) if want_attn else out[0]
 
     @staticmethod
-    def backward(ctx, d_hf):
+    def backward(ctx, d_hf, d_attn=None):
         if ctx.generation != ctx.engine.generation:
             raise RuntimeError("EncoderFunction.backward: another training forward ran on this engine since this graph was built; the "
                                "library keeps the saved activations of the last forward only (one forward -> one backward)")
-        dct = ctx.engine.backward(d_hf)
-        return dct.view(ctx.ct_shape), None, None, None
+        dct = ctx.engine.backward(d_hf, d_attn if ctx.want_attn else None)
+        return dct.view(ctx.ct_shape), None, None, None, None
 
 
 def adapters_from_state_dict(state_dict, layers: int, dim: int, bottleneck: int) -> list:

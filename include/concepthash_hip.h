@@ -119,14 +119,18 @@ int ch_trainer_refresh(ch_trainer *t, void *stream);
 /* Forward in training mode (adapter dropout 0, as the reference configs have it).
  *   concept_tokens    [Q,D] fp32 device: forward_hash_query() output (models/arch/coop.py:413-427), before pre_layrnorm
  *   out_hash_features [B,Q,D] fp32: last-layer states of the concept tokens (coop.py:503-509)
- *   out_cls           [B,D] fp32 last-layer CLS states (optional, NULL) */
+ *   out_cls           [B,D] fp32 last-layer CLS states (optional, NULL)
+ *   out_concept_attn  [B,heads,Q,Np] fp32 last-layer attention of the concept tokens over the patch tokens
+ *                     = attn_cache[-1][:, :, -Q:, 1:-Q] (coop.py:481-482), what the attention-diversity term of the loss reads
+ *                     (models/loss/coop.py:164-189)                                                    (optional, NULL) */
 int ch_train_forward(ch_trainer *t, const void *images, int32_t image_dtype, int32_t B, const float *concept_tokens,
-                     float *out_hash_features, float *out_cls, void *stream);
-/* Backward of the last ch_train_forward: d_hash_features [B,Q,D] fp32 in; adapter gradients into the gradient arena,
- * d_concept_tokens [Q,D] fp32 out. */
-int ch_train_backward(ch_trainer *t, const float *d_hash_features, float *d_concept_tokens, void *stream);
+                     float *out_hash_features, float *out_cls, float *out_concept_attn, void *stream);
+/* Backward of the last ch_train_forward: d_hash_features [B,Q,D] fp32 and (optional, NULL) d_concept_attn [B,heads,Q,Np] fp32 in;
+ * adapter gradients into the gradient arena, d_concept_tokens [Q,D] fp32 out. */
+int ch_train_backward(ch_trainer *t, const float *d_hash_features, const float *d_concept_attn, float *d_concept_tokens, void *stream);
 /* Kernel taps of the training step (tests): see train_kernels.hip / attention_bwd.hip. */
-int ch_debug_attention_bwd(const void *qkv, const void *dO, int32_t B, int32_t ntok, int32_t heads, void *dqkv, void *stream);
+int ch_debug_attention_bwd(const void *qkv, const void *dO, int32_t B, int32_t ntok, int32_t heads, void *dqkv, const float *dpext,
+                           int32_t ncon, void *stream);
 int ch_debug_wgrad(const void *A, int32_t lda, const void *Bm, int32_t ldb, int64_t rows, int64_t rows_alloc, int32_t N, int32_t K,
                    float *out, void *stream);
 int ch_debug_ln_bwd(const void *dyg, const void *x, int64_t rows, int32_t D, float eps, const float *dres_in, float *dres_out,

@@ -200,7 +200,11 @@ class LGHWithoutText(nn.Module):
         eng = self._ensure_train_engine(x.device, int(x.shape[-1]), int(x.shape[0]))
         eng.sync_versions()                                      # an optimizer step since the last forward -> re-derive working copies
         ctx = self.forward_hash_query()
-        hash_features = EncoderFunction.apply(ctx, x, eng, eng.anchor)       # (B, Q, D): HIP forward, HIP backward
+        concept_attention = None
+        if self.return_concept_attention:      # the loss's attention-diversity term reads it (set by the trainer when that term is on)
+            hash_features, concept_attention = EncoderFunction.apply(ctx, x, eng, eng.anchor, True)
+        else:
+            hash_features = EncoderFunction.apply(ctx, x, eng, eng.anchor)   # (B, Q, D): HIP forward, HIP backward
         B = x.shape[0]
         vision_hash = self.hash_fc(hash_features + self.hash_pe).reshape(B, -1)      # reference :544-553
         vision_hash = self.hash_bn(vision_hash)                                      # BatchNorm1d on the batch statistics
@@ -211,6 +215,10 @@ class LGHWithoutText(nn.Module):
                    "codes": vision_hash, "image_hidden_states": (), "hash_features": hash_features, "attn_cache": None}
         if self.concept_reg:
             outputs["logits_concept"] = self.forward_concept(hash_features)
+        if concept_attention is not None:
+            # = attn_cache[-1][:, :, -Q:, 1:-Q] of the reference (coop.py:481-482), (B, heads, Q, Np), differentiable; the full
+            # per-layer (B, heads, N, N) maps are never materialised
+            outputs["concept_attention"] = concept_attention
         # image_features (pooled CLS -> post-LN -> projection, reference :498-501) feeds no term of the shipped loss
         # (loss_scales.logits = 0): not computed in training mode
         return None, outputs

@@ -5,7 +5,8 @@ The reference's trainer calls the criterion during inference to fill the loss/ac
 (`bin_logits`, `cont_logits`, `concept_logits`: margin-cosine cross-entropy with `scale`/`margin`; plus the `quan`
 diagnostic) on the small (B, C) logits the HIP head produces.  It is a few KB per batch; plain torch ops, differentiable (the training step, trainers/coop.py train_one_batch, backpropagates
 through it into the HIP encoder's backward).  `hash_logits` (mixture of
-softmaxes) is included for completeness; `attn_div_loss` needs attention maps, which the fused path never materialises.
+softmaxes) is included for completeness; `attn_div_loss` reads the last layer's concept-token attention rows
+(`outputs['concept_attention']`, tapped from the fused attention kernel and differentiable through `ch_train_backward`).
 """
 from __future__ import annotations
 
@@ -21,8 +22,10 @@ class LGHLoss(nn.Module):
         self.scale, self.margin, self.lmbd = scale, margin, lmbd
         self.loss_scales = dict(loss_scales) if loss_scales is not None else {
             "logits": 1, "hash_logits": 1, "bin_logits": 1, "cont_logits": 1, "concept_logits": 0, "attn_div_loss": 0}
-        if self.loss_scales.get("attn_div_loss", 0):
-            raise NotImplementedError("attn_div_loss needs attention maps, which the fused MI355X path does not emit")
+        if self.loss_scales.get("attn_div_loss", 0) and (kwargs.get("avg_attn") or kwargs.get("nregs")):
+            raise NotImplementedError("attn_div_loss with avg_attn / nregs needs every layer's full attention maps; the MI355X path emits "
+                                      "the last layer's concept-token rows only (outputs['concept_attention'])")
+        self.div_method, self.div_min = div_method, float(kwargs.get("div_min", 0))
         if exponential_scale:
             raise NotImplementedError("exponential_scale != 0 is not built")
         self.avg_before_softmax, self.ncontext, self.concept_cossim = avg_before_softmax, ncontext, concept_cossim
@@ -90,4 +93,19 @@ class LGHLoss(nn.Module):
         if ls.get("bin_logits", 0):
             self.losses["bin"] = self._ce(outputs["logits_bin"], labels)
             total = total + ls["bin_logits"] * self.losses["bin"]
+        if ls.get("attn_div_loss", 0):
+            # reference :161-187 on attn_cache[-1][:, :, -Q:, 1:-Q], which this path hands over directly as
+            # outputs["concept_attention"] (B, heads, Q, Np): head mean, l2 over the patches, pairwise cosine between the Q concept
+            # tokens, (div_method 0: relu(cos - div_min)), batch mean, mean of the strict upper triangle
+            if outputs.get("concept_attention") is None:
+                raise RuntimeError("attn_div_loss needs outputs['concept_attention']: set model.return_concept_attention = True "
+                                   "(COOPTrainer does it when the term is enabled)")
+            a = F.normalize(outputs["concept_attention"].mean(dim=1), dim=-1, p=2)
+            cos = a @ a.transpose(1, 2)
+            if self.div_method == 0:
+                cos = (cos - self.div_min).relu()
+            cos = cos.mean(dim=0)
+            tri = torch.triu(torch.ones_like(cos, dtype=torch.bool), 1)
+            self.losses["attn_div"] = cos[tri].mean()
+            total = total + ls["attn_div_loss"] * self.losses["attn_div"]
         return total

@@ -95,9 +95,32 @@ def main():
                 obj = getattr(obj, part)
             payload["grad/" + k] = obj.grad.detach().numpy()
             ngrad += 1
+    bn_after = (model.hash_bn.running_mean.detach().numpy().copy(), model.hash_bn.running_var.detach().numpy().copy())
+    # ---- the same step with the attention-diversity term on (loss_scales.attn_div_loss = 1, div_method 1 as shipped): the loss reads
+    # attn_cache[-1][:, :, -Q:, 1:-Q] and its gradient enters the last layer's attention.  Weight 25: the term itself is ~0.9 and its
+    # gradient small next to the three cross-entropies.
+    model.zero_grad()
+    crit2 = LGHLoss(margin=0.2, scale=8, loss_scales=dict(logits=0, hash_logits=0, bin_logits=1, cont_logits=1, l2=0, attn_div_loss=25,
+                                                          concept_logits=1), avg_before_softmax=False, lmbd=0.5, div_method=1, ncontext=4)
+    rm, rv = model.hash_bn.running_mean.clone(), model.hash_bn.running_var.clone()
+    feats2, out2 = model(x)
+    loss2 = crit2(out2, labels)
+    loss2.backward()
+    payload["attn/loss"] = loss2.detach().numpy()
+    payload["attn/loss_attn_div"] = crit2.losses["attn_div"].detach().numpy()
+    payload["attn/concept_attention"] = out2["attn_cache"][-1][:, :, -4:, 1:-4].detach().numpy()
+    for k, p in named.items():
+        if k.startswith(("adapter_params.", "trainable_params.")) or p.grad is None:
+            continue
+        if ".adapt_mlp_" in k or k.startswith("hash_attention.") :
+            payload["attngrad/" + k] = p.grad.detach().numpy()
+    payload["attngrad/hash_queries"] = model.hash_queries.grad.detach().numpy()
+    with torch.no_grad():
+        model.hash_bn.running_mean.copy_(rm)
+        model.hash_bn.running_var.copy_(rv)
     # BatchNorm running statistics after the step (momentum 0.1)
-    payload["out/bn_running_mean"] = model.hash_bn.running_mean.detach().numpy()
-    payload["out/bn_running_var"] = model.hash_bn.running_var.detach().numpy()
+    payload["out/bn_running_mean"] = bn_after[0]
+    payload["out/bn_running_var"] = bn_after[1]
     path = os.path.join(GOLDEN, "train_tiny.npz")
     np.savez_compressed(path, **payload)
     print("train_tiny ->", path, f"{os.path.getsize(path) / 1e6:.2f} MB, loss {float(loss):.6f}, {ngrad} gradient tensors")

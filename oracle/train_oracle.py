@@ -65,8 +65,9 @@ def forward_train(sd: Dict[str, torch.Tensor], images, heads, upt_heads=8, act="
     x = eo.embeddings(sd, images, R)
     x = torch.cat([x, ctx.expand(x.shape[0], -1, -1)], dim=1)
     h = eo.layer_norm(x, sd[VM + "pre_layrnorm.weight"].float(), sd[VM + "pre_layrnorm.bias"].float())
+    probs = None
     for i in range(dims["L"]):
-        h, _ = eo.encoder_layer(sd, i, h, heads, R, act)
+        h, probs = eo.encoder_layer(sd, i, h, heads, R, act, want_probs=(i == dims["L"] - 1))
     hf = h[:, -Q:, :]
     B = hf.shape[0]
     v = ((hf + sd["hash_pe"].float()) @ sd["hash_fc.weight"].float().t()).reshape(B, -1)
@@ -74,10 +75,24 @@ def forward_train(sd: Dict[str, torch.Tensor], images, heads, upt_heads=8, act="
     codes = (v - mean) / torch.sqrt(var + bn_eps) * sd["hash_bn.weight"].float() + sd["hash_bn.bias"].float()
     lc, lb = eo.center_logits(sd, codes)
     return dict(codes=codes, hash_features=hf, logits_cont=lc, logits_bin=lb, logits_concept=eo.concept_logits(sd, hf),
+                concept_attention=probs[:, :, -Q:, 1:-Q],       # attn_cache[-1][:, :, -Q:, 1:-Q] (coop.py:481-482)
                 bn_batch_mean=mean.detach(), bn_batch_var_unbiased=v.var(0, unbiased=True).detach(), concept_tokens=ctx)
 
 
-def train_step_grads(sd, images, labels, heads, upt_heads=8, act="quick_gelu", scale=8.0, margin=0.2) -> dict:
+def attn_div(concept_attention, div_method=1, div_min=0.0):
+    """attention-diversity term (models/loss/coop.py:161-187, avg_attn False, nregs 0): head mean of the concept tokens' last-layer
+    attention rows over the patches, l2 over patches, pairwise cosine (Q, Q) per image, (div_method 0: relu(cos - div_min)), batch
+    mean, mean of the strict upper triangle."""
+    a = F.normalize(concept_attention.mean(dim=1), dim=-1, p=2)
+    cos = a @ a.transpose(1, 2)
+    if div_method == 0:
+        cos = (cos - div_min).relu()
+    cos = cos.mean(dim=0)
+    return cos[torch.triu(torch.ones_like(cos, dtype=torch.bool), 1)].mean()
+
+
+def train_step_grads(sd, images, labels, heads, upt_heads=8, act="quick_gelu", scale=8.0, margin=0.2, attn_div_scale=0.0,
+                     div_method=1) -> dict:
     """loss terms + gradient of every trainable tensor for one batch (labels: int64 class indices)."""
     sd = {k: v.clone() for k, v in sd.items()}
     keys = trainable_keys(sd)
@@ -88,6 +103,9 @@ def train_step_grads(sd, images, labels, heads, upt_heads=8, act="quick_gelu", s
                   cont=margin_ce(out["logits_cont"], labels, scale, margin),
                   bin=margin_ce(out["logits_bin"], labels, scale, margin))
     total = losses["concept"] + losses["cont"] + losses["bin"]
+    if attn_div_scale:
+        losses["attn_div"] = attn_div(out["concept_attention"], div_method)
+        total = total + attn_div_scale * losses["attn_div"]
     total.backward()
     return dict(loss=total.detach(), losses={k: v.detach() for k, v in losses.items()},
                 grads={k: sd[k].grad.detach() for k in keys}, out={k: v.detach() for k, v in out.items()})

@@ -146,3 +146,28 @@ def test_training_step_matches_reference_losses_and_gradients():
     rv = 0.9 * sd["hash_bn.running_var"] + 0.1 * res["out"]["bn_batch_var_unbiased"]
     assert torch.allclose(rm, torch.from_numpy(z["out/bn_running_mean"]), atol=1e-5)
     assert torch.allclose(rv, torch.from_numpy(z["out/bn_running_var"]), atol=1e-5)
+
+
+def test_attention_diversity_term_matches_reference():
+    """train_tiny `attn/*`: the same step with loss_scales.attn_div_loss = 25 -- the reference's loss reads
+    attn_cache[-1][:, :, -Q:, 1:-Q] (models/loss/coop.py:161-187) and its gradient enters the last layer's attention."""
+    from oracle import train_oracle as to
+    sd, z = load_fixture("train_tiny")
+    x = fixture_images(z)
+    labels = torch.from_numpy(z["in/labels"])
+    res = to.train_step_grads(sd, x, labels, heads=int(z["meta/heads"]), upt_heads=8, act=str(z["meta/act"]), attn_div_scale=25.0)
+    ca = torch.from_numpy(z["attn/concept_attention"])
+    assert torch.allclose(res["out"]["concept_attention"], ca, atol=2e-6)
+    assert abs(float(res["losses"]["attn_div"]) - float(z["attn/loss_attn_div"])) < 2e-6
+    assert abs(float(res["loss"]) - float(z["attn/loss"])) < 3e-5
+    keys = [k[9:] for k in z.files if k.startswith("attngrad/")]
+    assert len(keys) == 28 + 14 + 1          # 4 adapters x 7 tensors, hash_attention x 14, hash_queries
+    changed = 0
+    for k in keys:
+        ref = torch.from_numpy(z["attngrad/" + k])
+        got = res["grads"][k]
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 5e-5 + 2e-3 * scale, (k, float((got - ref).abs().max()), scale)
+        if ".layers.1.adapt_mlp_" not in k:       # the term acts through the last layer's attention: everything upstream of it moves
+            changed += float((ref - torch.from_numpy(z["grad/" + k])).abs().max()) > 1e-3 * scale
+    assert changed >= 10

@@ -284,3 +284,56 @@ def test_backward_of_a_stale_graph_is_refused():
     model(x[3:])[1]["hash_features"].sum().backward()          # a second forward + its own backward: fine
     with pytest.raises(RuntimeError, match="one forward -> one backward"):
         first.backward()
+
+
+def test_attention_diversity_term_against_the_reference():
+    """loss_scales.attn_div_loss = 25 (train_tiny `attn/*`, generated by the reference): the model hands the concept tokens' last-layer
+    attention rows to the loss, the loss's gradient w.r.t. them goes back into the HIP attention backward."""
+    sd, z = load_fixture("train_tiny")
+    model = _train_model(sd, z)
+    from models.loss.coop import LGHLoss
+    crit = LGHLoss(margin=0.2, scale=8, loss_scales=dict(logits=0, hash_logits=0, bin_logits=1, cont_logits=1, l2=0, attn_div_loss=25,
+                                                         concept_logits=1), avg_before_softmax=False, lmbd=0.5, div_method=1, ncontext=4)
+    model.return_concept_attention = True
+    x = fixture_images(z).cuda()
+    labels = torch.from_numpy(z["in/labels"]).cuda()
+    _, out = model(x)
+    ca, ref = out["concept_attention"].detach().cpu(), torch.from_numpy(z["attn/concept_attention"])
+    assert ca.shape == ref.shape and float((ca - ref).abs().max()) < 2e-3
+    loss = crit(out, labels)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(crit.losses["attn_div"].detach()) - float(z["attn/loss_attn_div"])) < 2e-3
+    assert abs(float(loss.detach()) - float(z["attn/loss"])) < 6e-2
+    want = {k[9:]: z[k] for k in z.files if k.startswith("attngrad/")}
+    _check_grads(_named_grads(model), want, floor_keys=())
+
+
+def test_vjp_through_the_concept_attention_output():
+    """cotangent on the attention output only (hash_features' cotangent zero): isolates the new path -- forward tap, probability
+    cotangent in the attention backward, everything upstream of the last layer's attention."""
+    from oracle import train_oracle as to
+    sd, z = load_fixture("encode_n201")
+    from oracle import encoder_oracle as eo
+    model = _train_model(sd, z, 224)
+    model.return_concept_attention = True
+    x = eo.synthetic_images(2, 224, seed=6).to(torch.bfloat16).float()
+    cot = torch.randn(2, int(z["meta/heads"]), 4, 196, generator=torch.Generator().manual_seed(6))
+    _, out = model(x.cuda())
+    out["concept_attention"].backward(cot.cuda())
+    torch.cuda.synchronize()
+    sdg = {k: v.clone() for k, v in sd.items()}
+    keys = [k for k in to.trainable_keys(sdg) if ".layers.0.adapt_mlp_" in k or ".layers.1.adapt_mlp_" in k or k == "hash_queries"]
+    for k in keys:
+        sdg[k] = sdg[k].float().requires_grad_(True)
+    ref = to.forward_train(sdg, x, heads=int(z["meta/heads"]), upt_heads=8, act=str(z["meta/act"]))["concept_attention"]
+    assert float((out["concept_attention"].detach().cpu() - ref.detach()).abs().max()) < 2e-3
+    ref.backward(cot)
+    # the last layer's adapters sit AFTER its attention: their gradient from this output is exactly zero
+    want = {k: sdg[k].grad for k in keys if ".layers.1." not in k}
+    got = _named_grads(model)
+    for k in keys:
+        if ".layers.1." in k:
+            assert sdg[k].grad is None or float(sdg[k].grad.abs().max()) == 0.0
+            assert float(got[k].abs().max()) == 0.0, k
+    _check_grads(got, want, floor_keys=())

@@ -25,7 +25,7 @@ def test_attention_backward_against_autograd(B, ntok, heads):
     qkv = (torch.randn(B * ntok, 3 * D, generator=g, device="cuda") * 1.5).to(torch.bfloat16)
     dO = torch.randn(B * ntok, D, generator=g, device="cuda").to(torch.bfloat16)
     out = torch.full((B * ntok, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
-    L.check(lib.ch_debug_attention_bwd(L.ptr(qkv), L.ptr(dO), B, ntok, heads, L.ptr(out), L.stream_ptr()), "attention_bwd")
+    L.check(lib.ch_debug_attention_bwd(L.ptr(qkv), L.ptr(dO), B, ntok, heads, L.ptr(out), None, 0, L.stream_ptr()), "attention_bwd")
     torch.cuda.synchronize()
     x = qkv.float().view(B, ntok, 3, heads, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)   # [3, B, h, N, 64]
     q, k, v = x[0], x[1], x[2]
@@ -39,6 +39,33 @@ def test_attention_backward_against_autograd(B, ntok, heads):
         a, w = got[:, j * D:(j + 1) * D], want[:, j * D:(j + 1) * D]
         assert _rel(a, w) < 1.5e-2, (name, _rel(a, w))
         assert float((a - w).abs().max()) < 3e-2 * float(w.abs().max()) + 1e-3, name
+
+
+@pytest.mark.parametrize("B,ntok,heads,ncon", [(2, 21, 2, 4), (2, 201, 4, 4), (1, 41, 1, 8)])
+def test_attention_backward_with_a_cotangent_on_the_probabilities(B, ntok, heads, ncon):
+    """dpext: gradient arriving at the softmax rows of the last `ncon` (concept) tokens over tokens 1 .. ntok-ncon-1 -- what the
+    attention-diversity term of the loss produces -- on top of the usual dO."""
+    L, lib = _lib()
+    D = heads * 64
+    npatch = ntok - ncon - 1
+    g = torch.Generator(device="cuda").manual_seed(ntok + 1)
+    qkv = (torch.randn(B * ntok, 3 * D, generator=g, device="cuda") * 1.5).to(torch.bfloat16)
+    dO = torch.randn(B * ntok, D, generator=g, device="cuda").to(torch.bfloat16)
+    dpext = torch.randn(B, heads, ncon, npatch, generator=g, device="cuda") * 3
+    out = torch.full((B * ntok, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.ch_debug_attention_bwd(L.ptr(qkv), L.ptr(dO), B, ntok, heads, L.ptr(out), L.ptr(dpext), ncon, L.stream_ptr()),
+            "attention_bwd")
+    torch.cuda.synchronize()
+    x = qkv.float().view(B, ntok, 3, heads, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
+    p = torch.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
+    o = p @ x[2]
+    loss = (o * dO.float().view(B, ntok, heads, 64).permute(0, 2, 1, 3)).sum() + (p[:, :, -ncon:, 1:-ncon] * dpext).sum()
+    loss.backward()
+    want = x.grad.permute(1, 3, 0, 2, 4).reshape(B * ntok, 3 * D)
+    got = out.float()
+    for j, name in enumerate(("dq", "dk", "dv")):
+        a, w = got[:, j * D:(j + 1) * D], want[:, j * D:(j + 1) * D]
+        assert _rel(a, w) < 1.5e-2, (name, _rel(a, w))
 
 
 @pytest.mark.parametrize("rows,N,K", [(1000, 128, 128), (4321, 768, 384), (4321, 384, 768), (51456, 256, 128), (31, 128, 256)])

@@ -16,6 +16,21 @@ class COOPTrainer(BaseTrainer):
         super().__init__(config)
         os.environ["TOKENIZERS_PARALLELISM"] = "false"
 
+    def load_criterion(self):
+        super().load_criterion()
+        self._sync_attention_tap()
+
+    def load_model(self):
+        super().load_model()
+        self._sync_attention_tap()
+
+    def _sync_attention_tap(self):
+        """The attention-diversity term of the loss reads the concept tokens' last-layer attention rows: ask the model for them
+        exactly when that term is on (reference models/loss/coop.py:161-187 reads outputs['attn_cache'])."""
+        if self.model is not None and self.criterion is not None and hasattr(self.model, "return_concept_attention"):
+            if getattr(self.criterion, "loss_scales", {}).get("attn_div_loss", 0):
+                self.model.return_concept_attention = True
+
     def load_dataset(self, load_db=True):
         ds = self.config.dataset
         self.dataset = {"train": instantiate(ds.train_dataset) if ds.get("train_dataset") is not None else [],
