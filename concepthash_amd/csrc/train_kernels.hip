@@ -23,6 +23,14 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4s lds_v4s;
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char lds_char_t;
+// ds_read_b64_tr_b16 at an LDS byte address, invisible to the compiler's LDS-DMA alias analysis (see wgrad_tn_kernel)
+__device__ __forceinline__ v2i_t tr_read(uint32_t lds_addr) {
+    v2i_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr) : "memory");
+    return r;
+}
 
 constexpr int MAXP = 10;  // D <= 1280, D % 128 == 0 (row kernels: one wave per row, lane holds elements (j*64 + lane)*2 + {0,1})
 
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t *__restrict__ 
 
 // ---- weight gradient: out[n][k] = sum_m A[m][n] * B[m][k] ---------------------------------------------------------------------
 // Workgroup: 128 (n) x 128 (k) output tile over one chunk of rows; 4 waves = 2 x 2, wave tile 64 x 64 = acc[4][4] of
-// v_mfma_f32_16x16x32_bf16.  A K-step is 32 rows: A[32][128] and B[32][128] (8 KB each) by LDS-DMA, double buffered.  LDS rows
+// v_mfma_f32_16x16x32_bf16.  A K-step is 32 rows: A[32][128] and B[32][128] (8 KB each) by LDS-DMA, four-stage ring.  LDS rows
 // are 256 B (128 bf16); the 32-B column-tile index (16 columns) is XOR-swizzled with (row & 7) on the per-lane source address
 // and on the transpose-read address: the 32 lanes served together by ds_read_b64_tr_b16 address 8 different rows (r & 7 all
 // distinct) x 32 B -> all 64 banks once.
@@ -168,17 +176,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t *__restrict__ 
 constexpr int WG_TILE = 128, WG_KSTEP = 32, WG_STAGE = 2 * WG_KSTEP * WG_TILE * 2;  // 16 KB per stage (A + B)
 
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const bf16_t *__restrict__ A, int lda, const bf16_t *__restrict__ B, int ldb,
-                                                          int N, int K, int steps_per_chunk, int total_steps,
+                                                          int N, int K, int steps_per_chunk, int total_steps, int nchunks,
                                                           float *__restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * WG_STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[4 * WG_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid & 1, wk = wid >> 1;
-    const int tiles_k = K / WG_TILE;
-    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs, so ids congruent mod 8 walk the output tiles of ONE
+    // row chunk back to back on one XCD -- the 18 tiles of a chunk read the same rows (each A column block 3x, each B column block
+    // 6x) and find them in that XCD's L2 instead of re-fetching them (474 MB per call re-read against 118 MB of operands).
+    const int tiles_k = K / WG_TILE, tiles = (N / WG_TILE) * tiles_k;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int chunk = (j / tiles) * 8 + xcd, tile = j % tiles;
+    if (chunk >= nchunks) return;
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     const int n0 = tn * WG_TILE, k0 = tk * WG_TILE;
-    const int64_t m_begin = (int64_t)blockIdx.y * steps_per_chunk * WG_KSTEP;
-    const int nsteps = max(0, min(steps_per_chunk, total_steps - (int)blockIdx.y * steps_per_chunk));  // the last chunks may be short / empty
+    const int64_t m_begin = (int64_t)chunk * steps_per_chunk * WG_KSTEP;
+    const int nsteps = max(0, min(steps_per_chunk, total_steps - chunk * steps_per_chunk));  // the last chunks may be short / empty
 
     // staging: a stage image is [A rows 0..31 ; B rows 0..31] x 256 B = 16 wave-instructions of 4 rows; wave w issues 4w..4w+3
     const char *gsrc[4];
@@ -217,34 +231,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const bf16_t *__restri
     }
     union Frag {
         bf16x8 v;
-        v4s h[2];
+        v2i_t d[2];
     };
 
+    // four-stage ring, three K-steps of loads in flight (counted vmcnt + raw barrier, as gemm_r4.hip): with two stages and a
+    // vmcnt(0) per step the kernel ran at the HBM round-trip time per 32-row step (420 TFLOP/s, ~2 workgroups per CU)
     if (nsteps > 0) stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (nsteps > 1) stage(1, 1);
+    if (nsteps > 2) stage(2, 2);
     int cur = 0;
     for (int st = 0; st < nsteps; ++st) {
-        if (st + 1 < nsteps) stage(cur ^ 1, st + 1);
-        const char *sb = smem + cur * WG_STAGE;
+        const int ahead = nsteps - 1 - st;
+        if (ahead >= 2)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();   // stage st landed for every wave; every wave finished reading stage st - 1
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 3 < nsteps) stage((cur + 3) & 3, st + 3);
+        // The transpose reads are issued as inline asm: for the builtin the compiler assumes the read may alias the LDS-DMA in
+        // flight and puts `s_waitcnt vmcnt(0)` in front of it, i.e. it waits for the stages just requested -- which made the
+        // two-stage version of this kernel run at one HBM round trip per K-step.  The barrier above is what orders this stage's
+        // DMA before these reads; their completion is awaited by hand (lgkmcnt) before the first MFMA.
+        const uint32_t sbase = (uint32_t)(size_t)(lds_char_t *)(smem) + cur * WG_STAGE;
         Frag af[4], bfm[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            af[t].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(sb + aoff[t]));
-            af[t].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(sb + aoff[t] + 16 * 256));
-            bfm[t].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(sb + boff[t]));
-            bfm[t].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s *)(sb + boff[t] + 16 * 256));
+            af[t].d[0] = tr_read(sbase + aoff[t]);
+            af[t].d[1] = tr_read(sbase + aoff[t] + 16 * 256);
+            bfm[t].d[0] = tr_read(sbase + boff[t]);
+            bfm[t].d[1] = tr_read(sbase + boff[t] + 16 * 256);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfm[kt].v, af[nt].v, acc[kt][nt], 0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+        cur = (cur + 1) & 3;
     }
-    float *slab = partial + (size_t)blockIdx.y * N * K;
+    float *slab = partial + (size_t)chunk * N * K;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -648,8 +678,9 @@ int ch_wgrad_tn(bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int6
     CH_REQUIRE((int64_t)total_steps * WG_KSTEP <= rows_alloc, "wgrad: operands must be allocated to a multiple of 32 rows");
     if ((int64_t)total_steps * WG_KSTEP > rows)
         CH_CHECK_HIP(hipMemsetAsync(A + rows * lda, 0, sizeof(bf16_t) * ((int64_t)total_steps * WG_KSTEP - rows) * lda, s));
-    hipLaunchKernelGGL(wgrad_tn_kernel, dim3((N / WG_TILE) * (K / WG_TILE), chunks), dim3(256), 0, s, A, lda, B, ldb, N, K, spc,
-                       total_steps, ws);
+    const int tiles = (N / WG_TILE) * (K / WG_TILE);
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(8 * ((chunks + 7) / 8) * tiles), dim3(256), 0, s, A, lda, B, ldb, N, K, spc, total_steps, chunks,
+                       ws);
     CH_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)N * K / 4;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(n4, 32)), dim3(256), 0, s, ws, chunks, n4, out);
