@@ -5,7 +5,10 @@
 //   P = softmax(0.125 Q K^T),  O = P V                                   (forward, attention.hip)
 //   dV = P^T dO,  dP = dO V^T,  D_q = sum_j P_qj dP_qj (= dO_q . O_q),  dS = 0.125 P o (dP - D),  dQ = dS K,  dK = dS^T Q
 //
-// Q, K, V and dO of the pair are staged once in LDS (row-major, 128-B rows, 16-B chunk index XOR (row & 7), by LDS-DMA).
+// LDS holds two [rows][128 B] images (row-major, 16-B chunk index XOR (row & 7), filled by LDS-DMA): K and V during phase A, then --
+// restaged between the phases -- Q and dO during phase B; the operands a phase needs only as per-lane fragments (Q / dO rows of
+// the wave's query tile in A, K / V rows of its key tile in B) come straight from global memory, as the forward kernel reads Q.
+// 59 KB instead of 118 KB, so TWO workgroups share a CU and cover each other's latencies (one was alone before).
 // Phase A -- a wave owns 16-query tiles (the forward's layout: S^T = K Q^T, a lane holds one query's keys):
 //   softmax statistics, dP^T = V dO^T, D_q, dS^T in registers; dQ^T = K^T dS^T with K^T from the hardware transpose read
 //   (ds_read_b64_tr_b16), dS^T being already the B operand; (max, 1/sum, D_q) per query go to LDS.
@@ -20,7 +23,7 @@
 namespace {
 
 constexpr int HD = 64;
-constexpr int NW = 8;
+constexpr int NW = 4;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -30,14 +33,15 @@ typedef __attribute__((address_space(3))) v4s lds_v4s;
 // concept-token attention rows the forward can tap (attention.hip TAP; consumer: the attention-diversity term of the loss,
 // models/loss/coop.py:164-189) -- is added to dP = dO V^T on those (query, key) pairs, in both phases.
 template <int KB, bool EXT>
-__global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dO, int ntok,
+__global__ __launch_bounds__(NW * 64, 2) void attention_bwd_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dO, int ntok,
                                                                int heads, float scale_log2e, bf16_t *__restrict__ dqkv,
                                                                const float *__restrict__ dpext, int ncon) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = KB * 2;   // 16-row tiles
     constexpr int KP = KB * 32;  // padded rows (keys and queries)
-    char *Ks = smem, *Vs = smem + KP * 128, *Qs = smem + 2 * KP * 128, *Gs = smem + 3 * KP * 128;  // Gs: dO
-    float *stat = (float *)(smem + 4 * KP * 128);                                                    // [KP][4]: mxs, inv, D_q, -
+    char *Ks = smem, *Vs = smem + KP * 128;    // phase A: K, V
+    char *Qs = smem, *Gs = smem + KP * 128;    // phase B: Q, dO (same storage, restaged after phase A)
+    float *stat = (float *)(smem + 2 * KP * 128);   // [KP][4]: mxs, inv, D_q, -
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,14 +59,10 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__
             int row = i * 8 + lrow;
             row = row < ntok ? row : ntok - 1;
             const bf16_t *src = base + (size_t)row * ld + src_chunk * 8;
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src), (lds_void_t *)(Qs + i * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + D), (lds_void_t *)(Ks + i * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + 2 * D), (lds_void_t *)(Vs + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(gbase + (size_t)row * D + src_chunk * 8), (lds_void_t *)(Gs + i * 1024), 16, 0, 0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
     const int fr = lane & 15, fq = lane >> 4;
     const int QT = (ntok + 15) >> 4;  // tiles holding at least one valid row
@@ -77,12 +77,30 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) toff[dt] = (fq * 4 + tq) * 128 + (((dt * 2 + (tp >> 1)) ^ trow7) << 4) + (tp & 1) * 8;
 
+    // fragments of one 16-row tile straight from global memory: lane (row fr, fq) holds columns 8*fq.. and 32 + 8*fq.. of its row
+    // (rows past the sequence re-read the last row: finite, masked / zero weight)
+    auto row_frag = [&](const bf16_t *mat, size_t ldm, int tile, bf16x8 &f0, bf16x8 &f1) {
+        const int r = min(tile * 16 + fr, ntok - 1);
+        f0 = *(const bf16x8 *)(mat + (size_t)r * ldm + fq * 8);
+        f1 = *(const bf16x8 *)(mat + (size_t)r * ldm + fq * 8 + 32);
+    };
+    bf16x8 nq0, nq1, ng0, ng1;     // the next tile's fragments, requested one tile ahead
+    if (wid < QT) {
+        row_frag(base, ld, wid, nq0, nq1);
+        row_frag(gbase, D, wid, ng0, ng1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
     // ================================ phase A: per query tile -> statistics and dQ ==========================================
     for (int qt = wid; qt < QT; qt += NW) {
         const int q = qt * 16 + fr;
         const bool qvalid = q < ntok;
-        const bf16x8 qf0 = *(const bf16x8 *)(Qs + qt * 2048 + off0), qf1 = *(const bf16x8 *)(Qs + qt * 2048 + off1);
-        const bf16x8 gf0 = *(const bf16x8 *)(Gs + qt * 2048 + off0), gf1 = *(const bf16x8 *)(Gs + qt * 2048 + off1);
+        const bf16x8 qf0 = nq0, qf1 = nq1, gf0 = ng0, gf1 = ng1;
+        if (qt + NW < QT) {
+            row_frag(base, ld, qt + NW, nq0, nq1);
+            row_frag(gbase, D, qt + NW, ng0, ng1);
+        }
         f32x4 st[KT], dp[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -176,14 +194,33 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__
             }
         }
     }
+    __syncthreads();   // every wave is done with K and V in LDS, the statistics are complete
+    {  // restage: Q and dO take the place of K and V
+        const int lrow = lane >> 3;
+        const int src_chunk = (lane & 7) ^ lrow;
+        for (int i = wid; i < KP / 8; i += NW) {
+            int row = i * 8 + lrow;
+            row = row < ntok ? row : ntok - 1;
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(base + (size_t)row * ld + src_chunk * 8), (lds_void_t *)(Qs + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(gbase + (size_t)row * D + src_chunk * 8), (lds_void_t *)(Gs + i * 1024), 16, 0, 0);
+        }
+    }
+    bf16x8 k0, k1, v0, v1;   // this wave's first key tile, from global, under the restaging
+    if (wid < QT) {
+        row_frag(base + D, ld, wid, k0, k1);
+        row_frag(base + 2 * D, ld, wid, v0, v1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // ================================ phase B: per key tile -> dK, dV ========================================================
     for (int kt = wid; kt < QT; kt += NW) {
         const int key = kt * 16 + fr;
         const bool kvalid = key < ntok;
-        const bf16x8 k0 = *(const bf16x8 *)(Ks + kt * 2048 + off0), k1 = *(const bf16x8 *)(Ks + kt * 2048 + off1);
-        const bf16x8 v0 = *(const bf16x8 *)(Vs + kt * 2048 + off0), v1 = *(const bf16x8 *)(Vs + kt * 2048 + off1);
+        if (kt != wid) {
+            row_frag(base + D, ld, kt, k0, k1);
+            row_frag(base + 2 * D, ld, kt, v0, v1);
+        }
         f32x4 dkt[4], dvt[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dkt[dt] = dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -247,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(const bf16_t *__
 template <int KB, bool EXT>
 int launch_bwd_inst(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, const float *dpext, int ncon, hipStream_t s) {
     constexpr int KP = KB * 32;
-    const size_t lds = (size_t)KP * 128 * 4 + (size_t)KP * 16;
+    const size_t lds = (size_t)KP * 128 * 2 + (size_t)KP * 16;
     CH_REQUIRE(lds <= 160 * 1024, "attention backward: sequence too long for the LDS-resident kernel");
     static ch_once_per_device lds_once;
     if (int e = ch_func_max_lds((const void *)attention_bwd_kernel<KB, EXT>, (int)lds, lds_once)) return e;
