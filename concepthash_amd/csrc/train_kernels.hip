@@ -493,12 +493,13 @@ __global__ __launch_bounds__(256) void adapter_grads_elem_kernel(const float *__
     }
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
-// kernel 2: block 0 sums the AG_BLOCKS partials in a fixed order -> d(scale); blocks 1.. : 64 columns k each, 16 row lanes over j:
+// kernel 2: block 0 sums the AG_BLOCKS partials in a fixed order -> d(scale); blocks 1.. : 16 columns k each, 64 row lanes over j
+// (6 dependent loads per thread for b = 384; with 64 columns x 16 lanes it was a 24-load chain on 13 blocks):
 // dgamma[k] = sum_j T[j][k] W_dn[j][k], dbeta[k] = sum_j cd[j] W_dn[j][k]
 __global__ __launch_bounds__(1024) void adapter_grads_red_kernel(const float *__restrict__ T, const float *__restrict__ cd,
                                                                  const float *__restrict__ P, int D, int b, float *__restrict__ gr,
                                                                  const float *__restrict__ part) {
-    __shared__ float ra[16][64], rc[16][64];
+    __shared__ float ra[64][17], rc[64][17];
     if (blockIdx.x == 0) {
         __shared__ float red[256];
         if (threadIdx.x < 256) red[threadIdx.x] = threadIdx.x < AG_BLOCKS ? part[threadIdx.x] : 0.f;
@@ -511,11 +512,11 @@ __global__ __launch_bounds__(1024) void adapter_grads_red_kernel(const float *__
         return;
     }
     const float *down_w = P + 2 * D;
-    const int kl = threadIdx.x & 63, jl = threadIdx.x >> 6;
-    const int k = (blockIdx.x - 1) * 64 + kl;
+    const int kl = threadIdx.x & 15, jl = threadIdx.x >> 4;
+    const int k = (blockIdx.x - 1) * 16 + kl;
     float a = 0.f, c = 0.f;
     if (k < D)
-        for (int j = jl; j < b; j += 16) {
+        for (int j = jl; j < b; j += 64) {
             const float w = down_w[(size_t)j * D + k];
             a += T[(size_t)j * D + k] * w;
             c += cd[j] * w;
@@ -525,8 +526,7 @@ __global__ __launch_bounds__(1024) void adapter_grads_red_kernel(const float *__
     __syncthreads();
     if (jl == 0 && k < D) {
         float sa = 0.f, sc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 64; ++j) {   // fixed order
             sa += ra[j][kl];
             sc += rc[j][kl];
         }
@@ -733,7 +733,7 @@ int ch_adapter_grads(const float *G, const float *cu, const float *T, const floa
                      float *grads, float *ws, hipStream_t s) {
     hipLaunchKernelGGL(adapter_grads_elem_kernel, dim3(AG_BLOCKS), dim3(256), 0, s, G, cu, T, cd, params, D, b, bpad, grads, ws);
     CH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(adapter_grads_red_kernel, dim3(1 + (D + 63) / 64), dim3(1024), 0, s, T, cd, params, D, b, grads, ws);
+    hipLaunchKernelGGL(adapter_grads_red_kernel, dim3(1 + (D + 15) / 16), dim3(1024), 0, s, T, cd, params, D, b, grads, ws);
     CH_LAUNCH_CHECK();
     return 0;
 }
