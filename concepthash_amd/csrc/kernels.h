@@ -202,8 +202,9 @@ int ch_act_bwd(const bf16_t *g, const bf16_t *pre, int64_t n, int act, const flo
 int ch_normalize_bf16(const bf16_t *x, const float *stats, int64_t rows, int D, float eps, bf16_t *out, hipStream_t s);
 // LayerNorm backward per row given dyg = dy * gamma: result = dres_in + rstd (dyg - mean(dyg) - x_hat mean(dyg x_hat)) -> dres_out (fp32,
 // may alias dres_in, may be null), out_b (bf16, may be null)
+// xhat_out (optional): also write x_hat = (x - mean) * rstd as bf16
 int ch_ln_bwd(const bf16_t *dyg, const bf16_t *x, const float *stats, int64_t rows, int D, float eps, const float *dres_in,
-              float *dres_out, bf16_t *out_b, hipStream_t s);
+              float *dres_out, bf16_t *out_b, hipStream_t s, bf16_t *xhat_out = nullptr);
 // out[n][k] = sum_m A[m][n] * B[m][k]  (A [rows, N] ld lda, B [rows, K] ld ldb, bf16; out [N, K] fp32); ws: ch_wgrad_ws_floats floats.
 // Rows up to the next multiple of 32 are read: they must be allocated; A's are zeroed by the call, B's must be finite.
 int ch_wgrad_tn(bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int64_t rows_alloc, int N, int K, float *out,

@@ -17,8 +17,9 @@
 // Backward per layer, dH = gradient of the residual stream (fp32, bf16 copy dHb as the GEMM operand):
 //   adapter:  G = dHb^T g, cu = colsum(dH)                                [weight-gradient products, up]
 //             dpre = s (dHb W_up) o gelu'(pre)                            [dgrad GEMM + act_bwd]
+//             d(branch input) = dH + LN_bwd(dpre (W_dn o gamma))          [dgrad GEMM with gamma folded into W^T + ln_bwd, which
+//                                                                          also emits x_hat of the adapter input as bf16]
 //             T = dpre^T x_hat, cd = colsum(dpre)                         [weight-gradient products, down]
-//             d(branch input) = dH + LN_bwd(dpre (W_dn o gamma))          [dgrad GEMM with gamma folded into W^T + ln_bwd]
 //   MLP:      dF = (dM W_fc2) o act'(pre), dh = dF (W_fc1 o gamma2), dH += LN_bwd(dh)
 //   attn:     dctx = dA W_o, dqkv = attention_bwd(qkv, dctx), dh = dqkv (W_qkv o gamma1), dH += LN_bwd(dh)
 // Parameter arena (fp32, caller-owned, device): adapters in (layer, adapter) order, each
@@ -281,17 +282,16 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, const float *dca
         GemmCall g{bpad, D, dHb, aw.up_wT, zero, EPI_BIAS_DACT_GELU};   // dpre = s (dH W_up) o gelu'(pre), in the epilogue
         g.out = tB; g.ldo = bpad; g.aux = P; g.scale = ap.scale;
         if (int e = gemm(t, ch, cur, g, s, dalloc)) return e;
-        // down projection + adapter LayerNorm
-        if (int e = ch_normalize_bf16(in, stin, cur, D, 1e-5f, tD2, s)) return e;
-        if (int e = ch_wgrad_tn(tB, bpad, tD2, D, cur, ralloc, bpad, D, t->T[ch], t->ws_wgrad[ch], s)) return e;
-        if (int e = ch_colsum(tB, 0, bpad, cur, bpad, t->cd[ch], t->ws_colsum[ch], s)) return e;
-        if (int e = ch_adapter_grads(t->G[ch], t->cu[ch], t->T[ch], t->cd[ch], pbase, D, b, bpad, grads + (int64_t)(l * 2 + a) * t->ad_numel,
-                                     t->ws_colsum[ch], s))
-            return e;
+        // down projection + adapter LayerNorm: the input-gradient GEMM and the LayerNorm backward first -- the latter emits the
+        // normalised adapter input x_hat (bf16) on the way, which the weight-gradient product then consumes
         g = GemmCall{D, bpad, tB, aw.down_wgT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;
         if (int e = gemm(t, ch, cur, g, s)) return e;
-        return ch_ln_bwd(tD, in, stin, cur, D, 1e-5f, dH, nullptr, dMb, s);
+        if (int e = ch_ln_bwd(tD, in, stin, cur, D, 1e-5f, dH, nullptr, dMb, s, tD2)) return e;
+        if (int e = ch_wgrad_tn(tB, bpad, tD2, D, cur, ralloc, bpad, D, t->T[ch], t->ws_wgrad[ch], s)) return e;
+        if (int e = ch_colsum(tB, 0, bpad, cur, bpad, t->cd[ch], t->ws_colsum[ch], s)) return e;
+        return ch_adapter_grads(t->G[ch], t->cu[ch], t->T[ch], t->cd[ch], pbase, D, b, bpad, grads + (int64_t)(l * 2 + a) * t->ad_numel,
+                                t->ws_colsum[ch], s);
     };
 
     for (int l = L - 1; l >= 0; --l) {

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void normalize_kernel(const bf16_t *__restrict
 // dres_in, may be null) and / or out_b (bf16 GEMM operand, may be null)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t *__restrict__ dyg, const bf16_t *__restrict__ x,
                                                      const float *__restrict__ stats, int64_t rows, int D, float eps,
-                                                     const float *dres_in, float *dres_out, bf16_t *__restrict__ out_b) {
+                                                     const float *dres_in, float *dres_out, bf16_t *__restrict__ out_b,
+                                                     bf16_t *__restrict__ xhat_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -146,6 +147,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t *__restrict__ 
             const uint32_t ux = *(const uint32_t *)(x + row * D + (j * 64 + lane) * 2);
             g[j] = make_float2(bf2f((bf16_t)(ug & 0xffff)), bf2f((bf16_t)(ug >> 16)));
             xh[j] = make_float2((bf2f((bf16_t)(ux & 0xffff)) - mean) * rstd, (bf2f((bf16_t)(ux >> 16)) - mean) * rstd);
+            // x_hat as a bf16 GEMM operand (the adapter's weight-gradient product consumes it): a by-product here, a separate
+            // read of x otherwise (normalize_kernel)
+            if (xhat_out) *(uint32_t *)(xhat_out + row * D + (j * 64 + lane) * 2) = pack_bf16x2(xh[j].x, xh[j].y);
             s1 += g[j].x + g[j].y;
             s2 += g[j].x * xh[j].x + g[j].y * xh[j].y;
         }
@@ -648,10 +652,10 @@ int ch_normalize_bf16(const bf16_t *x, const float *stats, int64_t rows, int D, 
     return 0;
 }
 int ch_ln_bwd(const bf16_t *dyg, const bf16_t *x, const float *stats, int64_t rows, int D, float eps, const float *dres_in,
-              float *dres_out, bf16_t *out_b, hipStream_t s) {
+              float *dres_out, bf16_t *out_b, hipStream_t s, bf16_t *xhat_out) {
     CH_REQUIRE(D % 128 == 0 && D <= 128 * MAXP, "ln_bwd: D must be a multiple of 128, <= 1280");
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, s, dyg, x, stats, rows, D, eps, dres_in, dres_out,
-                       out_b);
+                       out_b, xhat_out);
     CH_LAUNCH_CHECK();
     return 0;
 }
