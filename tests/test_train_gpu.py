@@ -246,6 +246,15 @@ def test_main_v2_exp_hashing_trains_end_to_end(tmp_path):
                     "eval_logdir=" + ev] + common, check=True, env=env, cwd=str(tmp_path))
     hist = json.load(open(os.path.join(ev, "history.json")))
     assert abs(hist["mAP"] - te[0]["mAP"]) < 1e-12          # best.pth == the only evaluated epoch: same codes, same score
+    # the attention-diversity term switched on from the command line: the trainer asks the model for the concept tokens' attention
+    # rows, the loss meter appears, and it is a cosine mean in [0, 1]
+    logdir2 = str(tmp_path / "run_attn")
+    subprocess.run([sys.executable, os.path.join(ROOT, "main_v2.py"), "exp=hashing", "optim=sgd", "optim.lr=0.02", "scheduler=no_decay",
+                    "model.backbone.name=synthetic/clip-vit-small-patch16", "model.nbit=64", "epochs=1", "eval_interval=0",
+                    "batch_size=32", "criterion.loss_scales.attn_div_loss=1", "logdir=" + logdir2] + common, check=True, env=env,
+                   cwd=str(tmp_path))
+    tr2 = json.load(open(os.path.join(logdir2, "train_history.json")))
+    assert 0.0 < tr2[0]["train_attn_div"] < 1.0 and tr2[0]["train_loss"] > tr[0]["train_loss"] - 1.0
 
 
 @pytest.mark.parametrize("chains", [1, 2])
