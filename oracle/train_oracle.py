@@ -57,11 +57,13 @@ def margin_ce(logits, labels, scale, margin):
     return F.cross_entropy(scale * (logits - margin * onehot), labels)
 
 
-def forward_train(sd: Dict[str, torch.Tensor], images, heads, upt_heads=8, act="quick_gelu", bn_eps=1e-5) -> dict:
+def forward_train(sd: Dict[str, torch.Tensor], images, heads, upt_heads=8, act="quick_gelu", bn_eps=1e-5, ctx=None) -> dict:
+    """ctx: optional (1, Q, D) concept tokens to use instead of forward_hash_query() -- a leaf for tests of d(concept tokens)"""
     dims = eo.infer_dims(sd)
     Q = dims["Q"]
     R = eo._R(False)
-    ctx = eo.concept_tokens(sd, upt_heads)
+    if ctx is None:
+        ctx = eo.concept_tokens(sd, upt_heads)
     x = eo.embeddings(sd, images, R)
     x = torch.cat([x, ctx.expand(x.shape[0], -1, -1)], dim=1)
     h = eo.layer_norm(x, sd[VM + "pre_layrnorm.weight"].float(), sd[VM + "pre_layrnorm.bias"].float())

@@ -346,3 +346,45 @@ def test_vjp_through_the_concept_attention_output():
             assert sdg[k].grad is None or float(sdg[k].grad.abs().max()) == 0.0
             assert float(got[k].abs().max()) == 0.0, k
     _check_grads(got, want, floor_keys=())
+
+
+@pytest.mark.parametrize("config,layers,batch", [("vit_s16", 2, 2), ("vit_b16", 2, 2), ("vit_b32", 3, 3)])
+def test_engine_gradients_at_real_widths(config, layers, batch):
+    """The C-ABI level (TrainEngine.forward / backward) at the widths of the real backbones -- D = 384 (N not a multiple of 256:
+    128x128 GEMM tiles, bottleneck 384 = its padded size), D = 768 with 201 and 54 tokens -- cut to 2-3 layers so that fp32
+    autograd of the oracle stays in seconds: every adapter tensor's gradient and d(concept tokens) for a random cotangent."""
+    from concepthash_amd import synthetic
+    from concepthash_amd.training import ADAPTER_FIELDS, TrainEngine, adapters_from_state_dict
+    from oracle import encoder_oracle as eo
+    from oracle import train_oracle as to
+    cfg = dict(synthetic.CONFIGS[config])
+    cfg["L"] = layers
+    sd = synthetic.synthetic_state_dict(cfg, nbit=64, nclass=10, seed=3)
+    sd = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in sd.items()}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = TrainEngine(sd, adapters_from_state_dict(sd, layers, cfg["D"], cfg["b"]), heads=cfg["heads"], max_batch=batch, device=dev)
+    x = synthetic.synthetic_images(batch, cfg["image"], seed=2).to(torch.bfloat16).float()
+    g = torch.Generator().manual_seed(1)
+    cot = torch.randn(batch, 4, cfg["D"], generator=g)
+    ctx = (torch.randn(1, 4, cfg["D"], generator=g) * 0.5)
+    hf, _ = eng.forward(x.to(dev), ctx.to(dev))
+    dct = eng.backward(cot.to(dev)).cpu()
+    torch.cuda.synchronize()
+    sdg = {k: v.clone() for k, v in sd.items()}
+    keys = [k for k in to.trainable_keys(sdg) if ".adapt_mlp_" in k]
+    for k in keys:
+        sdg[k] = sdg[k].float().requires_grad_(True)
+    ctx_leaf = ctx.clone().requires_grad_(True)
+    ref = to.forward_train(sdg, x, heads=cfg["heads"], ctx=ctx_leaf)["hash_features"]
+    assert float((hf.cpu() - ref.detach()).norm() / ref.detach().norm()) < 5e-3
+    ref.backward(cot)
+    want = {k: sdg[k].grad for k in keys}
+    got = {}
+    it = iter(eng._views)
+    for l in range(layers):
+        for a in (1, 2):
+            for field in ADAPTER_FIELDS:
+                got[f"{VM}encoder.layers.{l}.adapt_mlp_{a}.{field}"] = next(it)[1].detach().float().cpu()
+    want["concept_tokens"], got["concept_tokens"] = ctx_leaf.grad[0], dct
+    _check_grads(got, want, floor_keys=())
+    eng.close()
