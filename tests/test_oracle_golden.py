@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/encoder_oracle.py) against golden vectors produced by the reference's own model code
 (tests/golden/encode_*.npz, generator oracle/gen_golden.py).  fp32, atol 2e-5 on every tapped stage."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -171,3 +173,33 @@ def test_attention_diversity_term_matches_reference():
         if ".layers.1.adapt_mlp_" not in k:       # the term acts through the last layer's attention: everything upstream of it moves
             changed += float((ref - torch.from_numpy(z["grad/" + k])).abs().max()) > 1e-3 * scale
     assert changed >= 10
+
+
+def test_full_size_seeded_fixture_pins_the_oracle_at_vit_b16():
+    """tests/golden/seeded_vit_b16.npz: the reference's own model at the headline size (ViT-B/16 x 12 layers, 201 tokens) on weights
+    rebuilt from a seed (checksummed), 2 images: eval outputs, and -- training mode -- gradient signatures (norm, projection on a
+    seeded direction) of all 168 adapter tensors for a seeded cotangent on hash_features."""
+    from conftest import GOLDEN
+    from oracle import seeded as gen
+    from oracle import train_oracle as to
+    z = np.load(os.path.join(GOLDEN, "seeded_vit_b16.npz"))
+    cfg, sd, x, cot = gen.seeded_inputs()
+    for k, v in sd.items():
+        if v.is_floating_point():
+            chk = z["chk/" + k]
+            assert abs(float(v.double().sum()) - chk[0]) <= 1e-9 * max(1.0, abs(chk[0])) and \
+                abs(float(v.double().pow(2).sum()) - chk[1]) <= 1e-9 * max(1.0, chk[1]), f"seeded weights drifted: {k}"
+    out = eo.encode(sd, x, heads=cfg["heads"])
+    for key in ("codes", "hash_features", "logits_cont", "logits_bin", "logits_concept", "image_features"):
+        ref = torch.from_numpy(z["out/" + key])
+        assert torch.allclose(out[key], ref, atol=1e-4, rtol=0), (key, float((out[key] - ref).abs().max()))
+    sdg = {k: v.clone() for k, v in sd.items()}
+    keys = [k for k in to.trainable_keys(sdg) if ".adapt_mlp_" in k] + ["hash_queries"]
+    for k in keys:
+        sdg[k] = sdg[k].float().requires_grad_(True)
+    to.forward_train(sdg, x, heads=cfg["heads"])["hash_features"].backward(cot)
+    assert len([k for k in z.files if k.startswith("sig/")]) == 169
+    for k in keys:
+        norm, proj = gen.signature(k, sdg[k].grad)
+        rn, rp = z["sig/" + k]
+        assert abs(norm - rn) <= 2e-3 * rn and abs(proj - rp) <= 2e-3 * rn, (k, norm, rn, proj, rp)
