@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/seeded_vit_b16.npz: the REFERENCE's own model (unmodified source from /root/reference, through
+"""Generate tests/golden/seeded_{vit_b16,vit_l14,vit_s16}.npz: the REFERENCE's own model (unmodified source from /root/reference, through
 oracle/_ref_shim.py) at the headline size -- ViT-B/16, 12 layers, D = 768, 201 tokens, adapters b = 384 -- on SEEDED weights and images.
 
 The weights (86 M parameters) are not stored: `concepthash_amd.synthetic.synthetic_state_dict(CONFIGS['vit_b16'], seed=...)` rebuilds them
@@ -8,7 +8,7 @@ them, the reference's eval outputs for 2 images, and -- for the training step --
 hash_features as SIGNATURES: per adapter tensor its L2 norm and its dot product with a seeded random direction (the full gradients
 would be 57 MB).
 
-Run in the build container only:   python -B oracle/gen_seeded_golden.py      (about a minute of CPU)
+Run in the build container only:   python -B oracle/gen_seeded_golden.py [config ...]     (a few minutes of CPU for all three)
 """
 import os
 import sys
@@ -24,11 +24,17 @@ import torch
 import _ref_shim as shim
 
 GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
-from oracle.seeded import BATCH, CONFIG, COT_SEED, DIR_SEED, IMG_SEED, NBIT, NCLASS, SD_SEED, direction, seeded_inputs, signature
+from oracle.seeded import COT_SEED, DIR_SEED, IMG_SEED, SD_SEED, SETUPS, direction, seeded_inputs, signature
 
 
 def main():
-    cfg, sd, x, cot = seeded_inputs()
+    for config in (sys.argv[1:] or list(SETUPS)):
+        generate(config)
+
+
+def generate(CONFIG):
+    NBIT, NCLASS, BATCH = SETUPS[CONFIG]
+    cfg, sd, x, cot = seeded_inputs(CONFIG)
     vd = dict(hidden_size=cfg["D"], intermediate_size=cfg["M"], num_hidden_layers=cfg["L"], num_attention_heads=cfg["heads"],
               image_size=cfg["image"], patch_size=cfg["patch"], projection_dim=cfg["P"])
     model = shim.build_reference_model(vd, nbit=NBIT, nclass=NCLASS, adapter_bottleneck_dim=cfg["b"], seed=1, center_dim=sd["center"].shape[1],
@@ -62,9 +68,9 @@ def main():
             payload["sig/" + k] = np.array(signature(k, p.grad))
             n += 1
     payload["sig/hash_queries"] = np.array(signature("hash_queries", model.hash_queries.grad))
-    path = os.path.join(GOLDEN, "seeded_vit_b16.npz")
+    path = os.path.join(GOLDEN, f"seeded_{CONFIG}.npz")
     np.savez_compressed(path, **payload)
-    print("seeded_vit_b16 ->", path, f"{os.path.getsize(path) / 1e3:.1f} KB, {n} adapter gradient signatures")
+    print(f"seeded_{CONFIG} ->", path, f"{os.path.getsize(path) / 1e3:.1f} KB, {n} adapter gradient signatures")
 
 
 if __name__ == "__main__":

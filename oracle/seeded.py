@@ -6,16 +6,19 @@ import torch
 
 from concepthash_amd import synthetic
 
-CONFIG, SD_SEED, IMG_SEED, COT_SEED, DIR_SEED, NBIT, NCLASS, BATCH = "vit_b16", 77, 5, 6, 7, 64, 200, 2
+SD_SEED, IMG_SEED, COT_SEED, DIR_SEED = 77, 5, 6, 7
+# config -> (nbit, nclass, batch): the BASELINE.json model sizes
+SETUPS = {"vit_b16": (64, 200, 2), "vit_l14": (128, 555, 2), "vit_s16": (16, 200, 2)}
 
 
-def seeded_inputs():
-    """(cfg, state_dict, images, cotangent): bf16-representable weights and images of the ViT-B/16 config, rebuilt from the seeds"""
-    cfg = synthetic.CONFIGS[CONFIG]
-    sd = synthetic.synthetic_state_dict(cfg, nbit=NBIT, nclass=NCLASS, seed=SD_SEED)
+def seeded_inputs(config="vit_b16"):
+    """(cfg, state_dict, images, cotangent): bf16-representable weights and images of a synthetic.CONFIGS entry, rebuilt from the seeds"""
+    nbit, nclass, batch = SETUPS[config]
+    cfg = synthetic.CONFIGS[config]
+    sd = synthetic.synthetic_state_dict(cfg, nbit=nbit, nclass=nclass, seed=SD_SEED)
     sd = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in sd.items()}
-    x = synthetic.synthetic_images(BATCH, cfg["image"], seed=IMG_SEED).to(torch.bfloat16).float()
-    cot = torch.randn(BATCH, 4, cfg["D"], generator=torch.Generator().manual_seed(COT_SEED))
+    x = synthetic.synthetic_images(batch, cfg["image"], seed=IMG_SEED).to(torch.bfloat16).float()
+    cot = torch.randn(batch, 4, cfg["D"], generator=torch.Generator().manual_seed(COT_SEED))
     return cfg, sd, x, cot
 
 

@@ -175,15 +175,17 @@ def test_attention_diversity_term_matches_reference():
     assert changed >= 10
 
 
-def test_full_size_seeded_fixture_pins_the_oracle_at_vit_b16():
-    """tests/golden/seeded_vit_b16.npz: the reference's own model at the headline size (ViT-B/16 x 12 layers, 201 tokens) on weights
-    rebuilt from a seed (checksummed), 2 images: eval outputs, and -- training mode -- gradient signatures (norm, projection on a
-    seeded direction) of all 168 adapter tensors for a seeded cotangent on hash_features."""
+@pytest.mark.parametrize("config", ["vit_b16", "vit_s16", "vit_l14"])
+def test_full_size_seeded_fixtures_pin_the_oracle(config):
+    """tests/golden/seeded_<config>.npz: the reference's own model at the BASELINE.json model sizes (ViT-B/16 x 12 layers, 201 tokens;
+    ViT-S/16 x 12; ViT-L/14 x 24, 261 tokens) on weights rebuilt from a seed (checksummed), 2 images: eval outputs, and -- training
+    mode -- gradient signatures (norm, projection on a seeded direction) of every adapter tensor for a seeded cotangent on
+    hash_features."""
     from conftest import GOLDEN
     from oracle import seeded as gen
     from oracle import train_oracle as to
-    z = np.load(os.path.join(GOLDEN, "seeded_vit_b16.npz"))
-    cfg, sd, x, cot = gen.seeded_inputs()
+    z = np.load(os.path.join(GOLDEN, f"seeded_{config}.npz"))
+    cfg, sd, x, cot = gen.seeded_inputs(config)
     for k, v in sd.items():
         if v.is_floating_point():
             chk = z["chk/" + k]
@@ -192,13 +194,13 @@ def test_full_size_seeded_fixture_pins_the_oracle_at_vit_b16():
     out = eo.encode(sd, x, heads=cfg["heads"])
     for key in ("codes", "hash_features", "logits_cont", "logits_bin", "logits_concept", "image_features"):
         ref = torch.from_numpy(z["out/" + key])
-        assert torch.allclose(out[key], ref, atol=1e-4, rtol=0), (key, float((out[key] - ref).abs().max()))
+        assert torch.allclose(out[key], ref, atol=2e-4, rtol=0), (key, float((out[key] - ref).abs().max()))
     sdg = {k: v.clone() for k, v in sd.items()}
     keys = [k for k in to.trainable_keys(sdg) if ".adapt_mlp_" in k] + ["hash_queries"]
     for k in keys:
         sdg[k] = sdg[k].float().requires_grad_(True)
     to.forward_train(sdg, x, heads=cfg["heads"])["hash_features"].backward(cot)
-    assert len([k for k in z.files if k.startswith("sig/")]) == 169
+    assert len([k for k in z.files if k.startswith("sig/")]) == 14 * cfg["L"] + 1
     for k in keys:
         norm, proj = gen.signature(k, sdg[k].grad)
         rn, rp = z["sig/" + k]

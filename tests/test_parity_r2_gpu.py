@@ -298,16 +298,17 @@ def test_outlier_residual_channels_through_full_depth(dev):
 
 
 # ---- (h) the headline model against REFERENCE output (weights rebuilt from a seed) ----------------------------------------------
-def test_vit_b16_full_depth_against_the_reference_itself(dev):
-    """tests/golden/seeded_vit_b16.npz (oracle/gen_seeded_golden.py): the reference's own LGHWithFixedPrompt at ViT-B/16 x 12 layers,
-    201 tokens, on weights rebuilt here from the seed (checksums in the fixture).  Encode: the HIP path vs reference output, same
+@pytest.mark.parametrize("config", ["vit_b16", "vit_s16", "vit_l14"])
+def test_full_depth_against_the_reference_itself(dev, config):
+    """tests/golden/seeded_<config>.npz (oracle/gen_seeded_golden.py): the reference's own LGHWithFixedPrompt at ViT-B/16 x 12 layers
+    (201 tokens), ViT-S/16 x 12 and ViT-L/14 x 24 (261 tokens), on weights rebuilt here from the seed (checksums in the fixture).  Encode: the HIP path vs reference output, same
     bounds as against the fp32 oracle.  Training: gradient signatures (norm, projection on a seeded direction) of all 168 adapter
     tensors for a seeded cotangent on hash_features -- the reference's autograd vs ch_train_backward."""
     from concepthash_amd.training import ADAPTER_FIELDS, TrainEngine, adapters_from_state_dict
     from conftest import GOLDEN
     from oracle import seeded as gen
-    z = np.load(os.path.join(GOLDEN, "seeded_vit_b16.npz"))
-    cfg, sd, x, cot = gen.seeded_inputs()
+    z = np.load(os.path.join(GOLDEN, f"seeded_{config}.npz"))
+    cfg, sd, x, cot = gen.seeded_inputs(config)
     for k in ("backbone.vision_model.encoder.layers.7.mlp.fc1.weight", "hash_fc.weight"):
         assert abs(float(sd[k].double().sum()) - z["chk/" + k][0]) <= 1e-9 * max(1.0, abs(z["chk/" + k][0]))
     enc = _encoder(sd, cfg["heads"], max_batch=2)
@@ -316,7 +317,7 @@ def test_vit_b16_full_depth_against_the_reference_itself(dev):
     for key in ("codes", "hash_features", "logits_cont", "logits_bin", "logits_concept", "image_features"):
         ref = torch.from_numpy(z["out/" + key])
         e, r = _rel_err(out[key].cpu(), ref), _rms_err(out[key].cpu(), ref)
-        print(f"seeded vit_b16 {key}: vs REFERENCE output {e:.2e} (rms {r:.2e})")
+        print(f"seeded {config} {key}: vs REFERENCE output {e:.2e} (rms {r:.2e})")
         assert e < 4e-2 and r < 1e-2, key
     ref_codes = torch.from_numpy(z["out/codes"])
     flips = (out["codes"].cpu() > 0) != (ref_codes > 0)
@@ -348,6 +349,6 @@ def test_vit_b16_full_depth_against_the_reference_itself(dev):
                 err = max(abs(norm - rn), abs(proj - rp)) / rn
                 worst = max(worst, (err, k))
                 assert err < 5e-2, (k, norm, rn, proj, rp)
-    print("seeded vit_b16 training: worst scale-gradient error / largest |ds|: %.2e (%s)" % worst_scale)
-    print("seeded vit_b16 training: worst adapter gradient signature error vs the reference's autograd: %.2e (%s)" % worst)
+    print(f"seeded {config} training: worst scale-gradient error / largest |ds|: %.2e (%s)" % worst_scale)
+    print(f"seeded {config} training: worst adapter gradient signature error vs the reference's autograd: %.2e (%s)" % worst)
     eng.close()
