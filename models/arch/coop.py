@@ -108,6 +108,10 @@ class LGHWithoutText(nn.Module):
             self.concept_ce = CosSim(D, nclass)
             self.trainable_params["concept_ce_centroids"] = self.concept_ce.centroids
         self.return_concept_attention = bool(kwargs.get("return_concept_attention", False))
+        # reference forward always returns every layer's hidden state (`image_hidden_states`, coop.py:474-486, 582-598); nothing on
+        # the encode-and-retrieve path reads them, so they are produced on request only -- by the per-layer parity tap
+        # ch_encode_hidden, one partial run of the encoder per layer (L + 1 runs: for inspection, not for throughput)
+        self.return_hidden_states = bool(kwargs.get("return_hidden_states", False))
         self._engine: Optional[ConceptHashEncoder] = None
         self._engine_key = None
         self.eval()
@@ -259,6 +263,8 @@ class LGHWithoutText(nn.Module):
                    # the reference returns every layer's hidden state / attention map; the fused path does not
                    # materialise them (retrieval never reads them)
                    "image_hidden_states": (), "hash_features": out["hash_features"], "attn_cache": None}
+        if self.return_hidden_states:     # (L + 1) x (B, N, D) fp32: after pre-LN, then after every encoder layer
+            outputs["image_hidden_states"] = tuple(eng.hidden_states(x, layer) for layer in range(eng.cfg["layers"] + 1))
         if self.return_concept_attention:
             # what the reference's consumers slice out of attn_cache[-1]: [:, :, -Q:, 1:-Q]  (B, heads, Q, Np)
             outputs["concept_attention"] = out["concept_attn"]

@@ -37,6 +37,15 @@ def test_model_class_reproduces_reference_outputs():
     assert torch.allclose(model.get_center().cpu(), torch.from_numpy(
         np.maximum(z["sd/center"] @ z["sd/text_projection.0.weight"].T + z["sd/text_projection.0.bias"], 0)
         @ z["sd/text_projection.2.weight"].T + z["sd/text_projection.2.bias"]), atol=1e-4)
+    # the reference's `image_hidden_states` contract, on request: embeddings + one state per layer, last one's concept rows = hash_features
+    model.return_hidden_states = True
+    with torch.no_grad():
+        hs = model(x)[1]["image_hidden_states"]
+    model.return_hidden_states = False
+    assert len(hs) == 3 and hs[0].shape == (x.shape[0], 21, 128)
+    for i, key in ((0, "h0"), (1, "h1"), (2, "h_last")):
+        assert _rel_err(hs[i].cpu(), torch.from_numpy(z["out/" + key])) < 2e-2, key
+    assert _rel_err(hs[-1][:, -4:, :].cpu(), out["hash_features"].cpu()) < 1e-6
     # parameters changed in place -> the engine is rebuilt, outputs change
     with torch.no_grad():
         model.hash_bn.bias.add_(1.0)
