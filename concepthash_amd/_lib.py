@@ -77,6 +77,7 @@ SIGNATURES = {
     "ch_trainer_refresh": (c_int, [c_void_p, c_void_p]),
     "ch_train_forward": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int32, c_int32, c_void_p]),
     "ch_debug_attention_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "ch_debug_wgrad": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "ch_debug_ln_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

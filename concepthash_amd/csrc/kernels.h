@@ -223,6 +223,8 @@ int ch_adapter_grads(const float *G, const float *cu, const float *T, const floa
 // bf16 / LayerNorm-folded / transposed working copies of `nad` adapters from the parameter arena (slot arrays, one slot per adapter)
 int ch_adapter_refresh(const float *params, int64_t stride, int nad, int D, int b, int bpad, bf16_t *down_wf, float *fold_c, float *fold_d,
                        bf16_t *up_w, bf16_t *up_wT, bf16_t *down_wgT, hipStream_t s);
+int ch_sgd_step_launch(float *p, const float *g, float *buf, int64_t n, float lr, float momentum, float wd, float dampening, int nesterov,
+                       int first, hipStream_t s);
 int ch_concept_rows_sum(const float *dH, int B, int ntok, int Q, int D, float *out, hipStream_t s);
 int ch_scatter_concept_rows(const float *dhf, int B, int ntok, int Q, int D, float *dH, bf16_t *dHb, hipStream_t s);
 // compact head rows [B*(1+Q), D] (CLS, concept tokens) -> full token rows [B*ntok, D], zeros elsewhere; fp32 (is_f32) or bf16

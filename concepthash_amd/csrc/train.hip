@@ -515,6 +515,14 @@ extern "C" int ch_train_backward(ch_trainer *t, const float *d_hash_features, co
     return ch_small_ln_bwd(t->dctx_sum[0], t->ctx, t->m->pre_w, Q, D, c.ln_eps, d_concept_tokens, s);
 }
 
+// torch.optim.SGD semantics (maximize False) over a flat fp32 array, e.g. the adapter arena: see include/concepthash_hip.h
+extern "C" int ch_sgd_step(float *params, const float *grads, float *momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                           float dampening, int32_t nesterov, int32_t first_step, void *stream) {
+    CH_REQUIRE(params && grads && (momentum == 0.f || momentum_buf), "sgd_step: null argument");
+    CH_REQUIRE(n > 0, "sgd_step: empty array");
+    return ch_sgd_step_launch(params, grads, momentum_buf, n, lr, momentum, weight_decay, dampening, nesterov, first_step, (hipStream_t)stream);
+}
+
 // ---- kernel taps for the tests -------------------------------------------------------------------------------------------------
 extern "C" int ch_debug_attention_bwd(const void *qkv, const void *dO, int32_t B, int32_t ntok, int32_t heads, void *dqkv, const float *dpext,
                                       int32_t ncon, void *stream) {

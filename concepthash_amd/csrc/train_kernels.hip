@@ -539,6 +539,24 @@ __global__ __launch_bounds__(1024) void adapter_grads_red_kernel(const float *__
     }
 }
 
+// torch.optim.SGD (maximize False) over one flat fp32 array: d = g + wd * p; buf = d (first step) or momentum * buf + (1 - dampening) * d;
+// p -= lr * (nesterov ? d + momentum * buf : buf).  One launch over the 14 M-parameter adapter arena instead of the per-tensor
+// foreach kernels over its 168 views.
+__global__ __launch_bounds__(256) void sgd_step_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ buf, int64_t n4,
+                                                       float lr, float momentum, float wd, float dampening, int nesterov, int first) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 pv = *(const f32x4 *)(p + i * 4);
+        f32x4 d = *(const f32x4 *)(g + i * 4) + pv * wd;
+        f32x4 upd = d;
+        if (momentum != 0.f) {
+            f32x4 b = first ? d : *(const f32x4 *)(buf + i * 4) * momentum + d * (1.0f - dampening);
+            *(f32x4 *)(buf + i * 4) = b;
+            upd = nesterov ? d + b * momentum : b;
+        }
+        *(f32x4 *)(p + i * 4) = pv - upd * lr;
+    }
+}
+
 // rows of the concept tokens: out[q][:] = sum_b dH[b*ntok + ntok - Q + q][:]   (one block per (q, 256-column slab))
 __global__ __launch_bounds__(256) void concept_rows_sum_kernel(const float *__restrict__ dH, int B, int ntok, int Q, int D,
                                                                float *__restrict__ out) {
@@ -738,6 +756,15 @@ int ch_adapter_grads(const float *G, const float *cu, const float *T, const floa
     hipLaunchKernelGGL(adapter_grads_elem_kernel, dim3(AG_BLOCKS), dim3(256), 0, s, G, cu, T, cd, params, D, b, bpad, grads, ws);
     CH_LAUNCH_CHECK();
     hipLaunchKernelGGL(adapter_grads_red_kernel, dim3(1 + (D + 15) / 16), dim3(1024), 0, s, T, cd, params, D, b, grads, ws);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+int ch_sgd_step_launch(float *p, const float *g, float *buf, int64_t n, float lr, float momentum, float wd, float dampening, int nesterov,
+                       int first, hipStream_t s) {
+    CH_REQUIRE(n % 4 == 0, "sgd_step: element count must be a multiple of 4 (pad the arena)");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(n4, 256), 4096)), dim3(256), 0, s, p, g, buf, n4, lr,
+                       momentum, wd, dampening, nesterov, first);
     CH_LAUNCH_CHECK();
     return 0;
 }

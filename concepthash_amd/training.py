@@ -44,8 +44,10 @@ class TrainEngine:
         n = int(self.lib.ch_adapter_arena_numel(self.encoder._h))
         if n <= 0:
             raise RuntimeError("the model has no adapters: nothing to train in the encoder")
-        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+        npad = (n + 3) // 4 * 4          # ch_sgd_step works on float4s; the pad elements stay zero
+        self.params = torch.zeros(npad, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(npad, dtype=torch.float32, device=self.device)
+        self.momentum_buf = None         # created by the fused SGD step (fuse_adapter_sgd)
         self._views: List[tuple] = []   # (parameter, grad view)
         D, b, L = self.cfg["dim"], self.cfg["adapter_dim"], self.cfg["layers"]
         sizes = (D, D, b * D, b, D * b, D, 1)
@@ -170,6 +172,47 @@ class EncoderFunction(torch.autograd.Function):
                                "library keeps the saved activations of the last forward only (one forward -> one backward)")
         dct = ctx.engine.backward(d_hf, d_attn if ctx.want_attn else None)
         return dct.view(ctx.ct_shape), None, None, None, None
+
+
+def fuse_adapter_sgd(optimizer, model):
+    """torch.optim.SGD over the adapters = foreach kernels over 168 views of one arena (0.45 ms per step for B/16).  When the first
+    param group is exactly the adapters of `model` and its training engine exists, `optimizer.step()` updates that group with ONE
+    launch over the arena (`ch_sgd_step`, same arithmetic: weight decay, momentum buffer, dampening, nesterov) and lets torch step
+    the remaining groups.  Anything else (another optimizer class, maximize, a closure, the engine not built yet, a missing gradient)
+    falls through to the unmodified step.  Call BEFORE the lr scheduler is created (schedulers wrap `optimizer.step`)."""
+    if type(optimizer) is not torch.optim.SGD:
+        return optimizer
+    torch_step = optimizer.step
+    fused = {"steps": 0}
+
+    def step(self, closure=None):      # installed as a bound method: lr schedulers wrap `optimizer.step.__func__`
+        eng = getattr(model, "_train_engine", None)
+        g0 = optimizer.param_groups[0]
+        params = g0["params"]
+        ok = (closure is None and eng is not None and not g0.get("maximize", False) and len(params) == len(eng._views)
+              and {id(p) for p in params} == {id(v) for v, _ in eng._views} and all(p.grad is not None for p in params))
+        if not ok:
+            return torch_step(closure)
+        first = eng.momentum_buf is None
+        if first and g0["momentum"] != 0:
+            eng.momentum_buf = torch.zeros_like(eng.params)
+        with torch.cuda.device(eng.device):
+            _lib.check(eng.lib.ch_sgd_step(_lib.ptr(eng.params), _lib.ptr(eng.grads), _lib.ptr(eng.momentum_buf), eng.params.numel(),
+                                           float(g0["lr"]), float(g0["momentum"]), float(g0["weight_decay"]), float(g0["dampening"]),
+                                           int(bool(g0["nesterov"])), int(first), _lib.stream_ptr()), "ch_sgd_step")
+        eng.mark_stale()                                   # the library's working copies are re-derived before the next forward
+        torch.autograd.graph.increment_version(params[0])  # ... and the model's evaluation engine sees changed parameters
+        fused["steps"] += 1
+        g0["params"] = []
+        try:
+            return torch_step()
+        finally:
+            g0["params"] = params
+
+    import types
+    optimizer.step = types.MethodType(step, optimizer)
+    optimizer.fused_adapter_steps = fused
+    return optimizer
 
 
 def adapters_from_state_dict(state_dict, layers: int, dim: int, bottleneck: int) -> list:

@@ -128,6 +128,11 @@ int ch_train_forward(ch_trainer *t, const void *images, int32_t image_dtype, int
 /* Backward of the last ch_train_forward: d_hash_features [B,Q,D] fp32 and (optional, NULL) d_concept_attn [B,heads,Q,Np] fp32 in;
  * adapter gradients into the gradient arena, d_concept_tokens [Q,D] fp32 out. */
 int ch_train_backward(ch_trainer *t, const float *d_hash_features, const float *d_concept_attn, float *d_concept_tokens, void *stream);
+/* torch.optim.SGD.step (configs/optim/sgd.yaml; maximize False) over ONE flat fp32 array -- the adapter arena: d = g + weight_decay * p;
+ * buf = d on the first step, else momentum * buf + (1 - dampening) * d; p -= lr * (nesterov ? d + momentum * buf : buf).
+ * n must be a multiple of 4 (ch_adapter_arena_numel is padded by the caller if not). */
+int ch_sgd_step(float *params, const float *grads, float *momentum_buf, int64_t n, float lr, float momentum, float weight_decay,
+                float dampening, int32_t nesterov, int32_t first_step, void *stream);
 /* Kernel taps of the training step (tests): see train_kernels.hip / attention_bwd.hip. */
 int ch_debug_attention_bwd(const void *qkv, const void *dO, int32_t B, int32_t ntok, int32_t heads, void *dqkv, const float *dpext,
                            int32_t ncon, void *stream);

@@ -388,3 +388,43 @@ def test_engine_gradients_at_real_widths(config, layers, batch):
     want["concept_tokens"], got["concept_tokens"] = ctx_leaf.grad[0], dct
     _check_grads(got, want, floor_keys=())
     eng.close()
+
+
+def test_fused_arena_sgd_equals_torch_sgd():
+    """`fuse_adapter_sgd`: the adapters' param group updated by one launch over the arena (ch_sgd_step) -- against torch.optim.SGD
+    itself on a second copy of the model, three steps with momentum, weight decay and a changing lr: parameters equal to fp32
+    rounding, the other param groups bit-equal, the evaluation path sees the updates."""
+    from concepthash_amd.training import fuse_adapter_sgd
+    sd, z = load_fixture("train_tiny")
+    x = fixture_images(z).cuda()
+    labels = torch.from_numpy(z["in/labels"]).cuda()
+    models, opts = [], []
+    for fused in (False, True):
+        m = _train_model(sd, z)
+        groups = [{"params": list(m.get_adapter().parameters())}, {"params": list(m.get_training_modules().parameters())}]
+        o = torch.optim.SGD(groups, lr=0.05, momentum=0.9, weight_decay=5e-4)
+        if fused:
+            o = fuse_adapter_sgd(o, m)
+        models.append(m)
+        opts.append(o)
+    crit = _crit()
+    for it in range(3):
+        for m, o in zip(models, opts):
+            for g in o.param_groups:
+                g["lr"] = 0.05 / (it + 1)
+            o.zero_grad()
+            crit(m(x)[1], labels).backward()
+            o.step()
+    assert opts[1].fused_adapter_steps["steps"] == 3
+    a = dict(models[0].named_parameters(remove_duplicate=False))
+    b = dict(models[1].named_parameters(remove_duplicate=False))
+    for k in a:
+        if ".adapt_mlp_" in k and k.startswith("backbone."):
+            assert torch.allclose(a[k], b[k], rtol=2e-5, atol=1e-7), k
+        elif not k.startswith(("adapter_params.", "trainable_params.")):
+            assert torch.allclose(a[k], b[k], rtol=1e-4, atol=1e-6), k
+    for m in models:
+        m.eval()
+    with torch.no_grad():
+        c0, c1 = models[0](x)[1]["codes"], models[1](x)[1]["codes"]
+    assert float((c0 - c1).abs().max()) < 2e-2 and float((c1 - torch.from_numpy(z["out/codes"]).cuda()).abs().max()) > 1e-2

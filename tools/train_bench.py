@@ -88,7 +88,10 @@ def full_step(a, cfg, sd, batches):
     model.requires_grad_(False)
     for p in params:
         p.requires_grad_(True)
-    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    from concepthash_amd.training import fuse_adapter_sgd
+    groups = [{"params": list(model.get_adapter().parameters())}, {"params": list(model.get_training_modules().parameters())}]
+    # as trainers/base.py builds it: torch.optim.SGD with the adapters' group updated by one launch over the arena (ch_sgd_step)
+    opt = fuse_adapter_sgd(torch.optim.SGD(groups, lr=1e-3, momentum=0.9, weight_decay=5e-4), model)
     for B in batches:
         x = synthetic.synthetic_images(B, cfg["image"]).to("cuda", torch.bfloat16)
         y = torch.randint(0, C, (B,), device="cuda")
@@ -103,6 +106,7 @@ def full_step(a, cfg, sd, batches):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / a.steps * 1e3
         print(json.dumps({"config": a.config, "batch": B, "full_step_ms": round(ms, 3), "images_per_s": round(B / ms * 1e3, 1),
+                          "fused_adapter_sgd_steps": opt.fused_adapter_steps["steps"],
                           "what": "model.train() forward + LGHLoss + backward + SGD step, wall clock"}))
 
 

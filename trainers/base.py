@@ -146,6 +146,10 @@ class BaseTrainer:
                 count += p.numel()
         logging.info("Number of trainable params: %.3f%s", count / (1e6 if count >= 1e6 else 1e3), "M" if count >= 1e6 else "K")
         self.optimizer = instantiate(self.config.optim, groups)
+        if self.config.model.get("has_adapter", False):
+            # the adapters are 168 views of one arena: update them with one launch instead of torch's per-tensor kernels
+            from concepthash_amd.training import fuse_adapter_sgd
+            self.optimizer = fuse_adapter_sgd(self.optimizer, self.model)
         self.scheduler = instantiate(self.config.scheduler, self.optimizer)
 
     def get_learning_rate(self):
