@@ -195,7 +195,11 @@ def fuse_adapter_sgd(optimizer, model):
             return torch_step(closure)
         first = eng.momentum_buf is None
         if first and g0["momentum"] != 0:
-            eng.momentum_buf = torch.zeros_like(eng.params)
+            restored = getattr(optimizer, "restored_adapter_momentum", None)
+            if restored is not None and restored.numel() == eng.params.numel():
+                eng.momentum_buf, first = restored.to(eng.device, torch.float32).clone(), False
+            else:
+                eng.momentum_buf = torch.zeros_like(eng.params)
         with torch.cuda.device(eng.device):
             _lib.check(eng.lib.ch_sgd_step(_lib.ptr(eng.params), _lib.ptr(eng.grads), _lib.ptr(eng.momentum_buf), eng.params.numel(),
                                            float(g0["lr"]), float(g0["momentum"]), float(g0["weight_decay"]), float(g0["dampening"]),

@@ -160,12 +160,17 @@ class BaseTrainer:
 
     def save_training_state(self, fn):
         os.makedirs(os.path.dirname(fn) or ".", exist_ok=True)
-        torch.save({"optim": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict()}, fn)
+        state = {"optim": self.optimizer.state_dict(), "scheduler": self.scheduler.state_dict()}
+        eng = getattr(self.model, "_train_engine", None)
+        if eng is not None and eng.momentum_buf is not None:      # the adapters' momentum lives in the fused arena step, not in torch's state
+            state["adapter_momentum"] = eng.momentum_buf.cpu()
+        torch.save(state, fn)
 
     def load_training_state(self, fn):
         sd = torch.load(fn, map_location="cpu")
         self.optimizer.load_state_dict(sd["optim"])
         self.scheduler.load_state_dict(sd["scheduler"])
+        self.optimizer.restored_adapter_momentum = sd.get("adapter_momentum")   # picked up by the fused arena step on its first call
 
     def train_one_batch(self, *args, **kwargs):
         raise NotImplementedError
