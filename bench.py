@@ -415,9 +415,16 @@ def train_block(torch, syn, sd, cfg, B, dev):
                              "backward_ms": round(s_b * 1e3, 3), "tflops": round((fwd_f + bwd_f) * b / s_all / 1e12, 1),
                              "mfma_frac": round((fwd_f + bwd_f) * b / s_all / 1e12 / PEAK_BF16_TFLOPS, 4)}
     out["trainer_gib"] = round(eng.device_bytes / 2 ** 30, 2)
-    out["note"] = ("adapters + concept tokens trained, backbone frozen; bf16 operands, fp32 accumulation / residual gradient / "
-                   "parameter gradients; never used for `value`")
     eng.close()
+    eng = None
+    # the whole step through the drop-in surface (model.train() forward, LGHLoss, backward, SGD step), wall clock
+    from concepthash_amd.training import benchmark_full_step
+    for b, r in benchmark_full_step(cfg, sd, sorted({min(32, B), B}), steps=5, warmup=2).items():
+        out[f"batch_{b}"]["full_step_ms"] = r["full_step_ms"]
+        out[f"batch_{b}"]["full_step_images_per_s"] = r["images_per_s"]
+    out["note"] = ("adapters + concept tokens trained, backbone frozen; bf16 operands, fp32 accumulation / residual gradient / "
+                   "parameter gradients; ms_per_step = the two C-ABI calls (HIP events), full_step_ms = the whole step through the "
+                   "Python surface incl. head, loss and optimizer (wall clock); never used for `value`")
     return out
 
 

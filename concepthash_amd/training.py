@@ -247,3 +247,51 @@ def encoder_step_flops(cfg: dict) -> tuple:
 
 def adapter_modules(vision_model) -> list:
     return [(layer.adapt_mlp_1, layer.adapt_mlp_2) for layer in vision_model.encoder.layers]
+
+
+def benchmark_full_step(cfg: dict, state_dict, batches, steps: int = 10, warmup: int = 3) -> dict:
+    """Wall clock of the whole training step through the drop-in surface -- the reference's train_one_batch (trainers/coop.py:107-131):
+    `LGHWithFixedPrompt` in train mode, `LGHLoss` (shipped terms), `loss.backward()`, `torch.optim.SGD.step()` with the adapters' group
+    fused (fuse_adapter_sgd), synchronised once per measurement.  cfg: a concepthash_amd.synthetic.CONFIGS entry."""
+    import time
+
+    from concepthash_amd import config as cfglib
+    from concepthash_amd import synthetic
+    from models.arch.coop import LGHWithFixedPrompt
+    from models.backbone.clip import CLIP
+    from models.loss.coop import LGHLoss
+    dims = dict(hidden_size=cfg["D"], num_hidden_layers=cfg["L"], num_attention_heads=cfg["heads"], intermediate_size=cfg["M"],
+                patch_size=cfg["patch"], image_size=cfg["image"], projection_dim=cfg["P"], hidden_act="quick_gelu")
+    upt = cfglib.DictConfig(multi=True, num_heads=8, dropout=0.1, ensemble_method="concat", single_hash_fc=True, hash_pe=True)
+    C, cd = state_dict["center"].shape
+    nbit = state_dict["hash_fc.weight"].shape[0] * 4
+    tp = torch.nn.Sequential(torch.nn.Linear(cd, cd), torch.nn.ReLU(), torch.nn.Linear(cd, nbit))
+    model = LGHWithFixedPrompt(CLIP(dims, allow_random_init=True), nbit, C, 4, add_bn=True, upt_config=upt, fixed_center=torch.zeros(C, cd),
+                               text_projection=tp, has_adapter=True, adapter_bottleneck_dim=cfg["b"], concept_reg=True)
+    model.load_state_dict(state_dict)
+    model = model.cuda().train()
+    model.train_max_batch = max(batches)
+    crit = LGHLoss(margin=0.2, scale=8, loss_scales=dict(bin_logits=1, cont_logits=1, concept_logits=1), ncontext=4)
+    groups = [{"params": list(model.get_adapter().parameters())}, {"params": list(model.get_training_modules().parameters())}]
+    model.requires_grad_(False)
+    for g in groups:
+        for p in g["params"]:
+            p.requires_grad_(True)
+    opt = fuse_adapter_sgd(torch.optim.SGD(groups, lr=1e-3, momentum=0.9, weight_decay=5e-4), model)
+    out = {}
+    for B in batches:
+        x = synthetic.synthetic_images(B, cfg["image"]).to("cuda", torch.bfloat16)
+        y = torch.randint(0, C, (B,), device="cuda")
+        for it in range(warmup + steps):
+            if it == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            opt.zero_grad()
+            crit(model(x)[1], y).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[B] = {"full_step_ms": round(ms, 3), "images_per_s": round(B / ms * 1e3, 1),
+                  "what": "model.train() forward + LGHLoss + backward + SGD step (adapter group fused), wall clock"}
+    model._drop_train_engine()
+    return out

@@ -65,49 +65,9 @@ def main():
 
 
 def full_step(a, cfg, sd, batches):
-    """The reference's train_one_batch (trainers/coop.py:107-131) on this path: concept-token generator, head, loss and optimizer on
-    torch around the HIP encoder.  Wall clock per step, synchronised once per step."""
-    import time
-
-    from concepthash_amd import config as cfglib
-    from models.arch.coop import LGHWithFixedPrompt
-    from models.backbone.clip import CLIP
-    from models.loss.coop import LGHLoss
-    dims = dict(hidden_size=cfg["D"], num_hidden_layers=cfg["L"], num_attention_heads=cfg["heads"], intermediate_size=cfg["M"],
-                patch_size=cfg["patch"], image_size=cfg["image"], projection_dim=cfg["P"], hidden_act="quick_gelu")
-    upt = cfglib.DictConfig(multi=True, num_heads=8, dropout=0.1, ensemble_method="concat", single_hash_fc=True, hash_pe=True)
-    C, cd = sd["center"].shape
-    tp = torch.nn.Sequential(torch.nn.Linear(cd, cd), torch.nn.ReLU(), torch.nn.Linear(cd, 64))
-    model = LGHWithFixedPrompt(CLIP(dims, allow_random_init=True), 64, C, 4, add_bn=True, upt_config=upt, fixed_center=torch.zeros(C, cd),
-                               text_projection=tp, has_adapter=True, adapter_bottleneck_dim=cfg["b"], concept_reg=True)
-    model.load_state_dict(sd)
-    model = model.cuda().train()
-    model.train_max_batch = max(batches)
-    crit = LGHLoss(margin=0.2, scale=8, loss_scales=dict(bin_logits=1, cont_logits=1, concept_logits=1), ncontext=4)
-    params = list(model.get_adapter().parameters()) + list(model.get_training_modules().parameters())
-    model.requires_grad_(False)
-    for p in params:
-        p.requires_grad_(True)
-    from concepthash_amd.training import fuse_adapter_sgd
-    groups = [{"params": list(model.get_adapter().parameters())}, {"params": list(model.get_training_modules().parameters())}]
-    # as trainers/base.py builds it: torch.optim.SGD with the adapters' group updated by one launch over the arena (ch_sgd_step)
-    opt = fuse_adapter_sgd(torch.optim.SGD(groups, lr=1e-3, momentum=0.9, weight_decay=5e-4), model)
-    for B in batches:
-        x = synthetic.synthetic_images(B, cfg["image"]).to("cuda", torch.bfloat16)
-        y = torch.randint(0, C, (B,), device="cuda")
-        for it in range(a.warmup + a.steps):
-            if it == a.warmup:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            opt.zero_grad()
-            loss = crit(model(x)[1], y)
-            loss.backward()
-            opt.step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / a.steps * 1e3
-        print(json.dumps({"config": a.config, "batch": B, "full_step_ms": round(ms, 3), "images_per_s": round(B / ms * 1e3, 1),
-                          "fused_adapter_sgd_steps": opt.fused_adapter_steps["steps"],
-                          "what": "model.train() forward + LGHLoss + backward + SGD step, wall clock"}))
+    from concepthash_amd.training import benchmark_full_step
+    for B, r in benchmark_full_step(cfg, sd, batches, a.steps, a.warmup).items():
+        print(json.dumps(dict(config=a.config, batch=B, **r)))
 
 
 if __name__ == "__main__":
