@@ -23,7 +23,7 @@
 namespace {
 
 constexpr int HD = 64;
-constexpr int NW = 4;
+constexpr int NW = 8;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -33,7 +33,7 @@ typedef __attribute__((address_space(3))) v4s lds_v4s;
 // concept-token attention rows the forward can tap (attention.hip TAP; consumer: the attention-diversity term of the loss,
 // models/loss/coop.py:164-189) -- is added to dP = dO V^T on those (query, key) pairs, in both phases.
 template <int KB, bool EXT>
-__global__ __launch_bounds__(NW * 64, 2) void attention_bwd_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dO, int ntok,
+__global__ __launch_bounds__(NW * 64, 4) void attention_bwd_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dO, int ntok,
                                                                int heads, float scale_log2e, bf16_t *__restrict__ dqkv,
                                                                const float *__restrict__ dpext, int ncon) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -84,11 +84,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_bwd_kernel(const bf16_t 
         f0 = *(const bf16x8 *)(mat + (size_t)r * ldm + fq * 8);
         f1 = *(const bf16x8 *)(mat + (size_t)r * ldm + fq * 8 + 32);
     };
-    bf16x8 nq0, nq1, ng0, ng1;     // the next tile's fragments, requested one tile ahead
-    if (wid < QT) {
-        row_frag(base, ld, wid, nq0, nq1);
-        row_frag(gbase, D, wid, ng0, ng1);
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -96,41 +91,48 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_bwd_kernel(const bf16_t 
     for (int qt = wid; qt < QT; qt += NW) {
         const int q = qt * 16 + fr;
         const bool qvalid = q < ntok;
-        const bf16x8 qf0 = nq0, qf1 = nq1, gf0 = ng0, gf1 = ng1;
-        if (qt + NW < QT) {
-            row_frag(base, ld, qt + NW, nq0, nq1);
-            row_frag(gbase, D, qt + NW, ng0, ng1);
-        }
-        f32x4 st[KT], dp[KT];
+        bf16x8 qf0, qf1, gf0, gf1;      // not prefetched a tile ahead: 16 VGPRs that the four-waves-per-SIMD budget does not have
+        row_frag(base, ld, qt, qf0, qf1);
+        row_frag(gbase, D, qt, gf0, gf1);
+        // Register budget: only S^T / P^T of the tile (KT x 4 values) stays live; dP^T = V dO^T is RECOMPUTED where it is needed (once
+        // for D_q, once for dS) instead of kept -- 28 more MFMAs per query tile on a pipe that is a quarter busy, 56 fewer VGPRs, so
+        // that four waves per SIMD fit (the kernel is bound by its dependent LDS -> MFMA -> exp -> MFMA chains, not by throughput).
+        f32x4 st[KT];
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             const bf16x8 k0 = *(const bf16x8 *)(Ks + kt * 2048 + off0), k1 = *(const bf16x8 *)(Ks + kt * 2048 + off1);
-            const bf16x8 v0 = *(const bf16x8 *)(Vs + kt * 2048 + off0), v1 = *(const bf16x8 *)(Vs + kt * 2048 + off1);
-            f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf0, a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf1, a, 0, 0, 0);
+            st[kt] = a;   // S^T[key = kt*16 + 4*fq + r][query fr]
+        }
+        const bool ext_row = EXT && qt * 16 + 15 >= q_con0 && q >= q_con0 && qvalid;
+        const float *erow = ext_row ? ext + (size_t)(q - q_con0) * npatch : nullptr;
+        auto dp_tile = [&](int kt) {   // dP^T[key = kt*16 + 4*fq + r][query fr] (+ the cotangent on the probabilities, EXT)
+            const bf16x8 v0 = *(const bf16x8 *)(Vs + kt * 2048 + off0), v1 = *(const bf16x8 *)(Vs + kt * 2048 + off1);
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, gf0, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, gf1, c, 0, 0, 0);
-            st[kt] = a;   // S^T[key = kt*16 + 4*fq + r][query fr]
-            dp[kt] = c;   // dP^T, same layout
-        }
-        if constexpr (EXT) {
-            if (qt * 16 + 15 >= q_con0 && q >= q_con0 && qvalid) {
-                const float *row = ext + (size_t)(q - q_con0) * npatch;
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
+            if constexpr (EXT) {
+                if (ext_row) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = kt * 16 + fq * 4 + r;
-                        if (key >= 1 && key <= npatch) dp[kt][r] += row[key - 1];
+                        if (key >= 1 && key <= npatch) c[r] += erow[key - 1];
                     }
+                }
             }
-        }
+            return c;
+        };
+        // keys >= ntok exist only in the last (KP - ntok + 15) / 16 <= 2 key tiles: mask those under a wave-uniform test (the PMC
+        // counters show this kernel bound by VALU issue -- ~2,300 non-MFMA VALU instructions per wave against ~440 MFMAs)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int kt = KT - 2; kt < KT; ++kt)
+            if (kt >= 0 && kt * 16 + 16 > ntok) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (kt * 16 + fq * 4 + r >= ntok) st[kt][r] = -1e30f;
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + fq * 4 + r >= ntok) st[kt][r] = -1e30f;
+            }
         float mx = -1e30f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_bwd_kernel(const bf16_t 
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mxs = mx * scale_log2e;
-        float sum = 0.f, pd = 0.f;
+        float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -147,10 +149,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_bwd_kernel(const bf16_t 
                 const float e = __builtin_amdgcn_exp2f(st[kt][r] * scale_log2e - mxs);
                 st[kt][r] = e;
                 sum += e;
-                pd += e * dp[kt][r];
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
+        float pd = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            const f32x4 c = dp_tile(kt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pd += st[kt][r] * c[r];
+        }
         pd += __shfl_xor(pd, 16, 64);
         pd += __shfl_xor(pd, 32, 64);
         const float inv = 1.0f / sum;
@@ -167,10 +175,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_bwd_kernel(const bf16_t 
                 bf16x8 v;
                 uint32_t u[4];
             } pf;
-            pf.u[0] = pack_bf16x2(w * st[2 * kb][0] * (dp[2 * kb][0] - Dq), w * st[2 * kb][1] * (dp[2 * kb][1] - Dq));
-            pf.u[1] = pack_bf16x2(w * st[2 * kb][2] * (dp[2 * kb][2] - Dq), w * st[2 * kb][3] * (dp[2 * kb][3] - Dq));
-            pf.u[2] = pack_bf16x2(w * st[2 * kb + 1][0] * (dp[2 * kb + 1][0] - Dq), w * st[2 * kb + 1][1] * (dp[2 * kb + 1][1] - Dq));
-            pf.u[3] = pack_bf16x2(w * st[2 * kb + 1][2] * (dp[2 * kb + 1][2] - Dq), w * st[2 * kb + 1][3] * (dp[2 * kb + 1][3] - Dq));
+            const f32x4 c0 = dp_tile(2 * kb), c1 = dp_tile(2 * kb + 1);
+            pf.u[0] = pack_bf16x2(w * st[2 * kb][0] * (c0[0] - Dq), w * st[2 * kb][1] * (c0[1] - Dq));
+            pf.u[1] = pack_bf16x2(w * st[2 * kb][2] * (c0[2] - Dq), w * st[2 * kb][3] * (c0[3] - Dq));
+            pf.u[2] = pack_bf16x2(w * st[2 * kb + 1][0] * (c1[0] - Dq), w * st[2 * kb + 1][1] * (c1[1] - Dq));
+            pf.u[3] = pack_bf16x2(w * st[2 * kb + 1][2] * (c1[2] - Dq), w * st[2 * kb + 1][3] * (c1[3] - Dq));
             union {
                 bf16x8 v;
                 v4s hh[2];
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_bwd_kernel(const bf16_t 
     for (int kt = wid; kt < QT; kt += NW) {
         const int key = kt * 16 + fr;
         const bool kvalid = key < ntok;
+        const bool edge_tile = kt * 16 + 16 > ntok;
         if (kt != wid) {
             row_frag(base + D, ld, kt, k0, k1);
             row_frag(base + 2 * D, ld, kt, v0, v1);
@@ -245,7 +255,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_bwd_kernel(const bf16_t 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const f32x4 sv = *(const f32x4 *)(stat + (qt * 16 + fq * 4 + r) * 4);  // (mxs, inv or 0, D_q)
-                const float pr = kvalid ? __builtin_amdgcn_exp2f(s4[r] * scale_log2e - sv[0]) * sv[1] : 0.f;
+                float pr = __builtin_amdgcn_exp2f(s4[r] * scale_log2e - sv[0]) * sv[1];
+                if (edge_tile && !kvalid) pr = 0.f;   // only the tile that straddles the sequence end has invalid keys (wave-uniform test)
                 p[r] = pr;
                 ds[r] = 0.125f * pr * (d4[r] - sv[2]);
             }
