@@ -41,7 +41,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bwd_kernel(const bf16_t 
     constexpr int KP = KB * 32;  // padded rows (keys and queries)
     char *Ks = smem, *Vs = smem + KP * 128;    // phase A: K, V
     char *Qs = smem, *Gs = smem + KP * 128;    // phase B: Q, dO (same storage, restaged after phase A)
-    float *stat = (float *)(smem + 2 * KP * 128);   // [KP][4]: mxs, inv, D_q, -
+    float *stat = (float *)(smem + 2 * KP * 128);   // [KP][4]: lse (log2 domain), D_q / 8, -, -
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,7 +163,9 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bwd_kernel(const bf16_t 
         pd += __shfl_xor(pd, 32, 64);
         const float inv = 1.0f / sum;
         const float Dq = pd * inv;
-        if (fq == 0) *(f32x4 *)(stat + q * 4) = f32x4{mxs, qvalid ? inv : 0.f, Dq, 0.f};
+        // per query for phase B: lse = mxs + log2(sum) so that P = exp2(s * scale_log2e - lse) needs no multiply by 1/sum (an invalid
+        // query gets lse = 1e30 -> P = 0), and D_q / 8 so that dS = P * fma(dP, 0.125, -D_q/8): two VALU ops fewer per probability
+        if (fq == 0) *(f32x4 *)(stat + q * 4) = f32x4{qvalid ? mxs + __builtin_amdgcn_logf(sum) : 1e30f, 0.125f * Dq, 0.f, 0.f};
         // dS^T = 0.125 * P^T o (dP^T - D_q), as the bf16 B operand; logical k = 8*fq + j <-> key 32*kb + (j < 4 ? 4*fq + j : 16 + 4*fq + j - 4)
         f32x4 o[4];
 #pragma unroll
@@ -254,11 +256,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bwd_kernel(const bf16_t 
             float p[4], ds[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const f32x4 sv = *(const f32x4 *)(stat + (qt * 16 + fq * 4 + r) * 4);  // (mxs, inv or 0, D_q)
-                float pr = __builtin_amdgcn_exp2f(s4[r] * scale_log2e - sv[0]) * sv[1];
+                const f32x4 sv = *(const f32x4 *)(stat + (qt * 16 + fq * 4 + r) * 4);  // (lse, D_q / 8)
+                float pr = __builtin_amdgcn_exp2f(s4[r] * scale_log2e - sv[0]);
                 if (edge_tile && !kvalid) pr = 0.f;   // only the tile that straddles the sequence end has invalid keys (wave-uniform test)
                 p[r] = pr;
-                ds[r] = 0.125f * pr * (d4[r] - sv[2]);
+                ds[r] = pr * (d4[r] * 0.125f - sv[1]);
             }
             union {
                 v4s v;
