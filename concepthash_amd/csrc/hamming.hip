@@ -18,6 +18,7 @@
 //             (query, distance) bucket in gallery order, which with the prefix "base" gives its exact global rank and
 //             relevant-rank; AP numerators are accumulated in 2^-32 fixed point (integer, order independent).
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/concepthash_hip.h"
 #include "ch_common.h"
@@ -35,6 +36,30 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
     uint32_t d;
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
     return d;
+}
+// Two words of a distance against gallery words held by lane K of the lane's own row of 16 lanes: the broadcast is the DPP operand
+// of the xor (`row_newbcast:K`), so it costs no instruction.  Written as one asm block because of the DPP read hazard (a VGPR
+// written by a VALU instruction must not be read by a DPP instruction within the next two): the temporaries are distinct
+// early-clobber registers and each is written >= 2 instructions before the block ends, so back-to-back blocks are safe whatever
+// registers the allocator picks, without the s_nop the compiler puts between its own DPP instructions.  g0 / g1 are only ever
+// written by loads.
+template <int K>
+__device__ __forceinline__ uint32_t xor_bcnt2_row_bcast(uint32_t g0, uint32_t g1, uint32_t q0, uint32_t q1, uint32_t acc) {
+    uint32_t t0, t1, d;
+    asm("v_xor_b32_dpp %0, %3, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_xor_b32_dpp %1, %4, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_bcnt_u32_b32 %2, %0, %7\n\t"
+        "v_bcnt_u32_b32 %2, %1, %2"
+        : "=&v"(t0), "=&v"(t1), "=&v"(d)
+        : "v"(g0), "v"(g1), "v"(q0), "v"(q1), "v"(acc), "n"(K));
+    return d;
+}
+// x ^ (lane K's v), same DPP form; the result is not read by a DPP instruction
+template <int K>
+__device__ __forceinline__ uint32_t xor_row_bcast(uint32_t v, uint32_t x) {
+    uint32_t t;
+    asm("v_xor_b32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(t) : "v"(v), "v"(x), "n"(K));
+    return t;
 }
 // key = dist << KEY_SHIFT | row with the (wave-uniform) row number taken from an SGPR: one v_lshl_or_b32 (the compiler's own
 // form is a shift plus v_or3 with the row's low bits as a literal).
@@ -264,15 +289,15 @@ struct RankLimits {
 // v_bcnt, every row is one LDS counter update in the lane's own column (conflict free).
 //   MODE 0: ds_add (no return); at the end the [bucket][lane] counters leave through a coalesced transposed write.
 //   MODE 1: ds_add_rtn: the returned value is the row's position inside its (query, distance) bucket in gallery order; only
-//           when some lane of the wave holds a relevant row in the trip are the four "ranked before" bases gathered (four
-//           independent 8-byte loads in flight) and the AP terms of the relevant rows added -- to NR accumulators, one per
-//           rank limit, so that mAP@R for a list of R, P@k and R@k all come out of a single pass.
+//           when some lane of the wave holds a relevant row in the trip is the "ranked before" base of each lane's relevant row
+//           gathered (`account_trip`) and its AP term added -- to NR accumulators, one per rank limit, so that mAP@R for a list
+//           of R, P@k and R@k all come out of a single pass.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-// VM: the gallery block of a trip (codes and labels of four rows) arrives by VMEM broadcast loads -- every lane reads the same
-// address, in-order vmcnt, two blocks in flight -- instead of scalar loads.  SMEM shares lgkmcnt with the LDS atomics and returns
-// out of order, so the scalar form's per-trip `s_waitcnt lgkmcnt(0)` also drains the previous trip's four atomics; with VMEM the
-// row loop of the histogram pass never waits for an atomic, and the AP pass only inside the rare relevant-row branch.
+// VM: the gallery arrives through VMEM in blocks of 16 rows spread over the lanes (in-order vmcnt, four blocks in flight) and is
+// broadcast by DPP operands -- instead of scalar loads.  SMEM shares lgkmcnt with the LDS atomics and returns out of order, so the
+// scalar form's per-trip `s_waitcnt lgkmcnt(0)` also drains the trip's four atomics; with VMEM the row loop of the histogram pass
+// never waits for an atomic, and the AP pass only for counters issued a whole trip earlier.
 template <int W, int BLK, int MODE, int NR, bool VM>
 __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restrict__ q, int64_t Qn,
                                                        const uint64_t *__restrict__ g, int64_t G, const void *q_labels,
@@ -333,6 +358,62 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
             nrel[r] += in ? 1u : 0u;
         }
     };
+    // The relevant rows of the four-row trips (MODE 1).  With C classes a lane holds a relevant row in 4 / C of its trips, so SOME
+    // lane of the wave does in most trips while nearly every lane has none; accounting inside the trip (a gather of the "ranked
+    // before" base + an exact division, ~750 clocks with one wave per SIMD to hide nothing behind) is what bounded this pass.
+    // Instead every lane parks its relevant row -- (distance, returned counter) -- in a one-entry slot, and the wave accounts all
+    // parked rows at once only when some lane needs its slot a second time (about every 9 trips at 200 classes: 64 lanes, 2 % each
+    // per trip).  The parking of trip t runs in trip t + 1, in front of that trip's atomics, so it never waits for a counter to
+    // come back.  The sums are integers: the order of accumulation does not matter.
+    // (Tried and slower, 23 vs 16 ms at 16,384 x 1M: the same bookkeeping on the rows' 64-bit lane masks in SGPRs with a scalar
+    // test per row -- four more branches per trip cost more than the eight v_cndmask they skip.)
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    uint32_t pend_d = EMPTY, pend_old = 0;     // the parked row
+    // the previous trip, not yet parked (scalars, not arrays: an array the slow path below indexes ends up in scratch memory)
+    uint32_t pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0, po0 = 0, po1 = 0, po2 = 0, po3 = 0, prev_m = 0;
+    static_assert(UB == 4, "park_trip selects among four rows");
+    auto gather_account = [&](bool has, uint32_t dd, uint32_t oo) {
+        // lanes without a row read the wave-uniform head of `base`: one extra cache line instead of a divergent branch
+        const uint2 b = *(const uint2 *)(has ? base + brow + 2 * dd : base);
+        if (has) account(b, oo);
+    };
+    auto drain = [&]() {
+        const bool has = pend_d != EMPTY;
+        if (__builtin_amdgcn_ballot_w64(has) != 0ull) {
+            gather_account(has, pend_d, pend_old);
+            pend_d = EMPTY;
+        }
+    };
+    // the operand of the row `low` (one bit of a trip's relevance mask) names: three v_cndmask
+    auto pick = [](uint32_t low, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
+        uint32_t r = a3;
+        r = (low & 4u) ? a2 : r;
+        r = (low & 2u) ? a1 : r;
+        r = (low & 1u) ? a0 : r;
+        return r;
+    };
+    auto park_trip = [&]() {
+        const uint32_t m = prev_m;
+        const bool conflict = m != 0u && (pend_d != EMPTY || (m & (m - 1u)) != 0u);
+        if (__builtin_amdgcn_ballot_w64(conflict) != 0ull) {
+            drain();
+            uint32_t mm = m & (m - 1u);         // a lane's rows beyond its first: accounted directly (rare)
+            while (__builtin_amdgcn_ballot_w64(mm != 0u) != 0ull) {
+                const uint32_t low = mm & (0u - mm);
+                gather_account(mm != 0u, pick(low, pd0, pd1, pd2, pd3), pick(low, po0, po1, po2, po3));
+                mm ^= low;
+            }
+        }
+        const uint32_t low = m & (0u - m);
+        const uint32_t nd = pick(low, pd0, pd1, pd2, pd3), no = pick(low, po0, po1, po2, po3);
+        pend_d = m ? nd : pend_d;
+        pend_old = m ? no : pend_old;
+    };
+    auto keep_trip = [&](const uint32_t (&d)[UB], const uint32_t (&old)[UB], const bool (&rel)[UB]) {
+        pd0 = d[0]; pd1 = d[1]; pd2 = d[2]; pd3 = d[3];
+        po0 = old[0]; po1 = old[1]; po2 = old[2]; po3 = old[3];
+        prev_m = (uint32_t)rel[0] | ((uint32_t)rel[1] << 1) | ((uint32_t)rel[2] << 2) | ((uint32_t)rel[3] << 3);
+    };
     auto row = [&](const uint64_t *gw, bool rel) {   // single-row form (segment tail, multi-hot labels)
         const uint32_t d = (uint32_t)hamming<W>(qw, gw);
         const uint32_t inc = 1u | ((uint32_t)rel << 16);
@@ -346,76 +427,76 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
 
     int j = 0;
     if (LW == 0 && VM) {
-        constexpr int CV = UB * W / 2;  // dwordx4 loads per block of codes (UB rows x W words x 8 B = CV x 16 B); CV in {2, 4, 6, 8}
+        // Blocks of 16 gallery rows, lane l holding row (l & 15) of the block -- its 2 W code words and its label -- so a block
+        // costs the texture path TWO OR THREE load instructions per wave instead of the 20 that a same-address ("broadcast")
+        // load per row and word needs (those are not free: the address unit walks all 64 lanes of each; at four waves per CU it
+        // was the bound of this loop).  Row k of the block reaches every lane through the DPP operand of the xor itself
+        // (`v_xor_b32_dpp ... row_newbcast:k`: lane k of the lane's own row of 16), i.e. at no instruction at all.
+        // Four blocks in flight behind counted vmcnt waits (inline-asm loads: in order, and invisible to the compiler's own waits).
+        constexpr int RB = 16, NBUF = 4;
+        constexpr int NLD = (W <= 2) ? 2 : 3;   // load instructions per block
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
         struct VBlk {
-            u32x4_t c[CV];
-            u32x4_t lab;
+            u32x4_t p4, q4;
+            u32x2_t p2;
+            uint32_t lab;
         };
-        VBlk bA, bB;
-        // lane-constant but VGPR-resident running pointers (a uniform pointer would be re-materialised from SGPRs per load)
-        uint32_t zero_v;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
-        const char *pc = (const char *)gp + zero_v;
-        const char *pl = (const char *)gl32 + zero_v;
-#define CH_VLOAD(dst, ptr, off) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr) : "memory")
-        // block A of an iteration sits at offset 0 of the running pointers, block B right behind it
-        auto issue_a = [&]() {
-            CH_VLOAD(bA.c[0], pc, 0);
-            CH_VLOAD(bA.c[1], pc, 16);
-            if constexpr (CV > 2) { CH_VLOAD(bA.c[2], pc, 32); CH_VLOAD(bA.c[3], pc, 48); }
-            if constexpr (CV > 4) { CH_VLOAD(bA.c[4], pc, 64); CH_VLOAD(bA.c[5], pc, 80); }
-            if constexpr (CV > 6) { CH_VLOAD(bA.c[6], pc, 96); CH_VLOAD(bA.c[7], pc, 112); }
-            CH_VLOAD(bA.lab, pl, 0);
-        };
-        auto issue_b = [&]() {
-            if constexpr (CV == 2) { CH_VLOAD(bB.c[0], pc, 32); CH_VLOAD(bB.c[1], pc, 48); }
-            if constexpr (CV == 4) { CH_VLOAD(bB.c[0], pc, 64); CH_VLOAD(bB.c[1], pc, 80); CH_VLOAD(bB.c[2], pc, 96); CH_VLOAD(bB.c[3], pc, 112); }
-            if constexpr (CV == 6) {
-                CH_VLOAD(bB.c[0], pc, 96); CH_VLOAD(bB.c[1], pc, 112); CH_VLOAD(bB.c[2], pc, 128); CH_VLOAD(bB.c[3], pc, 144);
-                CH_VLOAD(bB.c[4], pc, 160); CH_VLOAD(bB.c[5], pc, 176);
+        VBlk b0, b1, b2, b3;
+        const char *pc = (const char *)(gp + (size_t)(tid & 15) * W);   // per-lane running pointers
+        const char *pl = (const char *)(gl32 + (tid & 15));
+#define CH_GLD(inst, dst, ptr, off) asm volatile(inst " %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr) : "memory")
+        auto issue = [&](VBlk &b) {
+            if constexpr (W == 1) CH_GLD("global_load_dwordx2", b.p2, pc, 0);
+            if constexpr (W == 2) CH_GLD("global_load_dwordx4", b.p4, pc, 0);
+            if constexpr (W == 3) {
+                CH_GLD("global_load_dwordx4", b.p4, pc, 0);
+                CH_GLD("global_load_dwordx2", b.p2, pc, 16);
             }
-            if constexpr (CV == 8) {
-                CH_VLOAD(bB.c[0], pc, 128); CH_VLOAD(bB.c[1], pc, 144); CH_VLOAD(bB.c[2], pc, 160); CH_VLOAD(bB.c[3], pc, 176);
-                CH_VLOAD(bB.c[4], pc, 192); CH_VLOAD(bB.c[5], pc, 208); CH_VLOAD(bB.c[6], pc, 224); CH_VLOAD(bB.c[7], pc, 240);
+            if constexpr (W == 4) {
+                CH_GLD("global_load_dwordx4", b.p4, pc, 0);
+                CH_GLD("global_load_dwordx4", b.q4, pc, 16);
             }
-            CH_VLOAD(bB.lab, pl, 16);
+            CH_GLD("global_load_dword", b.lab, pl, 0);
+            pc += RB * W * 8;
+            pl += RB * 4;
         };
-#undef CH_VLOAD
-        // wait until all but the youngest `CV + 1` loads (= the other block's) have landed; the "+v" operands pin every use of
-        // the block behind the wait
-        auto landed = [&](VBlk &b, bool other_in_flight) {
-            if (other_in_flight) {
-                if constexpr (CV == 2) asm volatile("s_waitcnt vmcnt(3)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.lab));
-                if constexpr (CV == 4) asm volatile("s_waitcnt vmcnt(5)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.lab));
-                if constexpr (CV == 6)
-                    asm volatile("s_waitcnt vmcnt(7)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.c[4]), "+v"(b.c[5]), "+v"(b.lab));
-                if constexpr (CV == 8)
-                    asm volatile("s_waitcnt vmcnt(9)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.c[4]), "+v"(b.c[5]),
-                                 "+v"(b.c[6]), "+v"(b.c[7]), "+v"(b.lab));
-            } else {
-                if constexpr (CV == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.lab));
-                if constexpr (CV == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.lab));
-                if constexpr (CV == 6)
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.c[4]), "+v"(b.c[5]), "+v"(b.lab));
-                if constexpr (CV == 8)
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b.c[0]), "+v"(b.c[1]), "+v"(b.c[2]), "+v"(b.c[3]), "+v"(b.c[4]), "+v"(b.c[5]),
-                                 "+v"(b.c[6]), "+v"(b.c[7]), "+v"(b.lab));
-            }
+#undef CH_GLD
+        // wait until all but the `younger` blocks issued after `b` have landed; the "+v" operands pin every use of the block
+        // behind the wait
+        auto landed = [&](VBlk &b, auto younger) {
+            constexpr int N = decltype(younger)::value * NLD;
+            if constexpr (W == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b.p2), "+v"(b.lab) : "n"(N));
+            if constexpr (W == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b.p4), "+v"(b.lab) : "n"(N));
+            if constexpr (W == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b.p4), "+v"(b.p2), "+v"(b.lab) : "n"(N));
+            if constexpr (W == 4) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b.p4), "+v"(b.q4), "+v"(b.lab) : "n"(N));
         };
-        auto scan_vblk = [&](const VBlk &b) {
+        auto word = [&](const VBlk &b, int i) -> uint32_t {
+            if constexpr (W == 1) return b.p2[i];
+            if constexpr (W == 2) return b.p4[i];
+            if constexpr (W == 3) return i < 4 ? b.p4[i] : b.p2[i - 4];
+            if constexpr (W == 4) return i < 4 ? b.p4[i] : b.q4[i - 4];
+        };
+        // rows 4 G .. 4 G + 3 of a block: one "trip" of the parking logic
+        auto group = [&](const VBlk &b, auto gc) {
+            constexpr int G = decltype(gc)::value;
             uint32_t d[UB], old[UB];
             bool rel[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
+            auto one = [&](auto uc) {
+                constexpr int U = decltype(uc)::value, K = 4 * G + U;
                 uint32_t acc = 0;
 #pragma unroll
-                for (int w = 0; w < 2 * W; ++w) {
-                    const int idx = u * 2 * W + w;
-                    acc = bcnt_acc(qw[w] ^ b.c[idx >> 2][idx & 3], acc);
-                }
-                d[u] = acc;
-                rel[u] = valid && ((int32_t)b.lab[u] == qlab);
-            }
+                for (int w = 0; w < W; ++w)
+                    acc = xor_bcnt2_row_bcast<K>(word(b, 2 * w), word(b, 2 * w + 1), qw[2 * w], qw[2 * w + 1], acc);
+                d[U] = acc;
+                bool r = xor_row_bcast<K>(b.lab, (uint32_t)qlab) == 0u;   // all lanes take part in the DPP read: no `valid &&` in front
+                r &= valid;
+                rel[U] = r;
+            };
+            one(std::integral_constant<int, 0>{});
+            one(std::integral_constant<int, 1>{});
+            one(std::integral_constant<int, 2>{});
+            one(std::integral_constant<int, 3>{});
+            if (MODE == 1) park_trip();     // the previous trip's rows; its counters came back long ago
 #pragma unroll
             for (int u = 0; u < UB; ++u) {  // in row order: two rows of a trip may share a bucket
                 const uint32_t inc = 1u | ((uint32_t)rel[u] << 16);
@@ -424,21 +505,14 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
                 else
                     old[u] = atomicAdd(col + d[u] * BLK, inc);
             }
-            if (MODE == 1) {
-                if (__builtin_amdgcn_ballot_w64(rel[0] | rel[1] | rel[2] | rel[3]) != 0ull) {
-                    uint2 bs[UB];
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) bs[u] = *(const uint2 *)(base + brow + 2 * d[u]);
-#pragma unroll
-                    for (int u = 0; u < UB; ++u)
-                        if (rel[u]) account(bs[u], old[u]);
-                }
-            }
+            if (MODE == 1) keep_trip(d, old, rel);
         };
-        // Two blocks in flight, no register copies: {wait A, scan A, re-issue A two blocks ahead, wait B, scan B, re-issue B}.
-        // A wait leaves exactly the other block's CV + 1 loads outstanding.  In MODE 1 the base gathers are compiler-managed
-        // loads: its own waits may drain our prefetch early (slower, never wrong: vmcnt retires in order).
-        const int npair = n / (2 * UB);
+        auto scan_vblk = [&](const VBlk &b) {
+            group(b, std::integral_constant<int, 0>{});
+            group(b, std::integral_constant<int, 1>{});
+            group(b, std::integral_constant<int, 2>{});
+            group(b, std::integral_constant<int, 3>{});
+        };
         {   // the query words come from a compiler-managed load: consume them once HERE, or the compiler's own wait for them
             // (vmcnt(0): it cannot see the asm loads) lands inside the loop and drains the prefetch every iteration
             uint32_t use = 0;
@@ -446,27 +520,30 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
             for (int w = 0; w < 2 * W; ++w) use |= qw[w];
             asm volatile("" ::"v"(use), "v"(qlab));
         }
-        if (npair > 0) {
-            issue_a();
-            issue_b();
+        const std::integral_constant<int, 0> y0{};
+        const std::integral_constant<int, 1> y1{};
+        const std::integral_constant<int, 2> y2{};
+        const std::integral_constant<int, 3> y3{};
+        const int nring = n / (RB * NBUF);   // rounds of the four-block ring
+        if (nring > 0) {
+            issue(b0);
+            issue(b1);
+            issue(b2);
+            issue(b3);
         }
-        for (int it = 0; it + 1 < npair; ++it) {   // steady state: branch free
-            landed(bA, true);
-            scan_vblk(bA);
-            pc += 2 * UB * W * 8;   // the running pointers now address the next pair
-            pl += 2 * UB * 4;
-            issue_a();
-            landed(bB, true);       // B is older than the A just issued
-            scan_vblk(bB);
-            issue_b();
+        for (int it = 0; it + 1 < nring; ++it) {   // steady state: the three blocks issued after a slot's are still in flight
+            landed(b0, y3); scan_vblk(b0); issue(b0);
+            landed(b1, y3); scan_vblk(b1); issue(b1);
+            landed(b2, y3); scan_vblk(b2); issue(b2);
+            landed(b3, y3); scan_vblk(b3); issue(b3);
         }
-        if (npair > 0) {            // last pair: nothing left to issue
-            landed(bA, true);
-            scan_vblk(bA);
-            landed(bB, false);
-            scan_vblk(bB);
+        if (nring > 0) {                           // last round: nothing left to issue
+            landed(b0, y3); scan_vblk(b0);
+            landed(b1, y2); scan_vblk(b1);
+            landed(b2, y1); scan_vblk(b2);
+            landed(b3, y0); scan_vblk(b3);
         }
-        j = npair * 2 * UB;
+        j = nring * RB * NBUF;
         for (; j < n; ++j) row(gp + (size_t)j * W, valid && (gl32[j] == qlab));
     } else if (LW == 0) {
         uint64_t bufA[UB * W], bufB[UB * W];
@@ -485,6 +562,7 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
                 d[u] = (uint32_t)hamming<W>(qw, blk + u * W);
                 rel[u] = valid && (lab[u] == qlab);
             }
+            if (MODE == 1) park_trip();     // the previous trip's rows; its counters came back long ago
 #pragma unroll
             for (int u = 0; u < UB; ++u) {  // in row order: two rows of a trip may share a bucket
                 const uint32_t inc = 1u | ((uint32_t)rel[u] << 16);
@@ -493,16 +571,7 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
                 else
                     old[u] = atomicAdd(col + d[u] * BLK, inc);
             }
-            if (MODE == 1) {
-                if (__builtin_amdgcn_ballot_w64(rel[0] | rel[1] | rel[2] | rel[3]) != 0ull) {
-                    uint2 b[UB];
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) b[u] = *(const uint2 *)(base + brow + 2 * d[u]);
-#pragma unroll
-                    for (int u = 0; u < UB; ++u)
-                        if (rel[u]) account(b[u], old[u]);
-                }
-            }
+            if (MODE == 1) keep_trip(d, old, rel);
         };
         if (n >= UB) load_block(bufA, labA, 0);
         for (; j + 2 * UB <= n; j += 2 * UB) {
@@ -520,6 +589,10 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
         for (; j < n; ++j) row(gp + (size_t)j * W, valid && relevant_multi(qm, glm + (size_t)j * LW, LW));
     }
 
+    if (MODE == 1) {
+        park_trip();
+        drain();
+    }
     if (MODE == 0) {
         // out_hist[seg][q][bucket] = (count, relevant count): element e of this tile's [BLK][NB] block is written by thread
         // e % BLK -> consecutive lanes write consecutive 8-byte elements
@@ -612,14 +685,12 @@ template <int W, int BLK, int MODE, int NR>
 int launch_scan_nr(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql, const void *gl, int LW,
                    int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims, int nlim,
                    const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
-    // Histogram pass: gallery through VMEM broadcast loads (measured 18.9 -> 14.5 ms at 16,384 x 1M x 128 bit, 0.48 -> 0.36 ms at
-    // the NABirds size; CH_HAMMING_VMEM=0 = scalar loads).  AP pass: scalar loads -- there the compiler-managed base gathers
-    // make its own vmcnt(0) waits drain the asm prefetch, and the VMEM form measured slower (39 -> 48 ms).  Same results.
+    // Both passes take the gallery through VMEM in 16-row blocks spread over the lanes + DPP broadcast (at 16,384 x 1M x 128 bit:
+    // histogram pass 18.9 ms with scalar loads -> 14.4 ms with same-address VMEM loads -> 8.0 ms; AP pass 39 -> 16 ms together
+    // with the parked accounting).  CH_HAMMING_VMEM=0 = the scalar-load form of both (same results; kept as the cross-check).
     static const bool vm_env = !(getenv("CH_HAMMING_VMEM") && atoi(getenv("CH_HAMMING_VMEM")) == 0);
-    if constexpr (MODE == 0) {
-        if (vm_env)
-            return launch_scan_vm<W, BLK, MODE, NR, true>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
-    }
+    if (vm_env)
+        return launch_scan_vm<W, BLK, MODE, NR, true>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
     return launch_scan_vm<W, BLK, MODE, NR, false>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
 }
 
