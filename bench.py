@@ -531,9 +531,10 @@ def hamming_block(torch, np, rt, syn, dist, dev, rank, world):
 
 # comparisons/s ceilings of the mAP row loops: (histogram pass, AP pass) at 4 cycles per wave64 VALU instruction on 1024 SIMDs
 # at 2.4 GHz = 6.14e11 wave-instructions/s, 64 pairs per wave-instruction slot: 3.93e13 / (VALU instructions per row of the bare
-# row loop: 7 at 64 bit, 11 at 128 bit -- ISA listing, and 11.03 measured by SQ_INSTS_VALU, profiles/r02_hamming_1m_pmc_*.txt;
+# row loop: 8 at 64 bit, 12 at 128 bit -- per 64-bit word 2 x (xor with the DPP-broadcast gallery word + chained bcnt), plus label
+# xor, compare, increment select, counter address; ISA listing, SQ_INSTS_VALU in profiles/r02_hamming_1m_pmc_*.txt;
 # the AP pass's relevant-row work is not counted, so its fraction is against the same bare-loop ceiling)
-MAP_VALU_CEILING = {64: (3.93e13 / 7.0, 3.93e13 / 7.0), 128: (3.93e13 / 11.0, 3.93e13 / 11.0)}
+MAP_VALU_CEILING = {64: (3.93e13 / 8.0, 3.93e13 / 8.0), 128: (3.93e13 / 12.0, 3.93e13 / 12.0)}
 
 
 def cpu_baselines(torch, np, syn, sd, cfg, g_np):

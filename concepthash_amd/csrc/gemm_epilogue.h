@@ -163,6 +163,22 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
     }
 
     if constexpr (BF16_ONLY) {
+        // (training, EPI_BIAS_DACT_*) the saved pre-activations this lane multiplies with, in the read-back loop's mapping: ALL
+        // requested before the staging -- inside the loop each load sits behind the previous row group's store (they may alias
+        // as far as the compiler knows), i.e. one exposed round trip per row group, 16 per 128-row wave tile
+        uint4 ax[T::dact ? MT * 2 : 1];
+        float dact_scale = 1.0f;
+        if constexpr (T::dact) {
+            const int lrow = lane >> 3, pos = lane & 7;
+#pragma unroll
+            for (int i = 0; i < MT * 2; ++i) {
+                const int row = i * 8 + lrow;
+                const int m = m_base + row;
+                const int mc = m < p.M ? m : p.M - 1;
+                ax[i] = *(const uint4 *)(p.aux + (size_t)mc * p.ldo + n_base + (pos ^ (row & 7)) * 8);
+            }
+            if (EPI == EPI_BIAS_DACT_GELU && p.scale_ptr) dact_scale = *p.scale_ptr;
+        }
         // ---- stage MT*16 rows x 64 cols of bf16 (128-B rows)
         f32x4 fc[4];
         if constexpr (T::fold) {
@@ -205,9 +221,8 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
             if (i & 1) v = make_uint4(v.z, v.w, v.x, v.y);  // rows with bit 3 set (row = 8 i + lrow) hold their 8-byte halves swapped
             const int m = m_base + row;
             if constexpr (T::dact) {  // training: times the activation's derivative at the saved pre-activation (and the adapter scale)
-                const int mc = m < p.M ? m : p.M - 1;
-                const uint4 a = *(const uint4 *)(p.aux + (size_t)mc * p.ldo + n_base + chunk * 8);
-                const float sc = (EPI == EPI_BIAS_DACT_GELU && p.scale_ptr) ? *p.scale_ptr : 1.0f;
+                const uint4 a = ax[i];
+                const float sc = dact_scale;
                 const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, aw[4] = {a.x, a.y, a.z, a.w};
                 uint32_t ow[4];
 #pragma unroll
