@@ -130,7 +130,8 @@ def hamming_hist(q, g, q_lab, g_lab, LW: int, seg_rows: int, stream=None) -> tor
     Qn, W = q.shape
     G = g.shape[0]
     nseg = max(1, -(-G // seg_rows))
-    hist = torch.zeros(nseg, Qn, 64 * W + 1, 2, dtype=torch.int32, device=q.device)
+    # the pass writes every counter of every (segment, query); an empty gallery launches nothing
+    hist = (torch.empty if G > 0 else torch.zeros)(nseg, Qn, 64 * W + 1, 2, dtype=torch.int32, device=q.device)
     with _dev_guard(q):
         _lib.check(lib.ch_hamming_hist(_lib.ptr(q), Qn, _lib.ptr(g), G, W, _lib.ptr(q_lab), _lib.ptr(g_lab), LW, seg_rows,
                                        _lib.ptr(hist), _lib.stream_ptr(stream)), "ch_hamming_hist")
@@ -230,15 +231,19 @@ def summarize(S, nrel, total, idx_of, Rs: Sequence[int], ks: Sequence[int]) -> d
     nR = len(Rs)
     aps = [ap_from_fixed(S[idx_of[i]], nrel[idx_of[i]]) for i in range(nR)]
     hits = torch.zeros(Qn, len(ks), dtype=torch.int32, device=dev)
-    precisions, recalls = [], []
+    if not Qn:
+        return dict(mAPs=[0.0] * nR, aps=aps, hits=hits, precisions=[0.0] * len(ks), recalls=[0.0] * len(ks))
+    means = [a.mean() for a in aps]                         # 0-dim float64 tensors; ONE device->host copy for all of them below
+    tot = total.clamp_min(1).double()
     for t, k in enumerate(ks):
         h = nrel[idx_of[nR + t]]
         hits[:, t] = h
-        precisions.append(float((h.double() / k).mean().item()) if Qn else 0.0)
-        recalls.append(float(torch.where(total > 0, h.double() / total.clamp_min(1).double(),
-                                         torch.zeros_like(h, dtype=torch.float64)).mean().item()) if Qn else 0.0)
-    return dict(mAPs=[float(a.mean().item()) if Qn else 0.0 for a in aps], aps=aps, hits=hits, precisions=precisions,
-                recalls=recalls)
+        means.append((h.double() / k).mean())
+    for t in range(len(ks)):
+        h = hits[:, t]
+        means.append(torch.where(total > 0, h.double() / tot, torch.zeros_like(tot)).mean())
+    vals = torch.stack(means).tolist()
+    return dict(mAPs=vals[:nR], aps=aps, hits=hits, precisions=vals[nR:nR + len(ks)], recalls=vals[nR + len(ks):])
 
 
 def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels: torch.Tensor, R=-1,
