@@ -681,7 +681,11 @@ int ch_ln_bwd(const bf16_t *dyg, const bf16_t *x, const float *stats, int64_t ro
 // number of row chunks of the two-stage reductions and the workspace they need (floats)
 int ch_wgrad_chunks(int64_t rows, int N, int K) {
     const int tiles = (N / WG_TILE) * (K / WG_TILE);
-    int chunks = std::max(1, 512 / std::max(tiles, 1));          // ~2 workgroups per CU at the most
+    // ONE round of workgroups: the kernel pins chunk c to XCD c % 8 (so that a chunk's tiles share that XCD's L2), and an XCD has
+    // 32 CUs x 2 resident workgroups = 64 slots -> at most floor(64 / tiles) chunks per XCD.  (The first version took 512 / tiles
+    // chunks over the whole chip: 28 chunks of 18 tiles put 72 workgroups on XCDs 0-3 -- 8 of them waited for a second round and
+    // the launch took two workgroup lifetimes, 56 us instead of 32.)
+    int chunks = 8 * std::max(1, 64 / std::max(tiles, 1));
     const int64_t steps = ceil_div64(rows, WG_KSTEP);
     // at least 16 K-steps (512 rows) per chunk: below that the fp32 partial slabs (chunks * N * K * 4 bytes, written and re-read)
     // cost more than the idle CUs
