@@ -116,10 +116,25 @@ def prepare_labels(q_labels: torch.Tensor, g_labels: torch.Tensor):
 
 
 def map_seg_rows(Qn: int, G: int, W: int) -> int:
+    """Gallery rows per segment of the two mAP passes (grid = query tiles x segments).  A workgroup holds its tile's counters in
+    LDS -- (64 W + 1) x BLK x 4 B -- so an MI355X has 256 (x 2 at 64 bit) workgroup slots, and a launch takes
+    ceil(workgroups / slots) rounds of one segment each: the segment count is chosen to fill whole rounds (e.g. NABirds size,
+    97 tiles: 10 segments = 1.9 rounds instead of 11 = 2.1 -> 3) at about 1024 workgroups, segments of 256 .. 65,535 rows."""
     blk = 256 if W <= 2 else 128
     tiles = max(1, -(-Qn // blk))
-    nseg = max(1, -(-1024 // tiles))
-    rows = -(-G // nseg)
+    slots = 256 * max(1, (160 * 1024) // ((64 * W + 1) * blk * 4))
+    nseg_max = max(1, min(65535, G // 256))          # segments of at least 256 rows
+    nseg_min = max(1, -(-G // 65535))                # ... and at most 65,535 (16-bit counters)
+    want = max(1, -(-1024 // tiles))
+    hi = max(nseg_min, min(nseg_max, 2 * want))
+    lo = min(hi, max(nseg_min, min(want, hi) // 2))
+    best, best_cost = None, None
+    for nseg in range(lo, hi + 1):
+        rows = -(-G // nseg)
+        cost = -(-(tiles * nseg) // slots) * (rows + 128)     # rounds x (rows of a segment + a workgroup's fixed cost in row units)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = nseg, cost
+    rows = -(-G // best)
     return int(min(65535, max(256, rows)))
 
 
