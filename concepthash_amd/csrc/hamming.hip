@@ -727,10 +727,15 @@ int scan_dispatch(int mode, const uint64_t *q, int64_t Qn, const uint64_t *g, in
     }
 }
 
-int topk_seg_rows(int64_t Qn, int64_t G) {
-    // enough (tile, segment) workgroups to fill 256 CUs a few times over, segments not shorter than 256 rows
+int topk_seg_rows(int64_t Qn, int64_t G, int k) {
+    // (tile, segment) workgroups for ONE full round and never a few more: the scan kernel has no LDS, so residency is set by its
+    // registers -- 24-42 VGPRs for lists of <= 16 keys (8 workgroups of four waves per CU), 68-74 for 32 (7), ~136 for 64 (3),
+    // the whole file for 128 (1).  ceil(2048 / tiles) segments put 2,134 workgroups on the 2,048 slots at the NABirds size
+    // (97 tiles): a second round for 86 of them doubled the launch (0.38 -> 0.2 ms).  Segments not shorter than 256 rows.
+    const int per_cu = k <= 16 ? 8 : k <= 32 ? 7 : k <= 64 ? 3 : 1;
+    const int64_t slots = 256 * per_cu;
     const int64_t tiles = ceil_div64(Qn, 256);
-    int64_t nseg = ceil_div64(2048, tiles);
+    int64_t nseg = std::max<int64_t>(1, slots / tiles);
     int64_t rows = ceil_div64(G, nseg);
     if (rows < 256) rows = 256;
     if (rows > (int64_t)KEY_MASK) rows = KEY_MASK;
@@ -774,7 +779,7 @@ extern "C" int ch_hamming_dist(const uint64_t *q, int64_t Qn, const uint64_t *g,
 extern "C" size_t ch_hamming_topk_workspace(int64_t Qn, int64_t G, int32_t W, int32_t k) {
     (void)W;
     if (Qn <= 0 || G <= 0 || k <= 0) return 16;
-    const int seg_rows = topk_seg_rows(Qn, G);
+    const int seg_rows = topk_seg_rows(Qn, G, k);
     const int64_t nseg = ceil_div64(G, seg_rows);
     return (size_t)(nseg * Qn * k) * sizeof(uint32_t) + 16;
 }
@@ -795,7 +800,7 @@ extern "C" int ch_hamming_topk(const uint64_t *q, int64_t Qn, const uint64_t *g,
     }
     CH_REQUIRE(g != nullptr, "hamming_topk: null gallery");
     CH_REQUIRE(workspace && workspace_bytes >= ch_hamming_topk_workspace(Qn, G, W, k), "hamming_topk: workspace too small");
-    const int seg_rows = topk_seg_rows(Qn, G);
+    const int seg_rows = topk_seg_rows(Qn, G, k);
     const int nseg = (int)ceil_div64(G, seg_rows);
     CH_REQUIRE(nseg <= 65535, "hamming_topk: gallery too large for one call (shard it)");
     uint32_t *part = (uint32_t *)workspace;
