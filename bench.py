@@ -499,7 +499,7 @@ def hamming_block(torch, np, rt, syn, dist, dev, rank, world):
     }
     if world > 1:
         return out
-    # ---- single GPU only: mAP@all (histogram pass + prefix + one multi-limit AP pass) at three sizes --------------------
+    # ---- single GPU only: mAP@all (one-scan and two-scan forms, per-pass times) at three sizes ---------------------------
     def map_eval(name, qn, gn, nbit, ncls, reps):
         Wm = nbit // 64
         gg = torch.Generator(device=dev).manual_seed(7)
@@ -512,10 +512,18 @@ def hamming_block(torch, np, rt, syn, dist, dev, rank, world):
         s_p, (base, _) = _ev_time(torch, lambda: rt.hist_prefix(hist), reps)
         limits, _ = rt.normalize_limits([-1, 1, 5, 10])
         s_a, _ = _ev_time(torch, lambda: rt.hamming_ap_multi(gq, ga, ql, gl, 0, seg, base, limits), reps)
+        s_hr, (_, recs) = _ev_time(torch, lambda: rt.hamming_hist_rec(gq, ga, ql, gl, 0, seg), reps)
+        s_ar, _ = _ev_time(torch, lambda: rt.hamming_ap_rec(gq, ga, ql, gl, 0, seg, base, recs, limits), reps)
+        s_e2, _ = _ev_time(torch, lambda: rt.evaluate(gq, ga, ql, gl, R=-1, ks=(1, 5, 10), records=False), max(1, reps // 2))
         s_e, ev = _ev_time(torch, lambda: rt.evaluate(gq, ga, ql, gl, R=-1, ks=(1, 5, 10)), max(1, reps // 2))
         pairs = qn * gn
         return {"workload": f"{name}: mAP@all + P/R@{{1,5,10}}, {qn} queries x {gn} gallery rows x {nbit} bit, {ncls} classes",
                 "ms": round(s_e * 1e3, 3), "queries_per_s": round(qn / s_e, 1), "mAP": round(ev["mAP"], 6),
+                # `ms` = evaluate() in its default one-scan form: histogram pass that records the relevant rows + prefix + AP terms
+                # from the records; the two-scan form (histogram pass, prefix, AP pass over the gallery again) beside it
+                "one_scan": {"hist_and_records_ms": round(s_hr * 1e3, 3), "ap_from_records_ms": round(s_ar * 1e3, 3),
+                             "record_list_entries": int(recs[1]), "workgroups_overflowed": int(recs[3].sum())},
+                "two_scan_ms": round(s_e2 * 1e3, 3),
                 "hist_pass_ms": round(s_h * 1e3, 3), "hist_prefix_ms": round(s_p * 1e3, 3), "ap_pass_ms": round(s_a * 1e3, 3),
                 "hist_pass_comparisons_per_s": float(f"{pairs / s_h:.4g}"), "ap_pass_comparisons_per_s": float(f"{pairs / s_a:.4g}"),
                 # VALU ceilings: instructions per pair of the row loop at 4 cycles per wave64 instruction

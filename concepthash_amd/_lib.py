@@ -70,6 +70,13 @@ SIGNATURES = {
                               c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_hamming_ap_multi": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
                                     c_void_p, POINTER(c_int64), c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_hamming_rec_workgroups": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),
+    "ch_hamming_rec_block": (c_int32, [c_int32]),
+    "ch_hamming_hist_rec": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                                    c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ch_hamming_ap_rec": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                                  c_void_p, c_void_p, c_int32, c_void_p, c_void_p, POINTER(c_int64), c_int32, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
     "ch_adapter_arena_numel": (c_int64, [c_void_p]),
     "ch_trainer_create": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, POINTER(c_void_p)]),
     "ch_trainer_destroy": (None, [c_void_p]),

@@ -284,6 +284,27 @@ struct RankLimits {
     uint32_t lim[MAX_LIMITS];  // mAP@R cut-offs of one AP pass; 0xFFFFFFFF = the whole ranking
 };
 
+// one relevant row: exact global rank / relevant-rank from (base, position in bucket), AP term into every limit it is inside
+template <int NR>
+__device__ __forceinline__ void ap_account(uint2 b, uint32_t old, int skip, int frel, const RankLimits &lims,
+                                           unsigned long long (&S)[NR], uint32_t (&nrel)[NR]) {
+    uint32_t rank = b.x + (old & 0xFFFFu) + 1u;     // 1-based global rank
+    uint32_t relrank = b.y + (old >> 16) + 1u;      // 1-based rank among relevant rows
+    if (skip) {
+        if (rank == 1u) return;
+        rank -= 1u;
+        relrank -= (uint32_t)frel;
+    }
+    if (rank > lims.lim[NR - 1]) return;            // limits ascend: outside the largest = outside all
+    const unsigned long long term = fixdiv32(relrank, rank);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool in = rank <= lims.lim[r];
+        S[r] += in ? term : 0ull;
+        nrel[r] += in ? 1u : 0u;
+    }
+}
+
 // One lane per query; the gallery segment is wave-uniform and walked four rows per trip: codes and labels of a trip come
 // through ONE scalar load each (the next trip's block is requested before this one is consumed), distances are chained
 // v_bcnt, every row is one LDS counter update in the lane's own column (conflict free).
@@ -292,7 +313,18 @@ struct RankLimits {
 //           when some lane of the wave holds a relevant row in the trip is the "ranked before" base of each lane's relevant row
 //           gathered (`account_trip`) and its AP term added -- to NR accumulators, one per rank limit, so that mAP@R for a list
 //           of R, P@k and R@k all come out of a single pass.
+//   MODE 2: MODE 0 and MODE 1 in ONE scan (the record form): the histogram is built with ds_add_rtn, and every relevant row leaves
+//           a record (distance, returned counter) in a per-lane list in global memory -- what the AP term needs once the "ranked
+//           before" bases exist.  `ap_records_kernel` then walks the lists (G / C records per query instead of G rows): the
+//           second distance scan disappears.  Lists are bounded (`cap` records per lane and segment); a workgroup with a lane
+//           that overflows raises its flag and is redone by the MODE 1 kernel (which then skips every other workgroup).
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+struct RecordArgs {
+    uint2 *rec;           // [workgroup][cap][BLK] (distance, returned counter); workgroup = segment * tiles + tile
+    uint32_t *rec_cnt;    // [nseg][Qn] records of the lane (may exceed cap: then the workgroup is flagged)
+    uint32_t *wg_flags;   // [nseg * tiles] 1 = some list overflowed (zeroed by the caller); MODE 1: run only flagged workgroups
+    int cap;
+};
 
 // VM: the gallery arrives through VMEM in blocks of 16 rows spread over the lanes (in-order vmcnt, four blocks in flight) and is
 // broadcast by DPP operands -- instead of scalar loads.  SMEM shares lgkmcnt with the LDS atomics and returns out of order, so the
@@ -304,8 +336,11 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
                                                        const void *g_labels, int LW, int seg_rows,
                                                        uint32_t *__restrict__ out_hist, const uint32_t *__restrict__ base,
                                                        RankLimits lims, int nlim, const int32_t *__restrict__ first_rel,
-                                                       unsigned long long *out_S, uint32_t *out_nrel) {
+                                                       unsigned long long *out_S, uint32_t *out_nrel, RecordArgs ra) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];  // [nb][BLK]
+    const uint32_t wg_index = blockIdx.y * gridDim.x + blockIdx.x;
+    if (MODE == 1 && ra.wg_flags != nullptr && ra.wg_flags[wg_index] == 0u) return;   // fallback launch: only the workgroups whose
+                                                                                       // record lists overflowed (wave-uniform)
     constexpr int NB = 64 * W + 1;
     constexpr int UB = 4;
     const int tid = threadIdx.x;
@@ -340,24 +375,7 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
     const size_t brow = ((size_t)seg * Qn + (valid ? qi : 0)) * NB * 2;
     uint32_t *col = cnt + tid;
 
-    // one relevant row: exact global rank / relevant-rank from (base, position in bucket), AP term into every limit it is inside
-    auto account = [&](uint2 b, uint32_t old) {
-        uint32_t rank = b.x + (old & 0xFFFFu) + 1u;     // 1-based global rank
-        uint32_t relrank = b.y + (old >> 16) + 1u;      // 1-based rank among relevant rows
-        if (skip) {
-            if (rank == 1u) return;
-            rank -= 1u;
-            relrank -= (uint32_t)frel;
-        }
-        if (rank > lims.lim[NR - 1]) return;            // limits ascend: outside the largest = outside all
-        const unsigned long long term = fixdiv32(relrank, rank);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const bool in = rank <= lims.lim[r];
-            S[r] += in ? term : 0ull;
-            nrel[r] += in ? 1u : 0u;
-        }
-    };
+    auto account = [&](uint2 b, uint32_t old) { ap_account<NR>(b, old, skip, frel, lims, S, nrel); };
     // The relevant rows of the four-row trips (MODE 1).  With C classes a lane holds a relevant row in 4 / C of its trips, so SOME
     // lane of the wave does in most trips while nearly every lane has none; accounting inside the trip (a gather of the "ranked
     // before" base + an exact division, ~750 clocks with one wave per SIMD to hide nothing behind) is what bounded this pass.
@@ -372,7 +390,15 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
     // the previous trip, not yet parked (scalars, not arrays: an array the slow path below indexes ends up in scratch memory)
     uint32_t pd0 = 0, pd1 = 0, pd2 = 0, pd3 = 0, po0 = 0, po1 = 0, po2 = 0, po3 = 0, prev_m = 0;
     static_assert(UB == 4, "park_trip selects among four rows");
+    uint32_t nrec = 0;   // MODE 2: records this lane has produced
     auto gather_account = [&](bool has, uint32_t dd, uint32_t oo) {
+        if (MODE == 2) {
+            if (has) {
+                if (nrec < (uint32_t)ra.cap) ra.rec[((size_t)wg_index * ra.cap + nrec) * BLK + tid] = make_uint2(dd, oo);
+                nrec += 1u;
+            }
+            return;
+        }
         // lanes without a row read the wave-uniform head of `base`: one extra cache line instead of a divergent branch
         const uint2 b = *(const uint2 *)(has ? base + brow + 2 * dd : base);
         if (has) account(b, oo);
@@ -419,6 +445,9 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
         const uint32_t inc = 1u | ((uint32_t)rel << 16);
         if (MODE == 0) {
             atomicAdd(col + d * BLK, inc);
+        } else if (MODE == 2) {
+            const uint32_t old = atomicAdd(col + d * BLK, inc);
+            gather_account(rel, d, old);
         } else {
             const uint32_t old = atomicAdd(col + d * BLK, inc);
             if (rel) account(*(const uint2 *)(base + brow + 2 * d), old);
@@ -496,7 +525,7 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
             one(std::integral_constant<int, 1>{});
             one(std::integral_constant<int, 2>{});
             one(std::integral_constant<int, 3>{});
-            if (MODE == 1) park_trip();     // the previous trip's rows; its counters came back long ago
+            if (MODE != 0) park_trip();     // the previous trip's rows; its counters came back long ago
 #pragma unroll
             for (int u = 0; u < UB; ++u) {  // in row order: two rows of a trip may share a bucket
                 const uint32_t inc = 1u | ((uint32_t)rel[u] << 16);
@@ -505,7 +534,7 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
                 else
                     old[u] = atomicAdd(col + d[u] * BLK, inc);
             }
-            if (MODE == 1) keep_trip(d, old, rel);
+            if (MODE != 0) keep_trip(d, old, rel);
         };
         auto scan_vblk = [&](const VBlk &b) {
             group(b, std::integral_constant<int, 0>{});
@@ -562,7 +591,7 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
                 d[u] = (uint32_t)hamming<W>(qw, blk + u * W);
                 rel[u] = valid && (lab[u] == qlab);
             }
-            if (MODE == 1) park_trip();     // the previous trip's rows; its counters came back long ago
+            if (MODE != 0) park_trip();     // the previous trip's rows; its counters came back long ago
 #pragma unroll
             for (int u = 0; u < UB; ++u) {  // in row order: two rows of a trip may share a bucket
                 const uint32_t inc = 1u | ((uint32_t)rel[u] << 16);
@@ -571,7 +600,7 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
                 else
                     old[u] = atomicAdd(col + d[u] * BLK, inc);
             }
-            if (MODE == 1) keep_trip(d, old, rel);
+            if (MODE != 0) keep_trip(d, old, rel);
         };
         if (n >= UB) load_block(bufA, labA, 0);
         for (; j + 2 * UB <= n; j += 2 * UB) {
@@ -589,11 +618,15 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
         for (; j < n; ++j) row(gp + (size_t)j * W, valid && relevant_multi(qm, glm + (size_t)j * LW, LW));
     }
 
-    if (MODE == 1) {
+    if (MODE != 0) {
         park_trip();
         drain();
     }
-    if (MODE == 0) {
+    if (MODE == 2) {
+        if (valid) ra.rec_cnt[(size_t)seg * Qn + qi] = nrec;
+        if (__builtin_amdgcn_ballot_w64(nrec > (uint32_t)ra.cap) != 0ull && (tid & 63) == 0) ra.wg_flags[wg_index] = 1u;
+    }
+    if (MODE == 0 || MODE == 2) {
         // out_hist[seg][q][bucket] = (count, relevant count): element e of this tile's [BLK][NB] block is written by thread
         // e % BLK -> consecutive lanes write consecutive 8-byte elements
         __syncthreads();
@@ -613,6 +646,52 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
                     atomicAdd(out_nrel + (size_t)r * Qn + qi, nrel[r]);
                 }
         }
+    }
+}
+
+// The AP pass of the record form: one lane per query (same grid as the scan), walking the records its MODE 2 workgroup left.
+// Workgroups whose lists overflowed are skipped here and redone by the MODE 1 scan.
+template <int NR>
+__global__ __launch_bounds__(256) void ap_records_kernel(int64_t Qn, int NB, RecordArgs ra, const uint32_t *__restrict__ base,
+                                                         RankLimits lims, int nlim, const int32_t *__restrict__ first_rel,
+                                                         unsigned long long *out_S, uint32_t *out_nrel) {
+    const int BLK = blockDim.x, tid = threadIdx.x;
+    const uint32_t wg_index = blockIdx.y * gridDim.x + blockIdx.x;
+    if (ra.wg_flags[wg_index] != 0u) return;
+    const int seg = blockIdx.y;
+    const int64_t qi = (int64_t)blockIdx.x * BLK + tid;
+    const bool valid = qi < Qn;
+    const uint32_t n = valid ? ra.rec_cnt[(size_t)seg * Qn + qi] : 0u;
+    unsigned long long S[NR];
+    uint32_t nrel[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        S[r] = 0ull;
+        nrel[r] = 0;
+    }
+    int skip = 0, frel = 0;
+    if (first_rel != nullptr) {
+        skip = 1;
+        frel = valid ? first_rel[qi] : 0;
+    }
+    const uint32_t *brow = base + ((size_t)seg * Qn + (valid ? qi : 0)) * NB * 2;
+    const uint2 *rp = ra.rec + (size_t)wg_index * ra.cap * BLK + tid;
+    // two records per trip: both record loads, then both base gathers, in flight together
+    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0ull; k += 2) {
+        const bool h0 = k < n, h1 = k + 1 < n;
+        const uint2 r0 = h0 ? rp[(size_t)k * BLK] : make_uint2(0u, 0u);
+        const uint2 r1 = h1 ? rp[(size_t)(k + 1) * BLK] : make_uint2(0u, 0u);
+        const uint2 b0 = *(const uint2 *)(brow + 2 * r0.x), b1 = *(const uint2 *)(brow + 2 * r1.x);
+        if (h0) ap_account<NR>(b0, r0.y, skip, frel, lims, S, nrel);
+        if (h1) ap_account<NR>(b1, r1.y, skip, frel, lims, S, nrel);
+    }
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (r < nlim && nrel[r]) {
+                atomicAdd(out_S + (size_t)r * Qn + qi, S[r]);
+                atomicAdd(out_nrel + (size_t)r * Qn + qi, nrel[r]);
+            }
     }
 }
 
@@ -666,65 +745,81 @@ __global__ __launch_bounds__(256) void hist_prefix_kernel(const uint32_t *__rest
     }
 }
 
+struct ScanArgs {   // everything a map_scan_kernel launch takes
+    const uint64_t *q;
+    int64_t Qn;
+    const uint64_t *g;
+    int64_t G;
+    const void *ql, *gl;
+    int LW, seg_rows;
+    uint32_t *out_hist;
+    const uint32_t *base;
+    RankLimits lims;
+    int nlim;
+    const int32_t *first_rel;
+    unsigned long long *out_S;
+    uint32_t *out_nrel;
+    RecordArgs ra;
+};
+
 template <int W, int BLK, int MODE, int NR, bool VM>
-int launch_scan_vm(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql, const void *gl, int LW,
-                   int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims, int nlim,
-                   const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
-    const int nseg = (int)ceil_div64(G, seg_rows);
+int launch_scan_vm(const ScanArgs &a, hipStream_t s) {
+    const int nseg = (int)ceil_div64(a.G, a.seg_rows);
     const size_t lds = sizeof(uint32_t) * (64 * W + 1) * BLK;
-    dim3 grid((unsigned)ceil_div64(Qn, BLK), (unsigned)nseg);
+    dim3 grid((unsigned)ceil_div64(a.Qn, BLK), (unsigned)nseg);
     static ch_once_per_device lds_once;
     if (int e = ch_func_max_lds((const void *)map_scan_kernel<W, BLK, MODE, NR, VM>, (int)lds, lds_once)) return e;
-    hipLaunchKernelGGL((map_scan_kernel<W, BLK, MODE, NR, VM>), grid, dim3(BLK), lds, s, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist,
-                       base, lims, nlim, first_rel, out_S, out_nrel);
+    hipLaunchKernelGGL((map_scan_kernel<W, BLK, MODE, NR, VM>), grid, dim3(BLK), lds, s, a.q, a.Qn, a.g, a.G, a.ql, a.gl, a.LW, a.seg_rows,
+                       a.out_hist, a.base, a.lims, a.nlim, a.first_rel, a.out_S, a.out_nrel, a.ra);
     CH_LAUNCH_CHECK();
     return 0;
 }
 
 template <int W, int BLK, int MODE, int NR>
-int launch_scan_nr(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql, const void *gl, int LW,
-                   int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims, int nlim,
-                   const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
-    // Both passes take the gallery through VMEM in 16-row blocks spread over the lanes + DPP broadcast (at 16,384 x 1M x 128 bit:
+int launch_scan_nr(const ScanArgs &a, hipStream_t s) {
+    // All passes take the gallery through VMEM in 16-row blocks spread over the lanes + DPP broadcast (at 16,384 x 1M x 128 bit:
     // histogram pass 18.9 ms with scalar loads -> 14.4 ms with same-address VMEM loads -> 8.0 ms; AP pass 39 -> 16 ms together
-    // with the parked accounting).  CH_HAMMING_VMEM=0 = the scalar-load form of both (same results; kept as the cross-check).
+    // with the parked accounting).  CH_HAMMING_VMEM=0 = the scalar-load form (same results; kept as the cross-check).
     static const bool vm_env = !(getenv("CH_HAMMING_VMEM") && atoi(getenv("CH_HAMMING_VMEM")) == 0);
-    if (vm_env)
-        return launch_scan_vm<W, BLK, MODE, NR, true>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
-    return launch_scan_vm<W, BLK, MODE, NR, false>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
+    if (vm_env) return launch_scan_vm<W, BLK, MODE, NR, true>(a, s);
+    return launch_scan_vm<W, BLK, MODE, NR, false>(a, s);
 }
 
+// mode 0: histogram, 1: AP pass (all workgroups, or only the flagged ones when a.ra.wg_flags is set), 2: histogram + records
 template <int W, int BLK>
-int launch_scan(int mode, int nlim, const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, const void *ql,
-                const void *gl, int LW, int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims,
-                const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
-    if (mode == 0)
-        return launch_scan_nr<W, BLK, 0, 1>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
-    if (nlim == 1)
-        return launch_scan_nr<W, BLK, 1, 1>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
-    if (nlim <= 4)
-        return launch_scan_nr<W, BLK, 1, 4>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
-    return launch_scan_nr<W, BLK, 1, MAX_LIMITS>(q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, nlim, first_rel, out_S, out_nrel, s);
+int launch_scan(int mode, const ScanArgs &a, hipStream_t s) {
+    if (mode == 0) return launch_scan_nr<W, BLK, 0, 1>(a, s);
+    if (mode == 2) return launch_scan_nr<W, BLK, 2, 1>(a, s);
+    if (a.nlim == 1) return launch_scan_nr<W, BLK, 1, 1>(a, s);
+    if (a.nlim <= 4) return launch_scan_nr<W, BLK, 1, 4>(a, s);
+    return launch_scan_nr<W, BLK, 1, MAX_LIMITS>(a, s);
 }
 
 // lims: nlim ascending rank limits, padded to MAX_LIMITS with copies of the last one (the kernel instance accumulates
 // NR = 1 / 4 / 16 of them and stores rows [0, nlim) of out_S / out_nrel)
-int scan_dispatch(int mode, const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int W, const void *ql,
-                  const void *gl, int LW, int seg_rows, uint32_t *out_hist, const uint32_t *base, const RankLimits &lims,
-                  int nlim, const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, hipStream_t s) {
+int scan_dispatch(int mode, const ScanArgs &a, int W, hipStream_t s) {
     CH_REQUIRE(W >= 1 && W <= 4, "hamming: 1 <= W <= 4 (nbit <= 256)");
-    CH_REQUIRE(seg_rows >= 1 && seg_rows <= 65535, "hamming: seg_rows must be in [1, 65535]");
-    CH_REQUIRE(LW >= 0, "hamming: LW must be >= 0");
-    CH_REQUIRE(Qn >= 0 && G >= 0, "hamming: negative sizes");
-    if (Qn == 0 || G == 0) return 0;
-    CH_REQUIRE(q && g && ql && gl, "hamming: null pointer");
-    CH_REQUIRE(ceil_div64(G, seg_rows) <= 65535, "hamming: too many gallery segments (raise seg_rows)");
+    CH_REQUIRE(a.seg_rows >= 1 && a.seg_rows <= 65535, "hamming: seg_rows must be in [1, 65535]");
+    CH_REQUIRE(a.LW >= 0, "hamming: LW must be >= 0");
+    CH_REQUIRE(a.Qn >= 0 && a.G >= 0, "hamming: negative sizes");
+    if (a.Qn == 0 || a.G == 0) return 0;
+    CH_REQUIRE(a.q && a.g && a.ql && a.gl, "hamming: null pointer");
+    CH_REQUIRE(ceil_div64(a.G, a.seg_rows) <= 65535, "hamming: too many gallery segments (raise seg_rows)");
     switch (W) {
-        case 1: return launch_scan<1, 256>(mode, nlim, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, first_rel, out_S, out_nrel, s);
-        case 2: return launch_scan<2, 256>(mode, nlim, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, first_rel, out_S, out_nrel, s);
-        case 3: return launch_scan<3, 128>(mode, nlim, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, first_rel, out_S, out_nrel, s);
-        default: return launch_scan<4, 128>(mode, nlim, q, Qn, g, G, ql, gl, LW, seg_rows, out_hist, base, lims, first_rel, out_S, out_nrel, s);
+        case 1: return launch_scan<1, 256>(mode, a, s);
+        case 2: return launch_scan<2, 256>(mode, a, s);
+        case 3: return launch_scan<3, 128>(mode, a, s);
+        default: return launch_scan<4, 128>(mode, a, s);
     }
+}
+
+bool fill_limits(const int64_t *rank_limits, int nlimits, RankLimits &lims) {
+    for (int i = 0; i < MAX_LIMITS; ++i) {
+        const int64_t r = rank_limits[i < nlimits ? i : nlimits - 1];
+        lims.lim[i] = (r <= 0 || r >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (uint32_t)r;
+        if (i > 0 && lims.lim[i] < lims.lim[i - 1]) return false;
+    }
+    return true;
 }
 
 int topk_seg_rows(int64_t Qn, int64_t G, int k) {
@@ -832,9 +927,8 @@ extern "C" int ch_topk_merge(const int64_t *idx_lists, const int32_t *dist_lists
 extern "C" int ch_hamming_hist(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
                                const void *g_labels, int32_t LW, int32_t seg_rows, uint32_t *out_hist, void *stream) {
     CH_REQUIRE(Qn == 0 || G == 0 || out_hist != nullptr, "hamming_hist: null output");
-    RankLimits lims{};
-    return scan_dispatch(0, q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, out_hist, nullptr, lims, 1, nullptr, nullptr, nullptr,
-                         (hipStream_t)stream);
+    ScanArgs a{q, Qn, g, G, q_labels, g_labels, LW, seg_rows, out_hist, nullptr, RankLimits{}, 1, nullptr, nullptr, nullptr, RecordArgs{}};
+    return scan_dispatch(0, a, W, (hipStream_t)stream);
 }
 
 extern "C" int ch_hamming_ap_multi(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
@@ -844,13 +938,9 @@ extern "C" int ch_hamming_ap_multi(const uint64_t *q, int64_t Qn, const uint64_t
     CH_REQUIRE(nlimits >= 1 && nlimits <= MAX_LIMITS && rank_limits != nullptr, "hamming_ap_multi: 1 <= nlimits <= 16");
     CH_REQUIRE(Qn == 0 || G == 0 || (base && out_S && out_nrel), "hamming_ap_multi: null pointer");
     RankLimits lims;
-    for (int i = 0; i < MAX_LIMITS; ++i) {
-        const int64_t r = rank_limits[i < nlimits ? i : nlimits - 1];
-        lims.lim[i] = (r <= 0 || r >= 0xFFFFFFFFll) ? 0xFFFFFFFFu : (uint32_t)r;
-        CH_REQUIRE(i == 0 || lims.lim[i] >= lims.lim[i - 1], "hamming_ap_multi: rank limits must ascend (<= 0 = unlimited, last)");
-    }
-    return scan_dispatch(1, q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, nullptr, base, lims, nlimits, first_rel, out_S, out_nrel,
-                         (hipStream_t)stream);
+    CH_REQUIRE(fill_limits(rank_limits, nlimits, lims), "hamming_ap_multi: rank limits must ascend (<= 0 = unlimited, last)");
+    ScanArgs a{q, Qn, g, G, q_labels, g_labels, LW, seg_rows, nullptr, base, lims, nlimits, first_rel, out_S, out_nrel, RecordArgs{}};
+    return scan_dispatch(1, a, W, (hipStream_t)stream);
 }
 
 extern "C" int ch_hamming_ap(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
@@ -858,6 +948,51 @@ extern "C" int ch_hamming_ap(const uint64_t *q, int64_t Qn, const uint64_t *g, i
                              const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, void *stream) {
     return ch_hamming_ap_multi(q, Qn, g, G, W, q_labels, g_labels, LW, seg_rows, base, &rank_limit, 1, first_rel, out_S, out_nrel,
                                stream);
+}
+
+// ---- record form: ONE distance scan (csrc/hamming.hip, MODE 2) --------------------------------------------------------------
+extern "C" size_t ch_hamming_rec_workgroups(int64_t Qn, int64_t G, int32_t W, int32_t seg_rows) {
+    if (Qn <= 0 || G <= 0 || seg_rows <= 0) return 0;
+    return (size_t)(ceil_div64(Qn, W <= 2 ? 256 : 128) * ceil_div64(G, seg_rows));
+}
+extern "C" int32_t ch_hamming_rec_block(int32_t W) { return W <= 2 ? 256 : 128; }
+
+extern "C" int ch_hamming_hist_rec(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                                   const void *g_labels, int32_t LW, int32_t seg_rows, uint32_t *out_hist, void *rec,
+                                   int32_t rec_cap, uint32_t *rec_cnt, uint32_t *wg_flags, void *stream) {
+    CH_REQUIRE(Qn == 0 || G == 0 || (out_hist && rec && rec_cnt && wg_flags), "hamming_hist_rec: null pointer");
+    CH_REQUIRE(rec_cap >= 1, "hamming_hist_rec: rec_cap must be >= 1");
+    ScanArgs a{q, Qn, g, G, q_labels, g_labels, LW, seg_rows, out_hist, nullptr, RankLimits{}, 1, nullptr, nullptr, nullptr,
+               RecordArgs{(uint2 *)rec, rec_cnt, wg_flags, rec_cap}};
+    return scan_dispatch(2, a, W, (hipStream_t)stream);
+}
+
+extern "C" int ch_hamming_ap_rec(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                                 const void *g_labels, int32_t LW, int32_t seg_rows, const uint32_t *base, const void *rec,
+                                 int32_t rec_cap, const uint32_t *rec_cnt, const uint32_t *wg_flags, const int64_t *rank_limits,
+                                 int32_t nlimits, const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel,
+                                 void *stream) {
+    CH_REQUIRE(nlimits >= 1 && nlimits <= MAX_LIMITS && rank_limits != nullptr, "hamming_ap_rec: 1 <= nlimits <= 16");
+    CH_REQUIRE(W >= 1 && W <= 4, "hamming_ap_rec: 1 <= W <= 4");
+    CH_REQUIRE(seg_rows >= 1 && seg_rows <= 65535 && rec_cap >= 1, "hamming_ap_rec: bad seg_rows / rec_cap");
+    if (Qn <= 0 || G <= 0) return 0;
+    CH_REQUIRE(base && rec && rec_cnt && wg_flags && out_S && out_nrel, "hamming_ap_rec: null pointer");
+    RankLimits lims;
+    CH_REQUIRE(fill_limits(rank_limits, nlimits, lims), "hamming_ap_rec: rank limits must ascend (<= 0 = unlimited, last)");
+    hipStream_t s = (hipStream_t)stream;
+    const int BLK = W <= 2 ? 256 : 128, NB = 64 * W + 1;
+    dim3 grid((unsigned)ceil_div64(Qn, BLK), (unsigned)ceil_div64(G, seg_rows));
+    RecordArgs ra{(uint2 *)rec, (uint32_t *)rec_cnt, (uint32_t *)wg_flags, rec_cap};
+    if (nlimits == 1)
+        hipLaunchKernelGGL(ap_records_kernel<1>, grid, dim3(BLK), 0, s, Qn, NB, ra, base, lims, nlimits, first_rel, out_S, out_nrel);
+    else if (nlimits <= 4)
+        hipLaunchKernelGGL(ap_records_kernel<4>, grid, dim3(BLK), 0, s, Qn, NB, ra, base, lims, nlimits, first_rel, out_S, out_nrel);
+    else
+        hipLaunchKernelGGL(ap_records_kernel<MAX_LIMITS>, grid, dim3(BLK), 0, s, Qn, NB, ra, base, lims, nlimits, first_rel, out_S, out_nrel);
+    CH_LAUNCH_CHECK();
+    // the workgroups whose lists overflowed: the two-scan form, which skips every unflagged workgroup at its first instruction
+    ScanArgs a{q, Qn, g, G, q_labels, g_labels, LW, seg_rows, nullptr, base, lims, nlimits, first_rel, out_S, out_nrel, ra};
+    return scan_dispatch(1, a, W, s);
 }
 
 extern "C" int ch_hamming_hist_prefix(const uint32_t *hist, int32_t nseg, int64_t Qn, int32_t nb, uint32_t *out_base,

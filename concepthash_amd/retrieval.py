@@ -8,6 +8,7 @@ Replaces the reference's un-vendored ``utils.hashing`` arithmetic (call sites ex
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -230,6 +231,68 @@ def hamming_ap_multi(q, g, q_lab, g_lab, LW: int, seg_rows: int, base: torch.Ten
     return S, nrel
 
 
+REC_BUDGET_BYTES = 4 << 30     # upper bound of the record buffer of one evaluation
+
+
+def record_cap(Qn: int, G: int, W: int, seg_rows: int) -> int:
+    """Entries per (query, segment) record list of the one-scan form: room for one relevant row in 64 (any label distribution with
+    no class above ~1.5 % of a segment fits; a (tile, segment) workgroup whose lists overflow is redone by the two-scan kernel, so
+    this only decides speed), bounded by the segment length and by REC_BUDGET_BYTES for the whole buffer."""
+    lib = _lib.load()
+    wgs = int(lib.ch_hamming_rec_workgroups(Qn, G, W, seg_rows))
+    blk = int(lib.ch_hamming_rec_block(W))
+    cap = min(seg_rows, seg_rows // 64 + 32)
+    return int(max(1, min(cap, REC_BUDGET_BYTES // max(1, wgs * blk * 8))))
+
+
+def hamming_hist_rec(q, g, q_lab, g_lab, LW: int, seg_rows: int, rec_cap: Optional[int] = None, stream=None):
+    """mAP pass 1 of the one-scan form: the histogram of hamming_hist plus the per-lane record lists of the relevant rows
+    -> (hist, records) where records = (rec, rec_cap, rec_cnt, wg_flags) is what hamming_ap_rec takes."""
+    lib = _lib.load()
+    q, g = _check_packed(q, g)
+    Qn, W = q.shape
+    G = g.shape[0]
+    nseg = max(1, -(-G // seg_rows))
+    cap = int(rec_cap) if rec_cap else record_cap(Qn, G, W, seg_rows)
+    wgs = int(lib.ch_hamming_rec_workgroups(Qn, G, W, seg_rows))
+    blk = int(lib.ch_hamming_rec_block(W))
+    hist = (torch.empty if G > 0 else torch.zeros)(nseg, Qn, 64 * W + 1, 2, dtype=torch.int32, device=q.device)
+    rec = torch.empty(max(1, wgs) * cap * blk, 2, dtype=torch.int32, device=q.device)
+    rec_cnt = torch.empty(nseg, Qn, dtype=torch.int32, device=q.device)
+    wg_flags = torch.zeros(max(1, wgs), dtype=torch.int32, device=q.device)
+    with _dev_guard(q):
+        _lib.check(lib.ch_hamming_hist_rec(_lib.ptr(q), Qn, _lib.ptr(g), G, W, _lib.ptr(q_lab), _lib.ptr(g_lab), LW, seg_rows,
+                                           _lib.ptr(hist), _lib.ptr(rec), cap, _lib.ptr(rec_cnt), _lib.ptr(wg_flags),
+                                           _lib.stream_ptr(stream)), "ch_hamming_hist_rec")
+    return hist, (rec, cap, rec_cnt, wg_flags)
+
+
+def hamming_ap_rec(q, g, q_lab, g_lab, LW: int, seg_rows: int, base: torch.Tensor, records, rank_limits: Sequence[int],
+                   first_rel: Optional[torch.Tensor] = None, stream=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """hamming_ap_multi from the records of hamming_hist_rec (no second distance scan except for overflowed workgroups)."""
+    lib = _lib.load()
+    q, g = _check_packed(q, g)
+    Qn, W = q.shape
+    G = g.shape[0]
+    rec, cap, rec_cnt, wg_flags = records
+    lim = [int(r) for r in rank_limits]
+    n = len(lim)
+    S = torch.zeros(n, Qn, dtype=torch.int64, device=q.device)
+    nrel = torch.zeros(n, Qn, dtype=torch.int32, device=q.device)
+    if first_rel is not None:
+        first_rel = first_rel.to(torch.int32).contiguous()
+    base = base.contiguous()
+    with _dev_guard(q):
+        for c0 in range(0, n, MAX_LIMITS):
+            chunk = lim[c0:c0 + MAX_LIMITS]
+            arr = (ctypes.c_int64 * len(chunk))(*chunk)
+            _lib.check(lib.ch_hamming_ap_rec(_lib.ptr(q), Qn, _lib.ptr(g), G, W, _lib.ptr(q_lab), _lib.ptr(g_lab), LW, seg_rows,
+                                             _lib.ptr(base), _lib.ptr(rec), cap, _lib.ptr(rec_cnt), _lib.ptr(wg_flags), arr,
+                                             len(chunk), _lib.ptr(first_rel), _lib.ptr(S[c0:c0 + len(chunk)]),
+                                             _lib.ptr(nrel[c0:c0 + len(chunk)]), _lib.stream_ptr(stream)), "ch_hamming_ap_rec")
+    return S, nrel
+
+
 def ap_from_fixed(S: torch.Tensor, nrel: torch.Tensor) -> torch.Tensor:
     """AP[q] = S / (nrel * 2^32) in float64 (0 where nrel == 0); S holds uint64 bit patterns."""
     Sf = S.to(torch.float64)
@@ -262,11 +325,14 @@ def summarize(S, nrel, total, idx_of, Rs: Sequence[int], ks: Sequence[int]) -> d
 
 
 def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels: torch.Tensor, R=-1,
-             ks: Sequence[int] = (1, 5, 10), remove_first: bool = False, seg_rows: Optional[int] = None) -> dict:
+             ks: Sequence[int] = (1, 5, 10), remove_first: bool = False, seg_rows: Optional[int] = None,
+             records: Optional[bool] = None, rec_cap: Optional[int] = None) -> dict:
     """Single-GPU mAP@R + P@k + R@k on packed codes: histogram pass, prefix, ONE AP pass whose rank limits are R (an int or
     a list) and every k -- the number of relevant rows inside limit k is exactly hits@k, for any k.  Returns python
     floats/lists plus the raw integer statistics (S, nrel, hits, total) that the parity tests compare bit-for-bit with the
-    oracle.  With a list R: mAP, S, nrel, ap are lists (one entry per R)."""
+    oracle.  With a list R: mAP, S, nrel, ap are lists (one entry per R).
+    records (default on; CH_HAMMING_RECORDS=0 = off): the one-scan form -- the histogram pass also records the relevant rows and
+    the AP pass walks those records instead of scanning the gallery again; rec_cap overrides the list capacity (tests)."""
     q, g = _check_packed(q, g)
     Qn, W = q.shape
     G = g.shape[0]
@@ -291,9 +357,16 @@ def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels:
         idx, _ = hamming_topk(q, g, 1)
         first_rel = _relevance_of(idx, q_lab, g_lab, LW)[:, 0].to(torch.int32)
     limits, idx_of = normalize_limits(Rs + ks)
-    hist = hamming_hist(q, g, q_lab, g_lab, LW, seg)
-    base, totals = hist_prefix(hist)
-    S, nrel = hamming_ap_multi(q, g, q_lab, g_lab, LW, seg, base, limits, first_rel=first_rel)
+    if records is None:
+        records = os.environ.get("CH_HAMMING_RECORDS", "1") != "0"
+    if records:   # one distance scan: histogram + records of the relevant rows, prefix, then the AP terms from the records
+        hist, recs = hamming_hist_rec(q, g, q_lab, g_lab, LW, seg, rec_cap=rec_cap)
+        base, totals = hist_prefix(hist)
+        S, nrel = hamming_ap_rec(q, g, q_lab, g_lab, LW, seg, base, recs, limits, first_rel=first_rel)
+    else:         # two scans (the round-1 / early round-2 form; also what the sharded evaluator runs)
+        hist = hamming_hist(q, g, q_lab, g_lab, LW, seg)
+        base, totals = hist_prefix(hist)
+        S, nrel = hamming_ap_multi(q, g, q_lab, g_lab, LW, seg, base, limits, first_rel=first_rel)
     total = totals[:, 1].clone()
     if remove_first:
         total = total - first_rel

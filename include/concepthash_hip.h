@@ -278,6 +278,24 @@ int ch_hamming_ap_multi(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_
                         const int64_t *rank_limits, int32_t nlimits, const int32_t *first_rel, unsigned long long *out_S,
                         uint32_t *out_nrel, void *stream);
 
+/* Record form of the two passes: ONE distance scan.  ch_hamming_hist_rec is ch_hamming_hist that additionally leaves, for every
+ * relevant (query, gallery row) pair, a record (distance, position inside its (segment, query, distance) bucket) in a per-lane list:
+ * rec = uint2[ch_hamming_rec_workgroups() * rec_cap * ch_hamming_rec_block(W)], rec_cnt = uint32[nseg, Qn] (list lengths),
+ * wg_flags = uint32[ch_hamming_rec_workgroups()], ZEROED by the caller, set to 1 for a (query tile, segment) workgroup in which
+ * some list needed more than rec_cap entries.  ch_hamming_ap_rec then produces exactly what ch_hamming_ap_multi produces (same
+ * arguments + the record buffers; out_S / out_nrel zeroed by the caller): it walks the lists -- G / C records per query instead of
+ * G rows -- and redoes the flagged workgroups by the two-scan kernel, so the result does not depend on rec_cap.  Replaces the second
+ * scan of calculate_mAP's ranking (experiments/test_hashing.py:114-119) where the label distribution lets the lists stay short. */
+size_t ch_hamming_rec_workgroups(int64_t Qn, int64_t G, int32_t W, int32_t seg_rows);
+int32_t ch_hamming_rec_block(int32_t W);
+int ch_hamming_hist_rec(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                        const void *g_labels, int32_t LW, int32_t seg_rows, uint32_t *out_hist, void *rec, int32_t rec_cap,
+                        uint32_t *rec_cnt, uint32_t *wg_flags, void *stream);
+int ch_hamming_ap_rec(const uint64_t *q, int64_t Qn, const uint64_t *g, int64_t G, int32_t W, const void *q_labels,
+                      const void *g_labels, int32_t LW, int32_t seg_rows, const uint32_t *base, const void *rec, int32_t rec_cap,
+                      const uint32_t *rec_cnt, const uint32_t *wg_flags, const int64_t *rank_limits, int32_t nlimits,
+                      const int32_t *first_rel, unsigned long long *out_S, uint32_t *out_nrel, void *stream);
+
 /* Single-GPU helper: hist [nseg,Qn,nb,2] -> base (same shape) + totals[Qn,2] (rows, relevant rows overall). */
 int ch_hamming_hist_prefix(const uint32_t *hist, int32_t nseg, int64_t Qn, int32_t nb, uint32_t *out_base,
                            uint32_t *out_totals, void *stream);

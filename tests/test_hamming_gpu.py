@@ -469,3 +469,35 @@ def test_scalar_load_form_of_the_map_passes_is_bit_identical(dev):
     g, gl = ho.synthetic_codes(7777, 128, seed=32, nclass=12, flip=0.15)
     ref = ho.mean_ap(q, g, ql, gl, R=-1, ks=(1, 5, 10), remove_first=True)
     assert hashlib.sha256(np.ascontiguousarray(ref["S"]).tobytes()).hexdigest() == default["128"][0]
+
+
+@pytest.mark.parametrize("nbit", [64, 128, 192])
+def test_record_form_equals_two_scan_form_and_survives_overflow(dev, nbit):
+    """The one-scan evaluation (histogram pass that records the relevant rows + AP terms from the records, csrc/hamming.hip MODE 2)
+    against the two-scan form and the oracle: default capacity, a capacity of 1 and 3 records per list (nearly every workgroup
+    overflows and is redone by the two-scan kernel), a gallery SORTED by class (whole segments relevant to a query), multi-hot
+    labels, remove_first and several rank limits."""
+    from concepthash_amd import retrieval as rt
+    from oracle import hamming_oracle as ho
+    rng = np.random.default_rng(nbit)
+    q, ql = ho.synthetic_codes(700, nbit, seed=51, nclass=7, flip=0.2)
+    g, gl = ho.synthetic_codes(6000, nbit, seed=52, nclass=7, flip=0.2)
+    order = np.argsort(gl, kind="stable")
+    cases = [("shuffled", g, gl), ("sorted", g[order], gl[order])]
+    for name, gg, ggl in cases:
+        refs = [ho.mean_ap(q, gg, ql, ggl, R=R, ks=(1, 5, 10), remove_first=True) for R in (-1, 100)]
+        for kw in (dict(records=False), dict(records=True), dict(records=True, rec_cap=1), dict(records=True, rec_cap=3),
+                   dict(records=True, seg_rows=257)):
+            got = rt.evaluate(_t(q, dev), _t(gg, dev), _t(ql, dev), _t(ggl, dev), R=[-1, 100], ks=(1, 5, 10), remove_first=True, **kw)
+            for i in range(2):
+                assert np.array_equal(got["S"][i].cpu().numpy().view(np.uint64), refs[i]["S"]), (name, kw, i)
+                assert np.array_equal(got["nrel"][i].cpu().numpy().astype(np.uint32), refs[i]["nrel"]), (name, kw, i)
+            assert np.array_equal(got["hits"].cpu().numpy().astype(np.uint32), refs[0]["hits"]), (name, kw)
+    # multi-hot relevance goes through the single-row form of the scan
+    qlab = (rng.random((700, 70)) < 0.05).astype(np.int64)
+    glab = (rng.random((6000, 70)) < 0.05).astype(np.int64)
+    ref = ho.mean_ap(q, g, qlab, glab, R=-1, ks=(1, 5, 10), remove_first=False)
+    for kw in (dict(records=True), dict(records=True, rec_cap=2)):
+        got = rt.evaluate(_t(q, dev), _t(g, dev), _t(qlab, dev), _t(glab, dev), R=-1, ks=(1, 5, 10), **kw)
+        assert np.array_equal(got["S"].cpu().numpy().view(np.uint64), ref["S"]), kw
+        assert np.array_equal(got["nrel"].cpu().numpy().astype(np.uint32), ref["nrel"]), kw

@@ -52,10 +52,16 @@ if a.mode in ("map", "both"):
     limits, _ = rt.normalize_limits([-1, 1, 5, 10])
     s_a1, _ = timed(lambda: rt.hamming_ap_multi(q, g, ql, gl, 0, seg, base, [0]), a.reps)
     s_a4, _ = timed(lambda: rt.hamming_ap_multi(q, g, ql, gl, 0, seg, base, limits), a.reps)
+    s_hr, (hist2, recs) = timed(lambda: rt.hamming_hist_rec(q, g, ql, gl, 0, seg), a.reps)
+    s_ar, _ = timed(lambda: rt.hamming_ap_rec(q, g, ql, gl, 0, seg, base, recs, limits), a.reps)
+    s_e2, ev2 = timed(lambda: rt.evaluate(q, g, ql, gl, R=-1, ks=(1, 5, 10), records=False), max(1, a.reps // 2))
     s_e, ev = timed(lambda: rt.evaluate(q, g, ql, gl, R=-1, ks=(1, 5, 10)), max(1, a.reps // 2))
     print(f"mAP@all {a.queries} x {a.rows} x {a.nbit} bit, {a.classes} classes, seg_rows {seg} ({hist.shape[0]} segments):")
     print(f"  hist pass     {s_h * 1e3:9.3f} ms  {pairs / s_h:.4g} cmp/s")
     print(f"  hist_prefix   {s_p * 1e3:9.3f} ms  ({hist.numel() * 4 * 2 / s_p / 1e9:.0f} GB/s over read + write)")
     print(f"  AP pass, 1 limit  {s_a1 * 1e3:9.3f} ms  {pairs / s_a1:.4g} cmp/s")
     print(f"  AP pass, 4 limits {s_a4 * 1e3:9.3f} ms  {pairs / s_a4:.4g} cmp/s")
+    print(f"  one-scan form: hist + records {s_hr * 1e3:9.3f} ms  {pairs / s_hr:.4g} cmp/s (lists of {recs[1]} entries, "
+          f"{int(recs[3].sum())} of {recs[3].numel()} workgroups overflowed); AP from records, 4 limits {s_ar * 1e3:9.3f} ms")
+    print(f"  evaluate() two-scan form                     {s_e2 * 1e3:9.3f} ms  mAP {ev2['mAP']:.6f}")
     print(f"  evaluate() end to end (mAP@all + P/R@1,5,10) {s_e * 1e3:9.3f} ms  {a.queries / s_e:.4g} queries/s  mAP {ev['mAP']:.6f}")
