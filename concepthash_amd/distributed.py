@@ -13,6 +13,7 @@ tests inject a CPU stand-in so that the collective choreography itself is covere
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -126,7 +127,13 @@ class ShardedRetrieval:
         gmax = max(self.counts) if self.counts else 0
         seg = seg_rows or ops.map_seg_rows(Qn, max(gmax, 1), W)
         nseg = max(1, -(-gmax // seg))
-        hist = ops.hamming_hist(q_all, self.gallery, q_lab, g_lab, LW, seg)            # [nseg_local, Qn, nb, 2]
+        # one-scan form where the ops provide it (concepthash_amd.retrieval does): the histogram pass also records this shard's
+        # relevant rows, and the AP terms come from the records once the GLOBAL bases exist (CH_HAMMING_RECORDS=0 = two scans)
+        use_rec = hasattr(ops, "hamming_hist_rec") and os.environ.get("CH_HAMMING_RECORDS", "1") != "0"
+        if use_rec:
+            hist, recs = ops.hamming_hist_rec(q_all, self.gallery, q_lab, g_lab, LW, seg)
+        else:
+            hist = ops.hamming_hist(q_all, self.gallery, q_lab, g_lab, LW, seg)        # [nseg_local, Qn, nb, 2]
         if hist.shape[0] < nseg:                                                       # shorter shard: pad with empty segments
             hist = torch.cat([hist, torch.zeros((nseg - hist.shape[0],) + tuple(hist.shape[1:]), dtype=hist.dtype,
                                                 device=dev)], dim=0)
@@ -134,7 +141,10 @@ class ShardedRetrieval:
         base_all, totals = ops.hist_prefix(hist_all)
         base = base_all[self.rank * nseg:(self.rank + 1) * nseg].contiguous()
         limits, idx_of = ops.normalize_limits(Rs + ks)
-        S, nrel = ops.hamming_ap_multi(q_all, self.gallery, q_lab, g_lab, LW, seg, base, limits, first_rel=first_rel)
+        if use_rec:
+            S, nrel = ops.hamming_ap_rec(q_all, self.gallery, q_lab, g_lab, LW, seg, base, recs, limits, first_rel=first_rel)
+        else:
+            S, nrel = ops.hamming_ap_multi(q_all, self.gallery, q_lab, g_lab, LW, seg, base, limits, first_rel=first_rel)
         if self.world > 1:
             dist.all_reduce(S, op=dist.ReduceOp.SUM, group=self.group)       # int64 wrap-around sum == uint64 sum
             dist.all_reduce(nrel, op=dist.ReduceOp.SUM, group=self.group)

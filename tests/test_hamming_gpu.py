@@ -260,6 +260,25 @@ def test_nabirds_sized_map_single_call_and_eight_way_shards(dev):
     for t in range(len(ks)):
         assert np.array_equal(nrel[idx_of[1 + t]].cpu().numpy().astype(np.uint32), ref["hits"][:, t])
     assert np.array_equal(totals[:, 1].cpu().numpy().astype(np.uint32), ref["total"])
+    # the same shards in the one-scan form (what ShardedRetrieval.evaluate runs): per-shard histogram + records, the GLOBAL
+    # prefix, per-shard AP terms from the shard's own records
+    hists, recs = [], []
+    for r in range(8):
+        h, rc = rt.hamming_hist_rec(gq, gg[b[r]:b[r + 1]], qlab, glab[b[r]:b[r + 1]], LW, seg)
+        if h.shape[0] < nseg:
+            h = torch.cat([h, torch.zeros((nseg - h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype, device=dev)])
+        hists.append(h)
+        recs.append(rc)
+    base_rec, _ = rt.hist_prefix(torch.cat(hists))
+    assert torch.equal(base_rec, base_all)
+    S2 = torch.zeros_like(S)
+    nrel2 = torch.zeros_like(nrel)
+    for r in range(8):
+        s_r, n_r = rt.hamming_ap_rec(gq, gg[b[r]:b[r + 1]], qlab, glab[b[r]:b[r + 1]], LW, seg,
+                                     base_rec[r * nseg:(r + 1) * nseg].contiguous(), recs[r], limits)
+        S2 += s_r
+        nrel2 += n_r
+    assert torch.equal(S2, S) and torch.equal(nrel2, nrel)
     parts = [rt.hamming_topk(gq, gg[b[r]:b[r + 1]], 10, g_index_base=b[r]) for r in range(8)]
     midx, mdst = rt.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     idx, dst = rt.hamming_topk(gq, gg, 10)
