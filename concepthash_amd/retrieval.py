@@ -232,17 +232,20 @@ def hamming_ap_multi(q, g, q_lab, g_lab, LW: int, seg_rows: int, base: torch.Ten
 
 
 REC_BUDGET_BYTES = 4 << 30     # upper bound of the record buffer of one evaluation
+REC_COMFORT_BYTES = 1 << 30    # ... and what is spent without need, for long lists (class-sorted galleries)
 
 
 def record_cap(Qn: int, G: int, W: int, seg_rows: int) -> int:
-    """Entries per (query, segment) record list of the one-scan form: room for one relevant row in 64 (any label distribution with
-    no class above ~1.5 % of a segment fits; a (tile, segment) workgroup whose lists overflow is redone by the two-scan kernel, so
-    this only decides speed), bounded by the segment length and by REC_BUDGET_BYTES for the whole buffer."""
+    """Entries per (query, segment) record list of the one-scan form.  At least room for one relevant row in 64 of a segment (+ 32:
+    any label distribution with no class above ~1.5 % of a segment fits), and as much more -- up to 2,048 entries -- as
+    REC_COMFORT_BYTES buys: galleries listed class by class put a whole class (hundreds of rows) into one segment's lists.  Never
+    above the segment length or REC_BUDGET_BYTES for the whole buffer.  A (tile, segment) workgroup whose lists overflow is redone
+    by the two-scan kernel, so this only decides speed."""
     lib = _lib.load()
     wgs = int(lib.ch_hamming_rec_workgroups(Qn, G, W, seg_rows))
-    blk = int(lib.ch_hamming_rec_block(W))
-    cap = min(seg_rows, seg_rows // 64 + 32)
-    return int(max(1, min(cap, REC_BUDGET_BYTES // max(1, wgs * blk * 8))))
+    unit = max(1, wgs * int(lib.ch_hamming_rec_block(W)) * 8)          # bytes per list entry over all lists
+    cap = max(seg_rows // 64 + 32, min(2048, REC_COMFORT_BYTES // unit))
+    return int(max(1, min(cap, seg_rows, REC_BUDGET_BYTES // unit)))
 
 
 def hamming_hist_rec(q, g, q_lab, g_lab, LW: int, seg_rows: int, rec_cap: Optional[int] = None, stream=None):
