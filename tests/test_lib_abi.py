@@ -74,3 +74,27 @@ def test_product_code_never_imports_the_oracle():
                             and "import" in src and re.search(r"import.*hamming_oracle|import.*encoder_oracle", src):
                         offenders.append(os.path.join(dp, fn))
     assert not offenders, offenders
+
+
+def test_map_pass_heuristics_stay_inside_the_kernels_limits():
+    """retrieval.map_seg_rows / record_cap (host arithmetic only): segments of 256 .. 65,535 rows (16-bit counters) that cover the
+    gallery, whole rounds of the LDS-limited workgroup slots where the sizes allow it, and record lists inside their budgets."""
+    from concepthash_amd import _lib, retrieval as rt
+    lib = _lib.load()
+    for Qn, G, W in [(1, 1, 1), (5794, 5994, 1), (24633, 23929, 1), (16384, 1_000_000, 2), (333, 4567, 1), (100, 300, 4),
+                     (50000, 50000, 2), (10, 70000, 2), (5, 10_000_000, 2), (25250, 75750, 1), (1500, 9000, 3), (7, 70_000_000, 4)]:
+        seg = rt.map_seg_rows(Qn, G, W)
+        assert 256 <= seg <= 65535 or seg >= G, (Qn, G, W, seg)
+        nseg = -(-G // seg)
+        assert nseg <= 65535 and nseg * seg >= G
+        blk = int(lib.ch_hamming_rec_block(W))
+        assert blk == (256 if W <= 2 else 128)
+        wgs = int(lib.ch_hamming_rec_workgroups(Qn, G, W, seg))
+        assert wgs == (-(-Qn // blk)) * nseg
+        cap = rt.record_cap(Qn, G, W, seg)
+        assert 1 <= cap <= seg
+        assert cap >= min(seg, seg // 64 + 32) or wgs * blk * 8 * (cap + 1) > rt.REC_BUDGET_BYTES
+        assert wgs * blk * 8 * cap <= rt.REC_BUDGET_BYTES
+    # whole rounds: NABirds size at 64 bit -> one round of the 512 slots; the 1M x 128-bit problem -> exactly four of 256
+    assert -(-24633 // 256) * -(-23929 // rt.map_seg_rows(24633, 23929, 1)) <= 512
+    assert -(-16384 // 256) * -(-1_000_000 // rt.map_seg_rows(16384, 1_000_000, 2)) == 1024
