@@ -98,3 +98,20 @@ def test_map_pass_heuristics_stay_inside_the_kernels_limits():
     # whole rounds: NABirds size at 64 bit -> one round of the 512 slots; the 1M x 128-bit problem -> exactly four of 256
     assert -(-24633 // 256) * -(-23929 // rt.map_seg_rows(24633, 23929, 1)) <= 512
     assert -(-16384 // 256) * -(-1_000_000 // rt.map_seg_rows(16384, 1_000_000, 2)) == 1024
+
+
+def test_hand_placed_dpp_instructions_have_no_read_after_valu_write_hazard():
+    """csrc/hamming.hip broadcasts gallery rows through DPP operands inside inline asm, where the compiler cannot insert the two
+    wait states gfx9 needs between a VALU write of a VGPR and a DPP read of it.  tools/check_dpp_hazards.py disassembles the built
+    object and checks every DPP instruction (a guard against a future compiler moving a copy in front of one)."""
+    import importlib.util
+    obj = os.path.join(ROOT, "concepthash_amd", "csrc", "build", "hamming.o")
+    if not os.path.exists(obj):
+        from concepthash_amd import build
+        build.build(verbose=False)
+    spec = importlib.util.spec_from_file_location("check_dpp_hazards", os.path.join(ROOT, "tools", "check_dpp_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    total, bad = mod.check(obj)
+    assert total > 1000, "the DPP form of the scans was not built"
+    assert not bad, bad[:5]
