@@ -129,7 +129,8 @@ class ShardedRetrieval:
         nseg = max(1, -(-gmax // seg))
         # one-scan form where the ops provide it (concepthash_amd.retrieval does): the histogram pass also records this shard's
         # relevant rows, and the AP terms come from the records once the GLOBAL bases exist (CH_HAMMING_RECORDS=0 = two scans)
-        use_rec = hasattr(ops, "hamming_hist_rec") and os.environ.get("CH_HAMMING_RECORDS", "1") != "0"
+        use_rec = (hasattr(ops, "hamming_hist_rec") and os.environ.get("CH_HAMMING_RECORDS", "1") != "0"
+                   and ops.records_fit(Qn, max(gmax, 1), W, seg))
         if use_rec:
             hist, recs = ops.hamming_hist_rec(q_all, self.gallery, q_lab, g_lab, LW, seg)
         else:

@@ -248,6 +248,12 @@ def record_cap(Qn: int, G: int, W: int, seg_rows: int) -> int:
     return int(max(1, min(cap, seg_rows, REC_BUDGET_BYTES // unit)))
 
 
+def records_fit(Qn: int, G: int, W: int, seg_rows: int) -> bool:
+    """False where REC_BUDGET_BYTES cannot even hold the minimum list length (very large Qn x G): the lists would overflow nearly
+    everywhere and the recording scan would be paid on top of the two-scan form -- evaluate() then runs the two-scan form."""
+    return record_cap(Qn, G, W, seg_rows) >= min(seg_rows, seg_rows // 64 + 32)
+
+
 def hamming_hist_rec(q, g, q_lab, g_lab, LW: int, seg_rows: int, rec_cap: Optional[int] = None, stream=None):
     """mAP pass 1 of the one-scan form: the histogram of hamming_hist plus the per-lane record lists of the relevant rows
     -> (hist, records) where records = (rec, rec_cap, rec_cnt, wg_flags) is what hamming_ap_rec takes."""
@@ -361,7 +367,7 @@ def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels:
         first_rel = _relevance_of(idx, q_lab, g_lab, LW)[:, 0].to(torch.int32)
     limits, idx_of = normalize_limits(Rs + ks)
     if records is None:
-        records = os.environ.get("CH_HAMMING_RECORDS", "1") != "0"
+        records = os.environ.get("CH_HAMMING_RECORDS", "1") != "0" and (rec_cap is not None or records_fit(Qn, G, W, seg))
     if records:   # one distance scan: histogram + records of the relevant rows, prefix, then the AP terms from the records
         hist, recs = hamming_hist_rec(q, g, q_lab, g_lab, LW, seg, rec_cap=rec_cap)
         base, totals = hist_prefix(hist)

@@ -95,6 +95,9 @@ def test_map_pass_heuristics_stay_inside_the_kernels_limits():
         assert 1 <= cap <= seg
         assert cap >= min(seg, seg // 64 + 32) or wgs * blk * 8 * (cap + 1) > rt.REC_BUDGET_BYTES
         assert wgs * blk * 8 * cap <= rt.REC_BUDGET_BYTES
+        assert rt.records_fit(Qn, G, W, seg) == (cap >= min(seg, seg // 64 + 32))
+    assert rt.records_fit(16384, 1_000_000, 2, rt.map_seg_rows(16384, 1_000_000, 2))
+    assert not rt.records_fit(200_000, 20_000_000, 2, rt.map_seg_rows(200_000, 20_000_000, 2))   # 4 GiB cannot hold the minimum lists
     # whole rounds: NABirds size at 64 bit -> one round of the 512 slots; the 1M x 128-bit problem -> exactly four of 256
     assert -(-24633 // 256) * -(-23929 // rt.map_seg_rows(24633, 23929, 1)) <= 512
     assert -(-16384 // 256) * -(-1_000_000 // rt.map_seg_rows(16384, 1_000_000, 2)) == 1024
