@@ -60,7 +60,15 @@ def parse_args():
     ap.add_argument("--no-hamming-scan", action="store_true")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step block (SURVEY.md section 8 row f4)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the single-stream profiled pass")
-    return ap.parse_args()
+    ap.add_argument("--no-evaluator", action="store_true", help="skip the evaluator-inclusive block (COOPTrainer.inference_one_epoch)")
+    ap.add_argument("--encode-only", action="store_true",
+                    help="nothing but the timed encode + retrieve steps (and the roofline pass unless --no-roofline-pass): no "
+                         "pcie / decode / evaluator / training / Hamming-scan / CPU-baseline blocks -- what the rocprofv3 passes of "
+                         "tools/profile_round.sh trace, so that every kernel row of a summary is the encoder's")
+    a = ap.parse_args()
+    if a.encode_only:
+        a.no_cpu_baseline = a.no_hamming_scan = a.no_train_step = a.no_evaluator = True
+    return a
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -230,11 +238,11 @@ def main():
             result.update(roofline_block(prof, args, enc, B, prof_ms_per_step, codes_same))
 
     # ---- PCIe-inclusive variant (outside the timed region): the same step fed from pinned host memory each time -----
-    if rank == 0:
+    if rank == 0 and not args.encode_only:
         result["pcie_inclusive"] = pcie_block(torch, enc, images, B)
 
     # ---- decode-inclusive variant (outside the timed region): decoded uint8 bytes -> GPU pre-processing -> encode ------------
-    if rank == 0:
+    if rank == 0 and not args.encode_only:
         result["decode_inclusive"] = decode_block(torch, enc, B, dev)
 
     # ---- training step of the adapters (outside the timed region) -------------------------------
@@ -272,42 +280,62 @@ def roofline_block(prof, args, enc, B, prof_ms_per_step, codes_same):
             traffic_tab = json.load(open(tpath)).get("per_kernel", {})
         except Exception:
             traffic_tab = {}
-    # kernel instances as rocprofv3 names them (default chain, LayerNorm folded): (label, rocprof name, launch categories)
+    # kernel instances as rocprofv3 names them (default chain, LayerNorm folded).  ONE problem shape per row: out_proj and fc2 run
+    # the same code under two symbol names (gemm_pp.hip, TAG), and the final layer's launches on the compact head rows have
+    # categories of their own ("*_pruned", not listed: < 1 % of the step).  grid = work-items, as the rocprofv3 CSVs print it.
     rows_tok = B * enc.ntok
-    D_, b_pad = enc.cfg["dim"], (enc.cfg["adapter_dim"] + 127) // 128 * 128
-    up_bytes = rows_tok * (D_ * 4 * 2 + D_ * 2 * 2 + b_pad * 2) + D_ * b_pad * 2      # fp32 RMW + bf16 addend + bf16 copy + X, W
-    down_bytes = rows_tok * (D_ * 2 + b_pad * 2) + D_ * b_pad * 2
-    instances = [
-        ("gemm_pp_kernel<EPI_BIAS_STATS> (out_proj + fc2, 256x256 ping-pong)", "gemm_pp_kernel<6, 0, 0>", ["gemm_out", "gemm_fc2"], None),
-        ("gemm_pp_kernel<EPI_FOLD_QUICKGELU> (fc1)", "gemm_pp_kernel<9, 0, 0>", ["gemm_fc1"], None),
-        ("gemm_pp_kernel<EPI_FOLD_BIAS> (qkv)", "gemm_pp_kernel<8, 0, 0>", ["gemm_qkv"], None),
-        ("gemm_bf16_kernel<EPI_SCALE_RESID_STATS> (adapter up, 128x128)", "gemm_bf16_kernel<7>", ["gemm_up"], up_bytes),
-        ("gemm_bf16_kernel<EPI_FOLD_GELU> (adapter down, 128x128)", "gemm_bf16_kernel<10>", ["gemm_down"], down_bytes),
+    D_, F_, b_pad = enc.cfg["dim"], enc.cfg["ffn"], (enc.cfg["adapter_dim"] + 127) // 128 * 128
+    st = rows_tok * (D_ // 64) * 8                       # one (sum, sumsq) pair per 64-column slice of a D-wide row
+
+    def gemm_bytes(N, K, out_bytes):                     # X + W + what the epilogue reads / writes
+        return rows_tok * K * 2 + N * K * 2 + out_bytes
+
+    pp_grid = lambda N: -(-rows_tok // 256) * (N // 256) * 512
+    v1_grid = lambda N: -(-rows_tok // 128) * (N // 128) * 256
+    instances = [  # (label, rocprof name, category, grid, algorithmic bytes per launch, bound)
+        ("gemm_pp_kernel<EPI_BIAS_STATS> out_proj (K = D, 256x256 ping-pong)", "gemm_pp_kernel<6, 0, 0, 0>", "gemm_out",
+         pp_grid(D_), gemm_bytes(D_, D_, rows_tok * D_ * 2 + st), "mfma"),
+        ("gemm_pp_kernel<EPI_BIAS_STATS, TAG 1> fc2 (K = 4 D)", "gemm_pp_kernel<6, 0, 0, 1>", "gemm_fc2",
+         pp_grid(D_), gemm_bytes(D_, F_, rows_tok * D_ * 2 + st), "mfma"),
+        ("gemm_pp_kernel<EPI_FOLD_QUICKGELU> fc1", f"gemm_pp_kernel<{9 if enc.cfg['act'] == 0 else 10}, 0, 0, 0>", "gemm_fc1",
+         pp_grid(F_), gemm_bytes(F_, D_, rows_tok * F_ * 2 + st), "mfma"),
+        ("gemm_pp_kernel<EPI_FOLD_BIAS> qkv (layers >= 1; layer 0 runs <EPI_BIAS>)", "gemm_pp_kernel<8, 0, 0, 0>", "gemm_qkv",
+         pp_grid(3 * D_), gemm_bytes(3 * D_, D_, rows_tok * 3 * D_ * 2 + st), "mfma"),
+        ("gemm_bf16_kernel<EPI_SCALE_RESID_STATS> adapter up (128x128)", "gemm_bf16_kernel<7>", "gemm_up",
+         v1_grid(D_), gemm_bytes(D_, b_pad, rows_tok * D_ * (4 * 2 + 2 + 2) + st), "hbm"),   # fp32 RMW + bf16 addend + bf16 copy
+        ("gemm_bf16_kernel<EPI_FOLD_GELU> adapter down (128x128)", "gemm_bf16_kernel<10>", "gemm_down",
+         v1_grid(b_pad), gemm_bytes(b_pad, D_, rows_tok * b_pad * 2 + st), "hbm"),
     ]
     per_kernel = []
-    for label, rname, cats, hbm_bytes in instances:
-        ms = sum(prof[c]["ms"] for c in cats if c in prof)
-        n = sum(prof[c]["launches"] for c in cats if c in prof)
-        fl = sum(prof[c]["flops"] for c in cats if c in prof)
-        if n == 0 or ms <= 0:
+    for label, rname, cat, grid, alg_bytes, bound in instances:
+        if cat not in prof or prof[cat]["launches"] == 0 or prof[cat]["ms"] <= 0:
             continue
+        ms, n, fl = prof[cat]["ms"], prof[cat]["launches"], prof[cat]["flops"]
         tf = fl / (ms * 1e-3) / 1e12
-        row = {"kernel": label, "rocprof_name": rname, "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS,
+        # HBM-side bytes of this (kernel, grid) from the PMC passes (tools/make_traffic_json.py); a figure below the algorithmic
+        # bytes of the launch cannot be one shape's counter and is refused (a mixed-shape average did that in round 2)
+        traffic = traffic_tab.get(f"{rname}@{grid}", {}).get("hbm_bytes_per_launch")
+        traffic_note = None
+        if traffic is not None and traffic < 0.98 * alg_bytes:
+            traffic_note, traffic = f"refused: counter bytes {traffic} < algorithmic bytes {int(alg_bytes)}", None
+        row = {"kernel": label, "rocprof_name": rname, "grid": grid, "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS,
                "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3 / n, 2),
                "launches_per_step": n // max(1, args.steps), "ms_per_step": round(ms / args.steps, 3),
-               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
-               "traffic": traffic_tab.get(rname, {}).get("hbm_bytes_per_launch")}
-        if hbm_bytes is not None:   # short-K adapter GEMMs: priced against HBM (algorithmic bytes per launch / duration)
-            gbs = hbm_bytes / (ms * 1e-3 / n) / 1e9
+               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2), "algorithmic_bytes_per_launch": int(alg_bytes),
+               "traffic": traffic}
+        if traffic_note:
+            row["traffic_note"] = traffic_note
+        if bound == "hbm":   # short-K adapter GEMMs: priced against HBM (algorithmic bytes per launch / duration)
+            gbs = alg_bytes / (ms * 1e-3 / n) / 1e9
             row.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(hbm_bytes),
-                        "tflops": round(tf, 2)})
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "tflops": round(tf, 2)})
         per_kernel.append(row)
     dominant = max(per_kernel, key=lambda r: r["ms_per_step"]) if per_kernel else None
     return {
         # dominant kernel = the instance with the most time per step (first row of profiles/*_kernel_stats.csv)
-        "roofline": ({k: dominant[k] for k in ("bound", "kernel", "rocprof_name", "achieved", "peak", "unit", "frac", "traffic",
-                                               "avg_launch_us", "launches_per_step", "algorithmic_gflop_per_launch")}
+        "roofline": ({k: dominant[k] for k in ("bound", "kernel", "rocprof_name", "grid", "achieved", "peak", "unit", "frac", "traffic",
+                                               "avg_launch_us", "launches_per_step", "algorithmic_gflop_per_launch",
+                                               "algorithmic_bytes_per_launch")}
                      if dominant else None),
         "roofline_pass": {"hip_streams": 1, "ms_per_step": round(prof_ms_per_step, 3),
                           "images_per_s": round(B / (prof_ms_per_step * 1e-3), 1), "codes_identical_to_timed_region": codes_same,

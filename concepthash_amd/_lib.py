@@ -1,4 +1,5 @@
-"""ctypes binding of libconcepthash_hip.so (the C-ABI declared in include/concepthash_hip.h).
+"""ctypes binding of libconcepthash_hip.so (the C-ABI declared in include/concepthash_hip.h; test / bench taps in
+include/concepthash_hip_debug.h).
 
 The product path has NO fallback: if the library is missing, or an entry point is absent, importing callers get a
 loud ``RuntimeError`` -- never a silent PyTorch/CPU path.
@@ -92,8 +93,10 @@ SIGNATURES = {
     "ch_hamming_hist_prefix": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
 }
 
+# launch-profiler categories, in the order of the CH_CAT_* enum; "*_pruned" = the final layer's launches on the compact head rows
 CATEGORIES = ("im2col", "gemm_patch", "rowops", "gemm_qkv", "attention", "gemm_out", "gemm_down", "gemm_up", "gemm_fc1",
-              "gemm_fc2", "head", "adapter_fused", "end")
+              "gemm_fc2", "head", "adapter_fused", "attention_pruned", "gemm_out_pruned", "gemm_down_pruned", "gemm_up_pruned",
+              "gemm_fc1_pruned", "gemm_fc2_pruned", "end")
 
 _lib = None
 

@@ -554,20 +554,19 @@ __global__ __launch_bounds__(BLK) void map_scan_kernel(const uint64_t *__restric
         const std::integral_constant<int, 2> y2{};
         const std::integral_constant<int, 3> y3{};
         const int nring = n / (RB * NBUF);   // rounds of the four-block ring
-        if (nring > 0) {
+        if (nring > 0) {   // ONE region: every path that issues ring loads also runs the last round's waits (tools/check_dpp_hazards.py
+                           // follows the control-flow graph and would otherwise see an infeasible "loop, then skip the drain" path)
             issue(b0);
             issue(b1);
             issue(b2);
             issue(b3);
-        }
-        for (int it = 0; it + 1 < nring; ++it) {   // steady state: the three blocks issued after a slot's are still in flight
-            landed(b0, y3); scan_vblk(b0); issue(b0);
-            landed(b1, y3); scan_vblk(b1); issue(b1);
-            landed(b2, y3); scan_vblk(b2); issue(b2);
-            landed(b3, y3); scan_vblk(b3); issue(b3);
-        }
-        if (nring > 0) {                           // last round: nothing left to issue
-            landed(b0, y3); scan_vblk(b0);
+            for (int it = 0; it + 1 < nring; ++it) {   // steady state: the three blocks issued after a slot's are still in flight
+                landed(b0, y3); scan_vblk(b0); issue(b0);
+                landed(b1, y3); scan_vblk(b1); issue(b1);
+                landed(b2, y3); scan_vblk(b2); issue(b2);
+                landed(b3, y3); scan_vblk(b3); issue(b3);
+            }
+            landed(b0, y3); scan_vblk(b0);             // last round: nothing left to issue
             landed(b1, y2); scan_vblk(b1);
             landed(b2, y1); scan_vblk(b2);
             landed(b3, y0); scan_vblk(b3);

@@ -61,6 +61,7 @@ struct GemmParams {
     int rev;                 // 1: walk the m-tiles from the last row tile to the first (serpentine launch order)
     int pp_sched;            // 256x256 kernel: 0 = four phases of 16 MFMAs per K-tile, 1 = two phases of 32 (gemm_pp.hip)
     int pp_min_k;            // dispatcher: smallest K that goes to the 256x256 ping-pong kernel (0 = default 512)
+    int tag;                 // profiling only: 1 = launch the 256x256 kernel under its second symbol name (gemm_pp.hip, TAG)
     int small_kernel;        // dispatcher, GEMMs that do not go to the 256x256 kernel: 0 = default, 1 = 128x128x64 two-phase, 2 = 128x128x32 ring (experiments build)
 };
 constexpr size_t CH_SPLITK_WS_BYTES = (size_t)256 * 256 * 256 * 4;  // 64 MiB: at most 256 tail units of one 256x256 fp32 slab

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/concepthash_hip.h"
+#include "../../include/concepthash_hip_debug.h"
 #include "ch_common.h"
 #include "kernels.h"
 
@@ -409,10 +410,21 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
     auto next_dir = [&]() { return mm->serpentine ? (dir ^= 1) : 0; };
     int cur_rows = rows;      // rows the GEMMs work on: all token rows, or the compact head rows in the pruned final layer
     float *cur_H = m->H;      // ... and their residual stream
+    auto pruned_cat = [](int cat) {   // profiler category of the same launch on the compact head rows (final layer)
+        switch (cat) {
+            case CH_CAT_GEMM_OUT: return (int)CH_CAT_GEMM_OUT_PRUNED;
+            case CH_CAT_GEMM_DOWN: return (int)CH_CAT_GEMM_DOWN_PRUNED;
+            case CH_CAT_GEMM_UP: return (int)CH_CAT_GEMM_UP_PRUNED;
+            case CH_CAT_GEMM_FC1: return (int)CH_CAT_GEMM_FC1_PRUNED;
+            case CH_CAT_GEMM_FC2: return (int)CH_CAT_GEMM_FC2_PRUNED;
+        }
+        return cat;
+    };
     auto gemm = [&](int cat, int n_true, int k_true, const bf16_t *X, const bf16_t *W, int N, int K, const float *bias,
                     int epi, bf16_t *out, int ldo, const float *scale, const bf16_t *addend = nullptr, const Fold &f = Fold()) {
-        mark(mm, pi, cat, 2.0 * cur_rows * (double)n_true * k_true, s);
+        mark(mm, pi, cur_rows != rows ? pruned_cat(cat) : cat, 2.0 * cur_rows * (double)n_true * k_true, s);
         GemmParams p{};
+        p.tag = cat == CH_CAT_GEMM_FC2 ? 1 : 0;   // fc2 runs out_proj's kernel instance: second symbol name for per-kernel profiles
         p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi]; p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.small_kernel = mm->small_kernel; p.rev = next_dir();
         p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
@@ -474,7 +486,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         }
         const bool pruned = prune && fold && mm->prune_last && i == nlayers - 1 && nlayers == c.layers;
         const int nq = 1 + c.ncontext;
-        mark(mm, pi, CH_CAT_ATTENTION, 4.0 * B * (double)(pruned ? nq : ntok) * ntok * D, s);
+        mark(mm, pi, pruned ? CH_CAT_ATTENTION_PRUNED : CH_CAT_ATTENTION, 4.0 * B * (double)(pruned ? nq : ntok) * ntok * D, s);
         if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, i == nlayers - 1 ? concept_attn : nullptr, c.ncontext, pruned,
                                  next_dir() != 0))
             return e;

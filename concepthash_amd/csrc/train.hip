@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "model_internal.h"
+#include "../../include/concepthash_hip_debug.h"
 
 namespace {
 struct AdWork {

@@ -137,14 +137,25 @@ class TrainEngine:
         self.generation += 1
         return (hf, cls, attn) if want_attn else (hf, cls)
 
+    def grads_live(self) -> bool:
+        """True when the adapters' `.grad`s still are the arena views of an earlier backward, i.e. no `zero_grad()` (set_to_none,
+        the default) ran since: the next backward must ADD to them, as autograd does for every other parameter."""
+        return any(p.grad is not None and p.grad.data_ptr() == gview.data_ptr() for p, gview in self._views[:1])
+
     def backward(self, d_hash_features: torch.Tensor, d_concept_attn: torch.Tensor = None) -> torch.Tensor:
+        """`ch_train_backward` OVERWRITES the gradient arena.  Gradient accumulation (two backward calls without a zero_grad in
+        between: micro-batches, several losses) therefore keeps the earlier arena aside and adds it back -- the adapters then
+        accumulate exactly as the head's parameters do under autograd (one extra copy + add of the arena per accumulated call)."""
         c = self.cfg
         g = d_hash_features.detach().to(self.device, torch.float32).contiguous()
         ga = d_concept_attn.detach().to(self.device, torch.float32).contiguous() if d_concept_attn is not None else None
         dct = torch.empty(c["ncontext"], c["dim"], dtype=torch.float32, device=self.device)
+        earlier = self.grads.clone() if self.grads_live() else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ch_train_backward(self._t, _lib.ptr(g), _lib.ptr(ga), _lib.ptr(dct), _lib.stream_ptr()),
                        "ch_train_backward")
+        if earlier is not None:
+            self.grads.add_(earlier)
         for p, gview in self._views:      # optimizer.zero_grad(set_to_none=True) drops the views: put them back
             p.grad = gview
         return dct

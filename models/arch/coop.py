@@ -158,6 +158,8 @@ class LGHWithoutText(nn.Module):
     def _drop_train_engine(self):
         eng = getattr(self, "_train_engine", None)
         if eng is not None:
+            if eng.momentum_buf is not None:      # the fused arena step's momentum outlives the engine (rebuilds: a larger batch,
+                self._carried_momentum = eng.momentum_buf   # .to(), load_state_dict), as torch's optimizer state does
             eng.close()
         self._train_engine = None
 
@@ -190,12 +192,16 @@ class LGHWithoutText(nn.Module):
         key = (str(device), image_size)
         eng = getattr(self, "_train_engine", None)
         if eng is not None and (self._train_engine_key != key or eng.max_batch < batch):
-            eng.close()
+            self._drop_train_engine()
             eng = None
         if eng is None:
             eng = TrainEngine(self._projected_state_dict(), adapter_modules(self.backbone.vision_model), heads=self._heads,
                               upt_heads=self._upt_heads, act=self._act, max_batch=max(batch, getattr(self, "train_max_batch", 0)),
                               device=device, image_size=image_size)
+            carried = getattr(self, "_carried_momentum", None)
+            if carried is not None and carried.numel() == eng.params.numel():
+                eng.momentum_buf = carried.to(eng.device)
+            self._carried_momentum = None
             self._train_engine, self._train_engine_key = eng, key
         return eng
 

@@ -16,10 +16,20 @@ def lib():
     return _lib.load()
 
 
-def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "concepthash_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ch_[a-z0-9_]+)\s*\(", text)))
+def _declared_functions(headers=("concepthash_hip.h", "concepthash_hip_debug.h")):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(ch_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_debug_taps_live_in_their_own_header():
+    """The drop-in boundary (concepthash_hip.h) declares no ch_debug_* tap; they are all in concepthash_hip_debug.h."""
+    assert not [n for n in _declared_functions(("concepthash_hip.h",)) if n.startswith("ch_debug_")]
+    dbg = _declared_functions(("concepthash_hip_debug.h",))
+    assert len(dbg) >= 10 and all(n.startswith("ch_debug_") for n in dbg)
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
@@ -103,18 +113,75 @@ def test_map_pass_heuristics_stay_inside_the_kernels_limits():
     assert -(-16384 // 256) * -(-1_000_000 // rt.map_seg_rows(16384, 1_000_000, 2)) == 1024
 
 
-def test_hand_placed_dpp_instructions_have_no_read_after_valu_write_hazard():
-    """csrc/hamming.hip broadcasts gallery rows through DPP operands inside inline asm, where the compiler cannot insert the two
-    wait states gfx9 needs between a VALU write of a VGPR and a DPP read of it.  tools/check_dpp_hazards.py disassembles the built
-    object and checks every DPP instruction (a guard against a future compiler moving a copy in front of one)."""
+def _hazard_tool():
     import importlib.util
+    spec = importlib.util.spec_from_file_location("check_dpp_hazards", os.path.join(ROOT, "tools", "check_dpp_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_hand_placed_instructions_of_the_map_scans_pass_the_static_checks():
+    """csrc/hamming.hip broadcasts gallery rows through DPP operands inside inline asm and keeps an inline-asm VMEM ring behind
+    counted `s_waitcnt vmcnt(N)` -- neither is visible to the compiler's hazard recogniser / wait insertion.  tools/check_dpp_hazards.py
+    disassembles the built object and checks, over the control-flow graph of every kernel: the VALU-write -> DPP-read distance
+    (2 wait states) and the EXEC-write -> DPP distance (5), that no instruction touches the destination of an outstanding
+    vector-memory load before the vmcnt wait that covers it, and that the map scans have no scratch (spill) traffic."""
     obj = os.path.join(ROOT, "concepthash_amd", "csrc", "build", "hamming.o")
     if not os.path.exists(obj):
         from concepthash_amd import build
         build.build(verbose=False)
-    spec = importlib.util.spec_from_file_location("check_dpp_hazards", os.path.join(ROOT, "tools", "check_dpp_hazards.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    total, bad = mod.check(obj)
-    assert total > 1000, "the DPP form of the scans was not built"
-    assert not bad, bad[:5]
+    r = _hazard_tool().check_all(obj)
+    assert r["dpp_total"] > 1000, "the DPP form of the scans was not built"
+    assert not r["dpp_bad"], r["dpp_bad"][:5]
+    assert r["vmem_loads"] > 500 and not r["vmem_bad"], r["vmem_bad"][:5]
+    assert not r["scratch_bad"], r["scratch_bad"][:5]
+
+
+def test_the_static_checker_catches_what_it_claims_to():
+    """Synthetic listings: a use of a ring register before its wait (also across a loop back-edge), a VALU write two slots in front
+    of a DPP read reached only through a branch, and a v_cmpx in front of a DPP instruction -- each must be reported; the corrected
+    listings must be clean."""
+    mod = _hazard_tool()
+
+    def kern(lines):
+        rows, addr = [], 0x1000
+        labels = {}
+        for ln in lines:                      # "L1:" defines a label, "... @L1" is a branch target
+            if ln.endswith(":"):
+                labels[ln[:-1]] = addr
+                continue
+            addr += 4
+        addr = 0x1000
+        for ln in lines:
+            if ln.endswith(":"):
+                continue
+            cmt = f" {addr:012X}: 00000000"
+            if "@" in ln:
+                ln, lab = ln.split("@")
+                cmt += f" <k+0x{labels[lab] - 0x1000:x}>"
+            rows.append((addr, ln.strip(), cmt))
+            addr += 4
+        return mod.Kernel("k", rows)
+
+    # ring register v4 consumed under vmcnt(1) although ONE younger load is allowed to be outstanding -> it is not covered
+    bad = kern(["global_load_dword v4, v[0:1], off", "global_load_dword v5, v[2:3], off", "s_waitcnt vmcnt(2)", "v_add_u32_e32 v6, v4, v4",
+                "s_endpgm"])
+    assert len(bad.check_vmem_order()[1]) == 1
+    ok = kern(["global_load_dword v4, v[0:1], off", "global_load_dword v5, v[2:3], off", "s_waitcnt vmcnt(1)", "v_add_u32_e32 v6, v4, v4",
+               "s_waitcnt vmcnt(0)", "v_add_u32_e32 v6, v5, v5", "s_endpgm"])
+    assert not ok.check_vmem_order()[1]
+    # loop: the load at the bottom is consumed at the top of the next iteration without a wait on the back-edge path
+    loop = kern(["global_load_dword v4, v[0:1], off", "s_waitcnt vmcnt(0)", "L:", "v_add_u32_e32 v6, v4, v4",
+                 "global_load_dword v4, v[0:1], off", "s_cbranch_scc1 0@L", "s_waitcnt vmcnt(0)", "s_endpgm"])
+    # (the re-issue into the still-pending v4 is reported too: a write under an outstanding load)
+    assert [x[2] for x in loop.check_vmem_order()[1]] == ["v_add_u32_e32 v6, v4, v4", "global_load_dword v4, v[0:1], off"]
+    # DPP: the writer sits in front of a branch INTO the DPP instruction (listing order shows harmless instructions before it)
+    dpp = kern(["v_mov_b32_e32 v7, v1", "s_branch 0@T", "s_nop 4", "s_nop 4", "T:", "v_xor_b32_dpp v2, v7, v3 row_newbcast:1 row_mask:0xf bank_mask:0xf",
+                "s_endpgm"])
+    assert [b[0] for b in dpp.check_dpp()[1]] == ["valu->dpp"]
+    fixed = kern(["v_mov_b32_e32 v7, v1", "s_nop 1", "s_branch 0@T", "T:", "v_xor_b32_dpp v2, v7, v3 row_newbcast:1 row_mask:0xf bank_mask:0xf",
+                  "s_endpgm"])
+    assert not fixed.check_dpp()[1]
+    cx = kern(["v_cmpx_eq_u32_e32 v1, v2", "s_nop 1", "v_xor_b32_dpp v2, v7, v3 row_newbcast:1 row_mask:0xf bank_mask:0xf", "s_endpgm"])
+    assert [b[0] for b in cx.check_dpp()[1]] == ["exec->dpp"]

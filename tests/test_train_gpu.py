@@ -54,11 +54,22 @@ def _role(k):
     return k.split(".adapt_mlp_")[1][2:] if ".adapt_mlp_" in k else k
 
 
-def _check_grads(got, want, floor_keys=("hash_pe",), strict=()):
-    """Per tensor: relative L2 error < 4e-2 and cosine > 0.999 -- or, for a tensor whose own gradient is small next to its
-    siblings' (same parameter role in another adapter: a sum over rows that mostly cancels), an ABSOLUTE error below 3e-2 of the
-    largest sibling gradient norm: bf16 operands put a noise floor of ~1e-2 of the typical gradient under every tensor, which is
-    what an optimizer sees; `strict` names tensors that must pass the relative test."""
+# Tensors that MAY take the sibling-scaled absolute bound below (everything else must pass the relative test): parameters whose own
+# gradient is a cancelled sum in these fixtures, so that bf16 operand noise (~1e-2 of a typical sibling gradient) is comparable to the
+# gradient itself.  Listed from a run with CH_TEST_LIST_ESCAPES=1, which prints every tensor that fails the relative test.
+SMALL_GRADIENT_TENSORS = (
+    ".adapt_mlp_2.",                     # second adapter of a layer: its true gradient is ~1/27 of the first adapter's
+    ".adapt_mlp_1.scale", ".adapt_mlp_1.up_proj.bias", ".adapt_mlp_1.adapter_layer_norm.bias",   # scalar / bias sums over all rows
+)
+
+
+def _check_grads(got, want, floor_keys=("hash_pe",), strict=(), escape=SMALL_GRADIENT_TENSORS):
+    """Per tensor: relative L2 error < 4e-2 and cosine > 0.999.  Only a tensor named in `escape` (default: SMALL_GRADIENT_TENSORS) may
+    instead pass on an ABSOLUTE error below 3e-2 of the largest sibling gradient norm (same parameter role in another adapter): bf16
+    operands put a noise floor of ~1e-2 of the typical gradient under every tensor, which is what an optimizer sees; `strict` names
+    tensors that must pass the relative test even if listed."""
+    import os
+    listing = os.environ.get("CH_TEST_LIST_ESCAPES") == "1"
     scale = {}
     for k, ref in want.items():
         scale[_role(k)] = max(scale.get(_role(k), 0.0), float(torch.as_tensor(ref).double().norm()))
@@ -76,6 +87,11 @@ def _check_grads(got, want, floor_keys=("hash_pe",), strict=()):
         if rel < 4e-2 and cos > 0.999:
             worst = max(worst, (rel, k))
             continue
+        if listing:
+            print("ESCAPE %s rel %.3e cos %.5f abs/sibling %.3e own/sibling %.3e" % (k, rel, cos, err / scale[_role(k)],
+                                                                                     float(r.norm()) / scale[_role(k)]))
+        else:
+            assert any(t in k for t in escape), ("not in the small-gradient list: must pass the relative test", k, rel, cos)
         assert not any(t in k for t in strict), (k, rel, cos)
         assert err < 3e-2 * scale[_role(k)], (k, rel, cos, err, scale[_role(k)])
         worst_abs = max(worst_abs, (err / scale[_role(k)], k))
@@ -281,6 +297,68 @@ def test_a_smaller_batch_after_a_larger_one_sees_no_stale_rows(chains, monkeypat
     fresh.train_max_batch = 6
     g_fresh = grads_of(fresh, 4)
     assert torch.equal(g_used, g_fresh)
+
+
+def test_gradient_accumulation_over_micro_batches_adds_up():
+    """Two backward calls without a zero_grad in between (micro-batches): `ch_train_backward` overwrites its gradient arena, so the
+    engine adds the earlier arena back -- the adapters accumulate as the head's parameters do under autograd.  Checked against the
+    two micro-batch gradients taken separately (fp32 add: exact to rounding), and zero_grad() really restarts the sum."""
+    sd, z = load_fixture("train_tiny")
+    model = _train_model(sd, z)
+    model.train_max_batch = 6
+    crit = _crit()
+    x = fixture_images(z).cuda()
+    labels = torch.from_numpy(z["in/labels"]).cuda()
+    head = model.hash_fc.weight
+
+    def one(lo, hi):
+        model.zero_grad()
+        crit(model(x[lo:hi])[1], labels[lo:hi]).backward()
+        torch.cuda.synchronize()
+        return model._train_engine.grads.clone(), head.grad.clone()
+
+    ga, ha = one(0, 3)
+    gb, hb = one(3, 6)
+    model.zero_grad()
+    crit(model(x[0:3])[1], labels[0:3]).backward()
+    assert model._train_engine.grads_live()
+    crit(model(x[3:6])[1], labels[3:6]).backward()          # no zero_grad in between
+    torch.cuda.synchronize()
+    assert torch.equal(model._train_engine.grads, ga + gb)
+    assert torch.allclose(head.grad, ha + hb, rtol=1e-6, atol=1e-8)
+    p0 = model.backbone.vision_model.encoder.layers[0].adapt_mlp_1.down_proj.weight
+    assert p0.grad.data_ptr() == model._train_engine._views[2][1].data_ptr()
+    model.zero_grad()
+    assert not model._train_engine.grads_live()
+    crit(model(x[3:6])[1], labels[3:6]).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(model._train_engine.grads, gb)
+
+
+def test_momentum_survives_an_engine_rebuild():
+    """The fused arena step keeps the adapters' momentum in the engine; a rebuild of the engine (here: a batch larger than its
+    max_batch) must carry it over, as torch's optimizer state survives for every other parameter."""
+    from concepthash_amd.training import fuse_adapter_sgd
+    sd, z = load_fixture("train_tiny")
+    model = _train_model(sd, z)
+    crit = _crit()
+    x = fixture_images(z).cuda()
+    labels = torch.from_numpy(z["in/labels"]).cuda()
+    groups = [{"params": list(model.get_adapter().parameters())}, {"params": list(model.get_training_modules().parameters())}]
+    opt = fuse_adapter_sgd(torch.optim.SGD(groups, lr=0.05, momentum=0.9), model)
+    opt.zero_grad()
+    crit(model(x[:3])[1], labels[:3]).backward()
+    opt.step()
+    torch.cuda.synchronize()
+    mom = model._train_engine.momentum_buf.clone()
+    assert float(mom.abs().max()) > 0
+    first = model._train_engine
+    opt.zero_grad()
+    crit(model(x)[1], labels).backward()                    # 6 images > max_batch 3: the engine is rebuilt
+    assert model._train_engine is not first
+    assert torch.equal(model._train_engine.momentum_buf, mom)
+    opt.step()
+    assert opt.fused_adapter_steps["steps"] == 2
 
 
 def test_backward_of_a_stale_graph_is_refused():
