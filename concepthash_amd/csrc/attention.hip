@@ -231,7 +231,7 @@ int launch_attn_inst(const bf16_t *qkv, int B, int ntok, int heads, bf16_t *out,
     static ch_once_per_device lds_once;
     if (int e = ch_func_max_lds((const void *)attention_kernel<KB, TAP, COMPACT>, (int)lds, lds_once)) return e;
     const float scale_log2e = 0.125f * 1.4426950408889634f;  // head_dim^-0.5 * log2(e), head_dim = 64
-    hipLaunchKernelGGL((attention_kernel<KB, TAP, COMPACT>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, ntok, heads, scale_log2e,
+    CH_LAUNCH((attention_kernel<KB, TAP, COMPACT>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, ntok, heads, scale_log2e,
                        out, cattn, ncon, rev);
     CH_LAUNCH_CHECK();
     return 0;

@@ -140,7 +140,7 @@ int launch(const GemmParams &p0, hipStream_t s) {
     constexpr int lds = 2 * STAGE_BYTES + (ch_epi::traits<EPI>::fold ? CH_FOLD_LDS_BYTES : 0);
     static ch_once_per_device lds_once;
     if (int e = ch_func_max_lds((const void *)gemm_bf16_kernel<EPI>, lds, lds_once)) return e;
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(NTHREADS), lds, s, p);
+    CH_LAUNCH(gemm_bf16_kernel<EPI>, dim3(tiles), dim3(NTHREADS), lds, s, p);
     CH_LAUNCH_CHECK();
     return 0;
 }

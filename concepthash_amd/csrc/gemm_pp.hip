@@ -469,14 +469,14 @@ int launch_pp_sched(GemmParams &p, int tiles, hipStream_t s) {
         if (p.tag == 1) {  // same code under a second name (fc2 of the encoder chain): see TAG above
             static ch_once_per_device lds_once_t;
             if (int e = ch_func_max_lds((const void *)gemm_pp_kernel<EPI, 0, SCHED, 1>, lds, lds_once_t)) return e;
-            hipLaunchKernelGGL((gemm_pp_kernel<EPI, 0, SCHED, 1>), grid, dim3(NTHREADS), lds, s, p);
+            CH_LAUNCH((gemm_pp_kernel<EPI, 0, SCHED, 1>), grid, dim3(NTHREADS), lds, s, p);
             CH_LAUNCH_CHECK();
             return 0;
         }
     }
     static ch_once_per_device lds_once;
     if (int e = ch_func_max_lds((const void *)gemm_pp_kernel<EPI, 0, SCHED>, lds, lds_once)) return e;
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, 0, SCHED>), grid, dim3(NTHREADS), lds, s, p);
+    CH_LAUNCH((gemm_pp_kernel<EPI, 0, SCHED>), grid, dim3(NTHREADS), lds, s, p);
     CH_LAUNCH_CHECK();
     return 0;
 }

@@ -13,6 +13,7 @@
 #include "kernels.h"
 
 static thread_local std::string g_last_error;
+thread_local ch_prof_pair g_ch_prof_pair;
 void ch_set_error(const std::string &msg) { g_last_error = msg; }
 extern "C" const char *ch_last_error(void) { return g_last_error.c_str(); }
 extern "C" int ch_abi_version(void) { return CH_ABI_VERSION; }
@@ -350,10 +351,17 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
 // profiler mark: called immediately before a launch of category `cat` doing `flops` algorithmic FLOPs
 inline void mark(ch_model *m, int pi, int cat, double flops, hipStream_t s) {
     ch_model::Prof &P = m->prof[pi];
+    g_ch_prof_pair = ch_prof_pair();
     if (!m->prof_on || P.n + 1 >= P.ev.size()) return;
     (void)hipEventRecord(P.ev[P.n], s);
     P.cat[P.n] = cat;
     P.flops[P.n] = flops;
+    P.exact[P.n] = 0;
+    if (cat != CH_CAT_END) {   // the launch that follows may take the pair (CH_LAUNCH): then its time is the dispatch's own
+        g_ch_prof_pair.start = P.kstart[P.n];
+        g_ch_prof_pair.stop = P.kstop[P.n];
+        g_ch_prof_pair.used = (bool *)&P.exact[P.n];
+    }
     P.n++;
 }
 
@@ -616,8 +624,11 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
 
 extern "C" void ch_model_destroy(ch_model *m) {
     if (!m) return;
-    for (auto &P : m->prof)
+    for (auto &P : m->prof) {
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : P.kstart) (void)hipEventDestroy(e);
+        for (hipEvent_t e : P.kstop) (void)hipEventDestroy(e);
+    }
     for (hipStream_t a : m->aux_stream)
         if (a) (void)hipStreamDestroy(a);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
@@ -715,12 +726,17 @@ extern "C" int ch_model_profile_begin(ch_model *m, int32_t max_launches) {
     CH_REQUIRE(m != nullptr && max_launches > 0, "profile_begin: null model or non-positive capacity");
     for (auto &P : m->prof) {
         while (P.ev.size() < (size_t)max_launches + 1) {
-            hipEvent_t e;
+            hipEvent_t e, a, b;
             CH_CHECK_HIP(hipEventCreate(&e));
+            CH_CHECK_HIP(hipEventCreate(&a));
+            CH_CHECK_HIP(hipEventCreate(&b));
             P.ev.push_back(e);
+            P.kstart.push_back(a);
+            P.kstop.push_back(b);
         }
         P.cat.assign(P.ev.size(), CH_CAT_END);
         P.flops.assign(P.ev.size(), 0.0);
+        P.exact.assign(P.ev.size(), 0);
         P.n = 0;
     }
     m->prof_on = true;
@@ -745,7 +761,10 @@ extern "C" int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *la
             const int cat = P.cat[j];
             if (cat == CH_CAT_END) continue;  // gap between two ch_encode calls
             float ms = 0.f;
-            CH_CHECK_HIP(hipEventElapsedTime(&ms, P.ev[j], P.ev[j + 1]));
+            if (P.exact[j])   // begin -> end of the dispatch itself; otherwise launch-to-launch interval (small LDS-free kernels)
+                CH_CHECK_HIP(hipEventElapsedTime(&ms, P.kstart[j], P.kstop[j]));
+            else
+                CH_CHECK_HIP(hipEventElapsedTime(&ms, P.ev[j], P.ev[j + 1]));
             ms_per_cat[cat] += ms;
             launches_per_cat[cat] += 1;
             flops_per_cat[cat] += P.flops[j];

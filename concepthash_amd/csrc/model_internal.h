@@ -49,7 +49,9 @@ struct ch_model {
     bool ln_fold = true;
     bool prof_on = false;
     struct Prof {
-        std::vector<hipEvent_t> ev;
+        std::vector<hipEvent_t> ev;          // interval form: one event in front of every launch (+ one behind the last)
+        std::vector<hipEvent_t> kstart, kstop;  // exact form: the dispatch's own begin / end (CH_LAUNCH, ch_common.h)
+        std::vector<char> exact;             // launch j took the pair (the GEMM and attention launch sites do)
         std::vector<int> cat;
         std::vector<double> flops;
         size_t n = 0;

@@ -53,30 +53,61 @@ class GpuPreprocess:
         self._mean = (ctypes.c_float * 3)(*[float(np.float32(m)) for m in mean])
         self._std = (ctypes.c_float * 3)(*[float(np.float32(s)) for s in std])
         self.max_taps = int(self.lib.ch_preprocess_max_taps())
+        self._geo = {}
+        self._ring = [{"buf": None, "event": None} for _ in range(self._RING)]
+        self._ring_pos = 0
 
-    def plan(self, sizes: Sequence[tuple]):
-        """sizes: [(h, w)] -> (descriptor array, total source bytes, workspace bytes, max rows)."""
-        B = len(sizes)
-        desc = (_lib.ImageDesc * B)()
-        src_off = tmp_off = 0
-        max_rows = 1
-        for i, (h, w) in enumerate(sizes):
-            h, w = int(h), int(w)
+    _DESC_DTYPE = np.dtype([("src_offset", "<i8"), ("tmp_offset", "<i8"), ("h", "<i4"), ("w", "<i4"), ("nh", "<i4"), ("nw", "<i4"),
+                            ("top", "<i4"), ("left", "<i4"), ("row0", "<i4"), ("nrows", "<i4")])   # == ch_image_desc / _lib.ImageDesc
+    _RING = 8          # pinned descriptor staging buffers in flight
+
+    def _geometry(self, h: int, w: int):
+        """(nh, nw, top, left, row0, nrows) of one image size; cached -- dataset images repeat a handful of sizes."""
+        key = (h, w)
+        g = self._geo.get(key)
+        if g is None:
             nw, nh = _resized_size(w, h, self.resize)
             left, top = int(round((nw - self.crop) / 2.0)), int(round((nh - self.crop) / 2.0))
             for n_in, n_out in ((w, nw), (h, nh)):
                 if 2 * math.ceil(2.0 * max(n_in / n_out, 1.0)) + 1 > self.max_taps:
-                    raise ValueError(f"image {i} ({h}x{w}) needs more than {self.max_taps} filter taps (down-scaling > ~15x)")
+                    raise ValueError(f"a {h}x{w} image needs more than {self.max_taps} filter taps (down-scaling > ~15x)")
             r0, _ = _row_bounds(h, nh, top)
             rl, cl = _row_bounds(h, nh, top + self.crop - 1)
-            nrows = rl + cl - r0
-            d = desc[i]
-            d.src_offset, d.tmp_offset = src_off, tmp_off
-            d.h, d.w, d.nh, d.nw, d.top, d.left, d.row0, d.nrows = h, w, nh, nw, top, left, r0, nrows
-            src_off += h * w * 3
-            tmp_off += nrows * self.crop * 3
-            max_rows = max(max_rows, nrows)
-        return desc, src_off, tmp_off, max_rows
+            g = self._geo[key] = (nh, nw, top, left, r0, rl + cl - r0)
+        return g
+
+    def plan(self, sizes: Sequence[tuple]):
+        """sizes: [(h, w)] -> (descriptor array (numpy, ch_image_desc layout), total source bytes, workspace bytes, max rows)."""
+        B = len(sizes)
+        hw = np.asarray(sizes, dtype=np.int64).reshape(B, 2)
+        geo = np.asarray([self._geometry(int(h), int(w)) for h, w in sizes], dtype=np.int64).reshape(B, 6)
+        desc = np.zeros(B, dtype=self._DESC_DTYPE)
+        src = hw[:, 0] * hw[:, 1] * 3
+        tmp = geo[:, 5] * self.crop * 3
+        desc["src_offset"] = np.cumsum(src) - src
+        desc["tmp_offset"] = np.cumsum(tmp) - tmp
+        desc["h"], desc["w"] = hw[:, 0], hw[:, 1]
+        for j, name in enumerate(("nh", "nw", "top", "left", "row0", "nrows")):
+            desc[name] = geo[:, j]
+        return desc, int(src.sum()), int(tmp.sum()), int(max(1, geo[:, 5].max())) if B else 1
+
+    def _stage(self, desc: np.ndarray, device) -> torch.Tensor:
+        """descriptors -> device without synchronising: through a ring of pinned host buffers and a non-blocking copy (a copy from
+        pageable memory would wait for everything queued on the stream -- once per batch, in the evaluator loop)."""
+        raw = torch.from_numpy(desc.view(np.uint8).reshape(-1))
+        slot = self._ring[self._ring_pos % self._RING]
+        self._ring_pos += 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()          # the copy that last used this buffer (8 calls ago) has long finished
+        if slot["buf"] is None or slot["buf"].numel() < raw.numel():
+            slot["buf"] = torch.empty(max(raw.numel(), 48 * 256), dtype=torch.uint8, pin_memory=True)
+        slot["buf"][:raw.numel()].copy_(raw)
+        ddev = torch.empty(raw.numel(), dtype=torch.uint8, device=device)
+        ddev.copy_(slot["buf"][:raw.numel()], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        slot["event"] = ev
+        return ddev
 
     def __call__(self, pixels: torch.Tensor, sizes: Sequence[tuple], stream=None) -> torch.Tensor:
         """pixels: uint8 device tensor, the images' HWC bytes back to back (image i is [h_i, w_i, 3]); sizes: [(h, w)]."""
@@ -90,9 +121,9 @@ class GpuPreprocess:
         if pixels.numel() != nbytes:
             raise ValueError(f"pixels holds {pixels.numel()} bytes, the sizes add up to {nbytes}")
         pixels = pixels.contiguous()
-        ddev = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(pixels.device)
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=pixels.device)
         with torch.cuda.device(pixels.device):
+            ddev = self._stage(desc, pixels.device)
+            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=pixels.device)
             _lib.check(self.lib.ch_preprocess(_lib.ptr(pixels), _lib.ptr(ddev), B, max_rows, self.crop, self._mean, self._std,
                                               _lib.ptr(out), 1 if self.out_dtype == torch.bfloat16 else 0, _lib.ptr(ws),
                                               _lib.stream_ptr(stream)), "ch_preprocess")

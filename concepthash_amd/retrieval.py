@@ -92,15 +92,22 @@ def topk_merge(idx_lists: torch.Tensor, dist_lists: torch.Tensor, stream=None) -
 # ---------------------------------------------------------------------------------------------------------------
 # labels
 # ---------------------------------------------------------------------------------------------------------------
-def prepare_labels(q_labels: torch.Tensor, g_labels: torch.Tensor):
+def labels_single(q_labels: torch.Tensor, g_labels: torch.Tensor) -> bool:
+    """2-D indicator matrices whose rows all hold exactly one class (a gallery SHARD decides for its own rows only: the ranks of a
+    sharded evaluation combine their answers, concepthash_amd.distributed)."""
+    return bool(((q_labels != 0).sum(1) == 1).all().item()) and bool(((g_labels != 0).sum(1) == 1).all().item())
+
+
+def prepare_labels(q_labels: torch.Tensor, g_labels: torch.Tensor, single=None):
     """Returns (q_lab, g_lab, LW).  1-D integer labels, or one-hot rows with exactly one class each -> int32 ids
-    (LW = 0); otherwise multi-hot -> int64 bitmasks [rows, LW]."""
+    (LW = 0); otherwise multi-hot -> int64 bitmasks [rows, LW].  `single`: the decision, when the caller has made it (globally)."""
     if q_labels.dim() == 1 and g_labels.dim() == 1:
         return q_labels.to(torch.int32).contiguous(), g_labels.to(torch.int32).contiguous(), 0
     if q_labels.dim() != 2 or g_labels.dim() != 2 or q_labels.shape[1] != g_labels.shape[1]:
         raise ValueError("labels must both be 1-D class ids or 2-D [rows, C] indicator matrices")
     qb, gb = q_labels != 0, g_labels != 0
-    single = bool((qb.sum(1) == 1).all().item()) and bool((gb.sum(1) == 1).all().item())
+    if single is None:
+        single = labels_single(q_labels, g_labels)
     if single:
         return qb.int().argmax(1).to(torch.int32).contiguous(), gb.int().argmax(1).to(torch.int32).contiguous(), 0
     C = qb.shape[1]

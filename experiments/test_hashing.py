@@ -27,6 +27,11 @@ from utils import io
 from utils.hashing import calculate_mAP, calculate_pr_curve
 
 
+def _rows(x, fn):
+    """row-wise function of an output: a tensor (single process) or this rank's block of one (`RowShard`, multi-rank)"""
+    return x.map(fn) if hasattr(x, "map") and not torch.is_tensor(x) else fn(x)
+
+
 class RetrievalEvaluation:
     def __init__(self, config: DictConfig):
         io.init_save_queue()
@@ -87,8 +92,8 @@ class RetrievalEvaluation:
                 print(f'Evaluating for "{name}"')
                 db_labels, test_labels = db_out["labels"].clone(), test_out["labels"].clone()
                 if db_labels.dim() == 1:
-                    db_labels = F.one_hot(db_labels, cfg.dataset.nclass)
-                    test_labels = F.one_hot(test_labels, cfg.dataset.nclass)
+                    db_labels = _rows(db_labels, lambda t: F.one_hot(t, cfg.dataset.nclass))
+                    test_labels = _rows(test_labels, lambda t: F.one_hot(t, cfg.dataset.nclass))
                 db_codes, test_codes = db_out[name], test_out[name]
                 if cfg.get("compute_mAP") and cfg.get("sub_code_eval"):      # reference: only inside `if compute_mAP` (:76-98)
                     db_codes, test_codes = self._sub_codes(db_codes, test_codes)
@@ -120,9 +125,13 @@ class RetrievalEvaluation:
             if self.rank == 0:
                 with open(os.path.join(self.eval_logdir, "history.json"), "w") as f:
                     json.dump(res, f)
-        if (cfg.get("save_code") or cfg.exp == "extract") and self.rank == 0:
-            print("Saving code")
-            io.fast_save({"test": test_out, "db": db_out}, os.path.join(self.eval_logdir, "outputs.pth"))
+        if cfg.get("save_code") or cfg.exp == "extract":
+            if self.distributed:       # the one place the fp32 codes move: gathered to rank 0's host, which writes the file
+                from concepthash_amd.distributed import gather_outputs
+                test_out, db_out = gather_outputs(test_out, 0), gather_outputs(db_out, 0)
+            if self.rank == 0:
+                print("Saving code")
+                io.fast_save({"test": test_out, "db": db_out}, os.path.join(self.eval_logdir, "outputs.pth"))
         total = time.time() - self.start_time
         print(f'Testing End at {datetime.today().strftime("%Y-%m-%d %H:%M:%S")}')
         print(f"Total time used: {total / 3600:.2f} hours")

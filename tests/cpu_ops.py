@@ -3,11 +3,11 @@
 import numpy as np
 import torch
 
-from concepthash_amd.retrieval import (ap_from_fixed, map_seg_rows, normalize_limits, prepare_labels,  # pure-torch host helpers
-                                       summarize)
+from concepthash_amd.retrieval import (ap_from_fixed, labels_single, map_seg_rows, normalize_limits,  # pure-torch host helpers
+                                       prepare_labels, summarize)
 from oracle import hamming_oracle as ho
 
-__all__ = ["hamming_topk", "topk_merge", "prepare_labels", "hamming_hist", "hist_prefix", "hamming_ap", "hamming_ap_multi",
+__all__ = ["hamming_topk", "topk_merge", "prepare_labels", "labels_single", "hamming_hist", "hist_prefix", "hamming_ap", "hamming_ap_multi",
            "map_seg_rows", "ap_from_fixed", "normalize_limits", "summarize"]
 
 

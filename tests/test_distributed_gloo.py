@@ -114,13 +114,32 @@ def _trainer_worker(rank, world, port, out_dir):
         tr.load_dataloader()
         tr.model, tr.criterion = FakeModel(), FakeCriterion()
         meters, out = tr.inference_one_epoch("db", True)
-        torch.save({"codes": out["codes"], "labels": out["labels"], "n": meters["loss"].count}, os.path.join(out_dir, f"t{rank}.pt"))
+        # outputs come back as RowShards: this rank's rows only (nothing gathered, nothing on another rank's host)
+        from concepthash_amd.distributed import RowShard, shard_bounds
+        b = shard_bounds(40, world)
+        assert isinstance(out["codes"], RowShard) and out["codes"].local.shape[0] == b[rank + 1] - b[rank]
+        assert out["codes"].shape == (40, 8) and out["codes"].offset == b[rank] and out["codes"].counts == [20, 20]
+        sub = out["codes"][:, 2:5]                                           # what sub_code_eval does
+        assert sub.shape == (40, 3) and torch.equal(sub.local, out["codes"].local[:, 2:5])
+        mean = out["codes"].mean(dim=0, keepdim=True)                        # what zero_mean_eval does
+        full = out["codes"].gather(dst=None)
+        assert torch.equal(mean, full.mean(dim=0, keepdim=True))
+        assert torch.equal((out["codes"] - mean).gather(dst=None), full - mean)
+        only0 = out["labels"].gather(dst=0)
+        assert (only0 is not None) == (rank == 0)
+        torch.save({"codes": full, "labels": out["labels"].gather(dst=None), "n": meters["loss"].count}, os.path.join(out_dir, f"t{rank}.pt"))
+        tr.config["gather_outputs"] = True                                   # the round-2 behaviour on request: gathered CPU tensors
+        _, outg = tr.inference_one_epoch("db", True)
+        assert torch.is_tensor(outg["codes"]) and torch.equal(outg["codes"], full)
+        tr.config["gather_outputs"] = False
         # a split with fewer samples than ranks: rank 1's shard is EMPTY -- it must still enter every collective (no hang) and
         # get the gathered outputs
         tr.dataset["test"] = SyntheticHashingDataset(5, size=1, image_size=4, seed=3)
         tr.load_dataloader()
         m1, o1 = tr.inference_one_epoch("test", True)
-        torch.save({"codes": o1["codes"], "labels": o1["labels"], "n": m1["loss"].count}, os.path.join(out_dir, f"e{rank}.pt"))
+        assert o1["codes"].counts == [1, 0]
+        torch.save({"codes": o1["codes"].gather(dst=None), "labels": o1["labels"].gather(dst=None), "n": m1["loss"].count},
+                   os.path.join(out_dir, f"e{rank}.pt"))
     finally:
         dist.destroy_process_group()
 

@@ -164,3 +164,24 @@ def test_main_v2_two_ranks_on_one_gpu_match_the_single_process_run(tmp_path):
         if k.startswith(("test_", "db_")):
             assert abs(h1[k] - h2[k]) < 1e-6, k          # sample-weighted meters, reduced over ranks
     assert sorted(os.listdir(ev2)) == sorted(os.listdir(ev1))      # one set of files, written once
+    # the code post-processing options on sharded outputs: a bit-range sub-code and the database-mean shift (the mean is taken
+    # with the single-process arithmetic on rank 0 and broadcast) -- history.json again equal bit for bit
+    extra = ["zero_mean_eval=True", "sub_code_eval=True", "sub_code_eval_setting.rand_bits=1", "sub_code_eval_setting.start_bit=8",
+             "sub_code_eval_setting.end_bit=56", "save_code=False"]
+    ev3, ev4 = str(tmp_path / "ev_single_pp"), str(tmp_path / "ev_two_ranks_pp")
+    subprocess.run([sys.executable, os.path.join(ROOT, "main_v2.py")] + args + extra + ["eval_logdir=" + ev3], check=True, env=env,
+                   cwd=str(tmp_path))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        e = dict(env, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 CH_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "main_v2.py")] + args + extra + ["eval_logdir=" + ev4], env=e,
+                                      cwd=str(tmp_path)))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    h3, h4 = json.load(open(os.path.join(ev3, "history.json"))), json.load(open(os.path.join(ev4, "history.json")))
+    assert h3["mAP"] == h4["mAP"] and h3["precisions"] == h4["precisions"] and h3["recalls"] == h4["recalls"]
+    assert h3["mAP"] != h1["mAP"]                                  # the options did change the codes that were scored
+    assert not os.path.exists(os.path.join(ev4, "outputs.pth"))

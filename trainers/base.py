@@ -4,7 +4,8 @@ trainers/base.py:17-71,128-175,195-210,275-307,340-358).
 Kept: method names, argument meaning, return shapes -- `inference_one_epoch(datakey, return_codes=True) ->
 (meters, {'codes': FloatTensor[N, nbit] on CPU, 'labels': Tensor[N, C]})`.
 Changed on purpose: per-batch outputs stay on the GPU and are copied to the host once per epoch (the reference does a
-synchronising `.cpu()` per batch, trainers/base.py:291-296).  Training: the adapters + get_training_modules() with the backbone frozen
+synchronising `.cpu()` per batch, trainers/base.py:291-296), and so do the loss / accuracy meters (utils.misc.DeviceMeters: the
+reference reads every term back with `.item()` per batch, trainers/coop.py:80-101).  Training: the adapters + get_training_modules() with the backbone frozen
 (`backbone_lr_scale: 0`, the shipped ConceptHash config); a trainable backbone is not built.
 """
 from __future__ import annotations
@@ -18,7 +19,7 @@ import torch
 import yaml
 
 from concepthash_amd.config import DictConfig, instantiate, to_container
-from utils.misc import AverageMeter
+from utils.misc import AverageMeter, DeviceMeters
 
 
 class BaseTrainer:
@@ -81,36 +82,47 @@ class BaseTrainer:
         assert self.is_ready_for_inference()
         self.model.eval()
         self.criterion.eval()
-        meters = defaultdict(AverageMeter)
+        dmeters = DeviceMeters(self.device)       # sums stay on the GPU: no `.item()` inside the batch loop
         ret = defaultdict(list)
         self.inference_datakey = datakey
         loader = self.dataloader[datakey]
         n = len(loader) if hasattr(loader, "__len__") else 0
         for i, data in enumerate(loader):
-            output = self.inference_one_batch(data, meters, bidx=i, **kwargs)
+            output = self.inference_one_batch(data, dmeters, bidx=i, **kwargs)
             if return_codes:
                 for key, val in output.items():
                     ret[key].append(val)          # GPU tensors stay on the GPU until the epoch ends
             if n and (i + 1) % max(1, n // 10) == 0:
-                logging.info("%s: batch %d/%d %s", datakey, i + 1, n, {k: round(v.avg, 4) for k, v in meters.items()})
+                # progress line without a synchronisation: the newest COMPLETED asynchronous snapshot of the sums (one interval old)
+                logging.info("%s: batch %d/%d %s", datakey, i + 1, n, dmeters.latest() or "")
+                dmeters.snapshot()
+        meters = defaultdict(AverageMeter, dmeters.finalize())     # the one device -> host read of the epoch's meters
         if not return_codes:
             return meters
         res = {}
         if self.distributed:
             # every rank enters the SAME sequence of collectives, also one whose shard produced no batch: the ranks first agree
             # on the output keys (name, trailing shape, dtype) -- taken from any rank that has data -- and an empty rank
-            # contributes zero-row tensors of that description
+            # contributes zero-row tensors of that description.
+            # Tensor outputs are NOT gathered: each comes back as a `RowShard` -- this rank's rows, on its GPU, plus the per-rank row
+            # counts -- so that retrieval shards the gallery where it was encoded (`utils.hashing` all-gathers only the packed QUERY
+            # codes); `config.gather_outputs: true` restores the gathered CPU tensors on every rank.
             import torch.distributed as dist
-            from concepthash_amd.distributed import _all_gather_ragged
+            from concepthash_amd.distributed import RowShard
             mine = [(k, tuple(v[0].shape[1:]), str(v[0].dtype).replace("torch.", "")) for k, v in sorted(ret.items())
                     if isinstance(v[0], torch.Tensor)]
+            other = sorted(k for k, v in ret.items() if not isinstance(v[0], torch.Tensor))
             allk = [None] * self.world_size
-            dist.all_gather_object(allk, mine)
-            spec = next((x for x in allk if x), [])
+            dist.all_gather_object(allk, (mine, other))
+            spec = next((x[0] for x in allk if x[0]), [])
             for key, tail, dt in spec:
                 t = torch.cat(ret[key]) if key in ret else torch.zeros((0,) + tuple(tail), dtype=getattr(torch, dt), device=self.device)
-                t, _ = _all_gather_ragged(t.contiguous())      # ranks hold contiguous blocks -> rank-major == dataset order
-                res[key] = t.cpu()
+                shard = RowShard(t.contiguous())                # ranks hold contiguous blocks -> rank-major == dataset order
+                res[key] = shard.gather(dst=None) if self.config.get("gather_outputs") else shard
+            for key in sorted(set().union(*[x[1] for x in allk])):      # non-tensor (numpy / list) outputs: small, replicated
+                parts = [None] * self.world_size
+                dist.all_gather_object(parts, np.concatenate(ret[key]) if key in ret else None)
+                res[key] = np.concatenate([p for p in parts if p is not None])
         else:
             for key, vals in ret.items():
                 if isinstance(vals[0], torch.Tensor):
@@ -179,12 +191,13 @@ class BaseTrainer:
         assert self.is_ready_for_training()
         self.model.train()
         self.criterion.train()
-        meters = defaultdict(AverageMeter)
+        dmeters = DeviceMeters(self.device)       # as in inference_one_epoch: nothing is read back inside the batch loop
         loader = self.dataloader["train"]
         n = len(loader) if hasattr(loader, "__len__") else 0
         for i, data in enumerate(loader):
-            self.train_one_batch(data, meters, bidx=i, **kwargs)
+            self.train_one_batch(data, dmeters, bidx=i, **kwargs)
             if n and (i + 1) % max(1, n // 5) == 0:
-                logging.info("train: batch %d/%d %s", i + 1, n, {k: round(v.avg, 4) for k, v in meters.items()})
+                logging.info("train: batch %d/%d %s", i + 1, n, dmeters.latest() or "")
+                dmeters.snapshot()
         self.scheduler.step()
-        return meters
+        return defaultdict(AverageMeter, dmeters.finalize())

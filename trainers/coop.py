@@ -80,13 +80,28 @@ class COOPTrainer(BaseTrainer):
         output = self.model(image, labels) if self.config.model.get("pass_labels") else self.model(image)
         return (image, labels, index), self.parse_model_output(output)
 
-    def _update_accuracy_meters(self, output, labels, meters, n):
-        for key, val in output.items():      # accuracy per logits tensor, named as the reference names them (:90-101, :140-150)
+    @staticmethod
+    def _accuracies(output, labels):
+        """accuracy per logits tensor, named as the reference names them (:90-101, :140-150) -- 0-dim DEVICE tensors"""
+        accs = {}
+        for key, val in output.items():
             if "logits" in key and torch.is_tensor(val):
                 val = val.detach()
                 pred = val.mean(dim=0).argmax(1) if val.dim() == 3 else val.argmax(1)
                 parts = key.split("_")
-                meters["acc" if len(parts) == 1 else f"acc_{parts[1]}"].update((pred == labels.argmax(1)).float().mean().item(), n)
+                accs["acc" if len(parts) == 1 else f"acc_{parts[1]}"] = (pred == labels.argmax(1)).float().mean()
+        return accs
+
+    @staticmethod
+    def _record(meters, values, n):
+        """One update for all meters of the batch.  `meters` from BaseTrainer's loops is a utils.misc.DeviceMeters: the values stay
+        on the GPU (two tiny launches, no `.item()`); a plain dict of AverageMeter (a caller driving the batch methods itself, as
+        the reference's loops do) gets the reference's per-value host update."""
+        if hasattr(meters, "update_many"):
+            meters.update_many(values, n)
+        else:
+            for key, val in values.items():
+                meters[key].update(val.item() if torch.is_tensor(val) else val, n)
 
     def train_one_batch(self, *args, **kwargs):
         """reference trainers/coop.py:107-154: zero_grad -> forward -> criterion -> backward -> step -> meters.  The encoder's forward
@@ -99,10 +114,10 @@ class COOPTrainer(BaseTrainer):
         loss.backward()
         self.optimizer.step()
         n = image.size(0)
-        meters["loss"].update(loss.item(), n)
-        for key, val in self.criterion.losses.items():
-            meters[key].update(val.item(), n)
-        self._update_accuracy_meters(output, labels, meters, n)
+        vals = {"loss": loss.detach()}
+        vals.update({k: v.detach() for k, v in self.criterion.losses.items()})
+        vals.update(self._accuracies(output, labels))
+        self._record(meters, vals, n)
 
     def inference_one_batch(self, *args, **kwargs):
         data, meters = args
@@ -111,8 +126,8 @@ class COOPTrainer(BaseTrainer):
             n = image.size(0)
             target = labels if self.config.dataset.get("multiclass") else labels.argmax(1)
             loss = self.criterion(output, target)
-            meters["loss"].update(loss.item(), n)
-            for key, val in self.criterion.losses.items():
-                meters[key].update(val.item(), n)
-            self._update_accuracy_meters(output, labels, meters, n)
+            vals = {"loss": loss}
+            vals.update(self.criterion.losses)
+            vals.update(self._accuracies(output, labels))
+            self._record(meters, vals, n)
         return {"codes": output["codes"], "labels": labels}

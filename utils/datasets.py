@@ -136,3 +136,25 @@ class SyntheticHashingDataset(Dataset):
         target = torch.zeros(self.nclass)
         target[lab] = 1.0
         return img.to(self.dtype), target, index
+
+
+class DeviceRawLoader:
+    """A loader-shaped iterable over decoded uint8 images that already sit in GPU memory (all of one size): yields
+    `(RawImageBatch, one-hot targets, indices)` per batch, exactly what `raw_collate` hands the trainer for a `gpu_preprocess`
+    dataset, without a DataLoader, worker processes or host copies.  For measuring the evaluator loop itself
+    (`bench.py`'s `evaluator_inclusive`) and for tests; `pixels` is [N, H, W, 3] uint8, `labels` [N] int64, both on the device."""
+
+    def __init__(self, pixels: torch.Tensor, labels: torch.Tensor, nclass: int, batch_size: int):
+        assert pixels.dim() == 4 and pixels.shape[-1] == 3 and pixels.dtype == torch.uint8
+        self.pixels, self.labels, self.nclass, self.batch_size = pixels, labels, int(nclass), int(batch_size)
+        self.targets = torch.nn.functional.one_hot(labels.long(), self.nclass).float()
+        self.index = torch.arange(pixels.shape[0], device=pixels.device)
+
+    def __len__(self):
+        return -(-self.pixels.shape[0] // self.batch_size)
+
+    def __iter__(self):
+        n, (h, w) = self.pixels.shape[0], self.pixels.shape[1:3]
+        for b0 in range(0, n, self.batch_size):
+            b1 = min(n, b0 + self.batch_size)
+            yield RawImageBatch(self.pixels[b0:b1].reshape(-1), [(h, w)] * (b1 - b0)), self.targets[b0:b1], self.index[b0:b1]

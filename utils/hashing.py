@@ -6,8 +6,9 @@ arity below are those of the call sites (experiments/test_hashing.py:106-131,153
 trainers/orthohash.py:362).  Semantics are the published definition of SURVEY.md section 8c / DESIGN.md section 2.
 
 Inputs may be CPU or GPU float tensors (the reference hands over CPU tensors, trainers/base.py:291-296); they are moved
-to the current GPU, sign-packed to uint64 and never expanded to a (Qn, G) matrix.  With an initialised
-`torch.distributed` group of more than one rank, the database rows are sharded across the ranks.
+to the current GPU, sign-packed to uint64 and never expanded to a (Qn, G) matrix.  In a multi-rank run the trainer hands over
+`concepthash_amd.distributed.RowShard`s -- each rank's rows, still on the GPU that encoded them: the database is scanned in place,
+only the packed query codes are all-gathered.
 """
 from __future__ import annotations
 
@@ -45,8 +46,30 @@ def _sharded():
 
 def _evaluate(db_codes, db_labels, test_codes, test_labels, R, ks, remove_first):
     dev = _device()
+    from concepthash_amd.distributed import RowShard
+    if isinstance(db_codes, RowShard) or isinstance(test_codes, RowShard):
+        # multi-rank evaluation on the outputs of BaseTrainer.inference_one_epoch: every rank's block of the DATABASE stays on the
+        # GPU that encoded it and is scanned there; the QUERIES' packed codes (8-16 bytes each) and compact labels are all-gathered
+        from concepthash_amd.distributed import ShardedRetrieval, _all_gather_ragged
+        if not (isinstance(db_codes, RowShard) and isinstance(db_labels, RowShard)):
+            raise TypeError("sharded evaluation: database codes and labels must both be RowShards")
+        g = rt.pack_sign(db_codes.local.to(dev, torch.float32))
+        sr = ShardedRetrieval(g, db_labels.local.to(dev))
+        if isinstance(test_codes, RowShard):
+            q = sr.gather_queries(rt.pack_sign(test_codes.local.to(dev, torch.float32)))
+        else:
+            q = rt.pack_sign(torch.as_tensor(test_codes).to(dev, torch.float32))
+        if isinstance(test_labels, RowShard):
+            tl = test_labels.local.to(dev)
+            if tl.dim() == 2:
+                tl = (tl != 0).to(torch.uint8)                      # indicator rows travel as bytes
+            ql, _ = _all_gather_ragged(tl.contiguous(), sr.group)
+        else:
+            ql = _labels(test_labels, dev)
+        return sr.evaluate(q, ql, R=R, ks=ks, remove_first=remove_first)
     q = rt.pack_sign(torch.as_tensor(test_codes).to(dev, torch.float32))
     if _sharded():
+        # replicated inputs under an initialised process group (a caller that gathered its codes): every rank takes its block
         import torch.distributed as dist
         from concepthash_amd.distributed import ShardedRetrieval, shard_bounds
         b = shard_bounds(db_codes.shape[0], dist.get_world_size())
