@@ -453,6 +453,7 @@ def evaluator_block(torch, syn, sd, cfg, B, dev, value):
     conf = cfglib.DictConfig(device=str(dev), batch_size=B, model=cfglib.DictConfig(has_adapter=True),
                              dataset=cfglib.DictConfig(multiclass=False, resize=256, crop=cfg["image"], norm=3, gpu_preprocess=True))
     tr = COOPTrainer(conf)
+    tr.distributed, tr.rank, tr.world_size = False, 0, 1       # a rank-0-only block: never enter a collective (N > 1 runs)
     tr.model = model.to(dev).eval()
     tr.criterion = LGHLoss(margin=0.2, scale=8, loss_scales=dict(bin_logits=1, cont_logits=1, concept_logits=1), ncontext=4).to(dev)
     nb, h, w = 8, 375, 500

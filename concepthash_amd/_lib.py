@@ -39,6 +39,7 @@ SIGNATURES = {
     "ch_model_destroy": (None, [c_void_p]),
     "ch_model_device_bytes": (c_size_t, [c_void_p]),
     "ch_model_flops_per_image": (c_double, [c_void_p]),
+    "ch_model_set_concept_attn_layers": (c_int, [c_void_p, c_int32]),
     "ch_model_profile_begin": (c_int, [c_void_p, c_int32]),
     "ch_model_profile_end": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "ch_debug_gemm": (c_int, [c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,

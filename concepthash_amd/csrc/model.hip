@@ -370,7 +370,7 @@ inline void mark(ch_model *m, int pi, int cat, double flops, hipStream_t s) {
 // prune: (ch_encode) in the final layer only the rows the hashing head reads -- CLS and the Q concept tokens of every image --
 // are carried past the attention (whose keys / values still cover all tokens); their residual lives in mm->Hc afterwards
 int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int img0, int B, int nlayers, hipStream_t s,
-              float *concept_attn, bool prune) {
+              float *concept_attn, bool prune, int Btot) {
     const ch_model_config &c = mm->cfg;
     const int D = c.dim, M = c.ffn, ntok = mm->ntok, np = mm->np;
     const int rows = B * ntok;
@@ -495,8 +495,11 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         const bool pruned = prune && fold && mm->prune_last && i == nlayers - 1 && nlayers == c.layers;
         const int nq = 1 + c.ncontext;
         mark(mm, pi, pruned ? CH_CAT_ATTENTION_PRUNED : CH_CAT_ATTENTION, 4.0 * B * (double)(pruned ? nq : ntok) * ntok * D, s);
-        if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, i == nlayers - 1 ? concept_attn : nullptr, c.ncontext, pruned,
-                                 next_dir() != 0))
+        // concept-token attention tap: the last layer's rows, or (ch_model_set_concept_attn_layers) every layer's, [L, Btot, heads, Q, Np]
+        float *cattn = !concept_attn ? nullptr
+                       : mm->attn_all_layers ? concept_attn + (size_t)i * Btot * c.heads * c.ncontext * np
+                       : i == nlayers - 1 ? concept_attn : nullptr;
+        if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, cattn, c.ncontext, pruned, next_dir() != 0))
             return e;
         if (pruned) {
             // from here on every buffer holds B * (1 + Q) compact rows (image-major: CLS, then the concept tokens)
@@ -532,14 +535,14 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
 int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nlayers, hipStream_t s,
                 float *concept_attn = nullptr, bool prune = false) {
     const int ns = std::min(m->nstreams, B);
-    if (ns < 2) return run_chain(m, 0, images, image_dtype, 0, B, nlayers, s, concept_attn, prune);
+    if (ns < 2) return run_chain(m, 0, images, image_dtype, 0, B, nlayers, s, concept_attn, prune, B);
     // micro-batch i = images [i*B/ns, (i+1)*B/ns); chain 0 on the caller's stream, the others fork from / join it
     CH_CHECK_HIP(hipEventRecord(m->ev_fork, s));
     for (int i = 0; i < ns; ++i) {
         const int b0 = (int)((int64_t)B * i / ns), b1 = (int)((int64_t)B * (i + 1) / ns);
         hipStream_t si = i == 0 ? s : m->aux_stream[i - 1];
         if (i > 0) CH_CHECK_HIP(hipStreamWaitEvent(si, m->ev_fork, 0));
-        if (int e = run_chain(m, i, images, image_dtype, b0, b1 - b0, nlayers, si, concept_attn, prune)) return e;
+        if (int e = run_chain(m, i, images, image_dtype, b0, b1 - b0, nlayers, si, concept_attn, prune, B)) return e;
         if (i > 0) {
             CH_CHECK_HIP(hipEventRecord(m->ev_join[i - 1], si));
             CH_CHECK_HIP(hipStreamWaitEvent(s, m->ev_join[i - 1], 0));
@@ -639,6 +642,12 @@ extern "C" void ch_model_destroy(ch_model *m) {
 }
 
 extern "C" size_t ch_model_device_bytes(const ch_model *m) { return m ? m->bytes : 0; }
+
+extern "C" int ch_model_set_concept_attn_layers(ch_model *m, int32_t all_layers) {
+    CH_REQUIRE(m != nullptr, "set_concept_attn_layers: null model");
+    m->attn_all_layers = all_layers != 0;
+    return 0;
+}
 
 extern "C" double ch_model_flops_per_image(const ch_model *m) {
     if (!m) return 0.0;

@@ -47,6 +47,7 @@ struct ch_model {
     // LayerNorm folded into the consumer GEMMs: no LayerNorm launches inside the layer loop.
     // Needs adapters (their up-projection epilogue is where the bf16 copy of the residual and its row statistics are made).
     bool ln_fold = true;
+    bool attn_all_layers = false;  // ch_model_set_concept_attn_layers: the concept-token attention tap covers every layer
     bool prof_on = false;
     struct Prof {
         std::vector<hipEvent_t> ev;          // interval form: one event in front of every launch (+ one behind the last)

@@ -198,7 +198,10 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
         if (int e = gemm(t, ch, rows, g, s)) return e;
         const bool pruned = t->prune_last && l == L - 1;
         // last layer: optionally tap the concept tokens' attention rows over the patch tokens (attn_cache[-1][:, :, -Q:, 1:-Q])
-        float *cattn = (l == L - 1 && out_cattn_all) ? out_cattn_all + (size_t)img0 * c.heads * Q * np : nullptr;
+        // (ch_model_set_concept_attn_layers: every layer's rows, [L, B, heads, Q, Np])
+        float *cattn = !out_cattn_all ? nullptr
+                       : m->attn_all_layers ? out_cattn_all + ((size_t)l * t->B + img0) * c.heads * Q * np
+                       : l == L - 1 ? out_cattn_all + (size_t)img0 * c.heads * Q * np : nullptr;
         if (int e = ch_attention(R.d3(v.QKV), B, ntok, c.heads, R.d(v.AO), s, cattn, Q, pruned)) return e;
         if (pruned) {      // from here on every buffer of this layer holds B * (1 + Q) compact rows (CLS, then the concept tokens)
             cur = B * nq;
@@ -323,7 +326,9 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, const float *dca
             dHb = dHbfull;
             cur = rows;
         }
-        const float *dpext = (l == L - 1 && dcattn_all) ? dcattn_all + (size_t)img0 * c.heads * Q * (ntok - Q - 1) : nullptr;
+        const float *dpext = !dcattn_all ? nullptr
+                             : t->m->attn_all_layers ? dcattn_all + ((size_t)l * t->B + img0) * c.heads * Q * (ntok - Q - 1)
+                             : l == L - 1 ? dcattn_all + (size_t)img0 * c.heads * Q * (ntok - Q - 1) : nullptr;
         if (int e = ch_attention_bwd(R.d3(v.QKV), dctx, B, ntok, c.heads, tQKV, s, dpext, Q)) return e;
         g = GemmCall{D, 3 * D, tQKV, x.qkv_wgT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;

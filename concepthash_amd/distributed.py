@@ -226,6 +226,9 @@ class ShardedRetrieval:
         # relevant rows, and the AP terms come from the records once the GLOBAL bases exist (CH_HAMMING_RECORDS=0 = two scans)
         use_rec = (hasattr(ops, "hamming_hist_rec") and os.environ.get("CH_HAMMING_RECORDS", "1") != "0"
                    and ops.records_fit(Qn, max(gmax, 1), W, seg))
+        if use_rec and LW == 0 and hasattr(ops, "predicted_overflow") and Qn * max(gmax, 1) >= ops.OVERFLOW_MIN_PAIRS:
+            # a local choice (each rank for its own shard): only speed depends on it
+            use_rec = ops.predicted_overflow(q_lab, g_lab, W, seg, ops.record_cap(Qn, max(gmax, 1), W, seg)) <= ops.OVERFLOW_SWITCH
         if use_rec:
             hist, recs = ops.hamming_hist_rec(q_all, self.gallery, q_lab, g_lab, LW, seg)
         else:

@@ -185,13 +185,16 @@ class ConceptHashEncoder:
             raise ValueError(f"images are on {images.device}, the model is on {self.device}")
 
     def encode(self, images: torch.Tensor, want: Iterable[str] = ("codes", "packed"), stream=None) -> Dict[str, torch.Tensor]:
-        """want: subset of {codes, packed, logits_cont, logits_bin, logits_concept, hash_features, image_features, concept_attn};
-        'codes' is always produced.  Batches larger than max_batch are processed in chunks on the same stream."""
+        """want: subset of {codes, packed, logits_cont, logits_bin, logits_concept, hash_features, image_features, concept_attn,
+        concept_attn_layers}; 'codes' is always produced.  Batches larger than max_batch are processed in chunks on the same stream.
+        concept_attn: the last layer's attention of the concept tokens over the patch tokens [B, heads, Q, Np];
+        concept_attn_layers: the same rows of EVERY layer [L, B, heads, Q, Np] (what the reference's `attn_cache` holds for those
+        tokens, models/arch/coop.py:481-482)."""
         self._check_images(images)
         images = images.contiguous()
         want = set(want) | {"codes"}
         unknown = want - {"codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features", "image_features",
-                          "concept_attn"}
+                          "concept_attn", "concept_attn_layers"}
         if unknown:
             raise KeyError(f"unknown outputs {sorted(unknown)}")
         B = images.shape[0]
@@ -208,10 +211,11 @@ class ConceptHashEncoder:
             out["hash_features"] = torch.empty(B, c["ncontext"], c["dim"], dtype=torch.float32, device=dev)
         if "image_features" in want:
             out["image_features"] = torch.empty(B, c["proj_dim"], dtype=torch.float32, device=dev)
-        if "concept_attn" in want:   # last-layer attention of the concept tokens over the patch tokens [B, heads, Q, Np]
+        all_layers = "concept_attn_layers" in want
+        if "concept_attn" in want and not all_layers:   # last-layer attention of the concept tokens over the patch tokens [B, heads, Q, Np]
             out["concept_attn"] = torch.empty(B, c["heads"], c["ncontext"], self.ntok - 1 - c["ncontext"], dtype=torch.float32,
                                               device=dev)
-        concept_chunks = []
+        concept_chunks, attn_chunks = [], []
         dt = 0 if images.dtype == torch.float32 else 1
         sp = _lib.stream_ptr(stream)
         mb = c["max_batch"]
@@ -226,11 +230,22 @@ class ConceptHashEncoder:
                 def sl(name):
                     return _lib.ptr(out[name][b0:b1]) if name in out else ctypes.c_void_p(0)
 
+                attn_ptr = sl("concept_attn")
+                if all_layers:       # [L, chunk, heads, Q, Np]: the library strides the layers by the chunk's batch
+                    al = torch.empty(c["layers"], b1 - b0, c["heads"], c["ncontext"], self.ntok - 1 - c["ncontext"],
+                                     dtype=torch.float32, device=dev)
+                    attn_chunks.append(al)
+                    attn_ptr = _lib.ptr(al)
+                _lib.check(self.lib.ch_model_set_concept_attn_layers(self._h, 1 if all_layers else 0), "ch_model_set_concept_attn_layers")
                 _lib.check(self.lib.ch_encode(self._h, _lib.ptr(images[b0:b1]), dt, b1 - b0, sl("codes"), sl("packed"),
                                               sl("logits_cont"), sl("logits_bin"), _lib.ptr(lc), sl("hash_features"),
-                                              sl("image_features"), sl("concept_attn"), sp), "ch_encode")
+                                              sl("image_features"), attn_ptr, sp), "ch_encode")
         if concept_chunks:
             out["logits_concept"] = concept_chunks[0] if len(concept_chunks) == 1 else torch.cat(concept_chunks, dim=1)
+        if attn_chunks:
+            out["concept_attn_layers"] = attn_chunks[0] if len(attn_chunks) == 1 else torch.cat(attn_chunks, dim=1)
+            if "concept_attn" in want:
+                out["concept_attn"] = out["concept_attn_layers"][-1]
         return out
 
     def hidden_states(self, images: torch.Tensor, layer: int, stream=None) -> torch.Tensor:

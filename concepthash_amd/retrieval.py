@@ -261,6 +261,33 @@ def records_fit(Qn: int, G: int, W: int, seg_rows: int) -> bool:
     return record_cap(Qn, G, W, seg_rows) >= min(seg_rows, seg_rows // 64 + 32)
 
 
+OVERFLOW_SWITCH = 0.30     # predicted fraction of overflowing (query tile, segment) workgroups above which two scans are faster
+OVERFLOW_MIN_PAIRS = 1 << 31   # below this many (query, row) pairs the whole evaluation is < 1 ms: not worth a prediction
+
+
+def predicted_overflow(q_lab: torch.Tensor, g_lab: torch.Tensor, W: int, seg_rows: int, cap: int) -> float:
+    """Fraction of the recording scan's (query tile, gallery segment) workgroups in which some query's record list would exceed
+    `cap` entries -- EXACT for single-label ids, from the per-segment class histogram of the gallery labels (a few launches on
+    G + Qn x nseg elements; one host read).  A list overflows when a query's class has more than `cap` rows inside one segment:
+    galleries listed class by class under shuffled queries do that in nearly every workgroup, and there the one-scan form (which
+    redoes every overflowed workgroup with the two-scan kernel) loses to running two scans outright: 81 vs 65 ms at 16,384 x 1M x
+    128 bit."""
+    lib = _lib.load()
+    G, Qn = g_lab.shape[0], q_lab.shape[0]
+    if G == 0 or Qn == 0 or cap >= seg_rows:
+        return 0.0
+    nseg = -(-G // seg_rows)
+    blk = int(lib.ch_hamming_rec_block(W))
+    ncls = int(torch.maximum(q_lab.max(), g_lab.max()).item()) + 1
+    seg_id = torch.arange(G, device=g_lab.device, dtype=torch.int64) // seg_rows
+    counts = torch.bincount(seg_id * ncls + g_lab.to(torch.int64), minlength=nseg * ncls).view(nseg, ncls)
+    over = counts[:, q_lab.to(torch.int64)] > cap                               # [nseg, Qn]
+    pad = (-Qn) % blk
+    if pad:
+        over = torch.cat([over, torch.zeros(nseg, pad, dtype=torch.bool, device=over.device)], dim=1)
+    return float(over.view(nseg, -1, blk).any(dim=2).float().mean().item())
+
+
 def hamming_hist_rec(q, g, q_lab, g_lab, LW: int, seg_rows: int, rec_cap: Optional[int] = None, stream=None):
     """mAP pass 1 of the one-scan form: the histogram of hamming_hist plus the per-lane record lists of the relevant rows
     -> (hist, records) where records = (rec, rec_cap, rec_cnt, wg_flags) is what hamming_ap_rec takes."""
@@ -348,7 +375,9 @@ def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels:
     floats/lists plus the raw integer statistics (S, nrel, hits, total) that the parity tests compare bit-for-bit with the
     oracle.  With a list R: mAP, S, nrel, ap are lists (one entry per R).
     records (default on; CH_HAMMING_RECORDS=0 = off): the one-scan form -- the histogram pass also records the relevant rows and
-    the AP pass walks those records instead of scanning the gallery again; rec_cap overrides the list capacity (tests)."""
+    the AP pass walks those records instead of scanning the gallery again; rec_cap overrides the list capacity (tests).  Left to the
+    default, large single-label problems first predict (exactly, from the labels) how many workgroups' lists would overflow and run
+    the two-scan form where most would (`predicted_overflow`)."""
     q, g = _check_packed(q, g)
     Qn, W = q.shape
     G = g.shape[0]
@@ -375,6 +404,9 @@ def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels:
     limits, idx_of = normalize_limits(Rs + ks)
     if records is None:
         records = os.environ.get("CH_HAMMING_RECORDS", "1") != "0" and (rec_cap is not None or records_fit(Qn, G, W, seg))
+        if records and rec_cap is None and LW == 0 and Qn * G >= OVERFLOW_MIN_PAIRS:
+            # the label layout decides which form is faster (never the result): lists that would overflow almost everywhere -> two scans
+            records = predicted_overflow(q_lab, g_lab, W, seg, record_cap(Qn, G, W, seg)) <= OVERFLOW_SWITCH
     if records:   # one distance scan: histogram + records of the relevant rows, prefix, then the AP terms from the records
         hist, recs = hamming_hist_rec(q, g, q_lab, g_lab, LW, seg, rec_cap=rec_cap)
         base, totals = hist_prefix(hist)

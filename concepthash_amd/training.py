@@ -116,7 +116,9 @@ class TrainEngine:
             _lib.check(self.lib.ch_trainer_refresh(self._t, _lib.stream_ptr(stream)), "ch_trainer_refresh")
         self._stale = False
 
-    def forward(self, images: torch.Tensor, concept_tokens: torch.Tensor, want_cls: bool = False, want_attn: bool = False):
+    def forward(self, images: torch.Tensor, concept_tokens: torch.Tensor, want_cls: bool = False, want_attn=False):
+        """want_attn: False | True (the last layer's concept-token attention rows [B, heads, Q, Np]) | "all" (every layer's,
+        [L, B, heads, Q, Np]); `backward` then takes the cotangent in the same form."""
         self.encoder._check_images(images)
         B = images.shape[0]
         if B > self.max_batch:
@@ -129,8 +131,11 @@ class TrainEngine:
         hf = torch.empty(B, c["ncontext"], c["dim"], dtype=torch.float32, device=self.device)
         cls = torch.empty(B, c["dim"], dtype=torch.float32, device=self.device) if want_cls else None
         npatch = (c["image_size"] // c["patch"]) ** 2
-        attn = torch.empty(B, c["heads"], c["ncontext"], npatch, dtype=torch.float32, device=self.device) if want_attn else None
+        all_layers = want_attn == "all"
+        shape = ((c["layers"],) if all_layers else ()) + (B, c["heads"], c["ncontext"], npatch)
+        attn = torch.empty(shape, dtype=torch.float32, device=self.device) if want_attn else None
         with torch.cuda.device(self.device):
+            _lib.check(self.lib.ch_model_set_concept_attn_layers(self.encoder._h, 1 if all_layers else 0), "ch_model_set_concept_attn_layers")
             _lib.check(self.lib.ch_train_forward(self._t, _lib.ptr(images), 0 if images.dtype == torch.float32 else 1, B,
                                                  _lib.ptr(ct), _lib.ptr(hf), _lib.ptr(cls), _lib.ptr(attn), _lib.stream_ptr()),
                        "ch_train_forward")
@@ -167,9 +172,10 @@ class EncoderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, concept_tokens, images, engine: TrainEngine, anchor, want_attn=False):
-        """-> hash_features [B, Q, D], or (hash_features, concept_attention [B, heads, Q, Np]) with want_attn: the last layer's
-        attention rows of the concept tokens over the patch tokens, differentiable as well."""
-        out = engine.forward(images, concept_tokens, want_attn=want_attn)
+        """-> hash_features [B, Q, D], or (hash_features, concept_attention) with want_attn: the attention rows of the concept tokens
+        over the patch tokens -- the last layer's [B, heads, Q, Np] (True) or every layer's [L, B, heads, Q, Np] ("all") --
+        differentiable as well."""
+        out = engine.forward(images, concept_tokens, want_attn=want_attn)     # want_attn: False | True (last layer) | "all"
         ctx.engine = engine
         ctx.generation = engine.generation
         ctx.ct_shape = concept_tokens.shape

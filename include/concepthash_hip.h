@@ -90,6 +90,13 @@ int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, f
               uint64_t *out_packed, float *out_logits_cont, float *out_logits_bin, float *out_logits_concept,
               float *out_hash_features, float *out_image_features, float *out_concept_attn, void *stream);
 
+/* Which layers' concept-token attention rows `out_concept_attn` (ch_encode, ch_train_forward) and `d_concept_attn`
+ * (ch_train_backward) carry: 0 (default) = the last layer only, [B,heads,Q,Np]; 1 = EVERY layer, [L,B,heads,Q,Np], layer l =
+ * attn_cache[l][:, :, -Q:, 1:-Q] -- what the `avg_attn` form of the attention-diversity loss averages (models/loss/coop.py:164-167,
+ * `torch.stack(outputs['attn_cache']).mean(0)`) and the per-layer visualisations read (models/arch/coop.py:481-482), without the
+ * (B, heads, N, N) maps ever being written.  Applies to trainers created on the model as well. */
+int ch_model_set_concept_attn_layers(ch_model *m, int32_t all_layers);
+
 /* Parity tap (tests only): run the encoder for `layer` layers (0 = embeddings + concept tokens + pre-LN) and copy the
  * fp32 residual stream [B*N, D], N = 1 + patches + Q, to out_hidden.  Mirrors `image_hidden_states[layer]`
  * (models/arch/coop.py:474-486). */

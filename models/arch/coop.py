@@ -107,7 +107,9 @@ class LGHWithoutText(nn.Module):
             self.trainable_params["concept_pe"] = self.concept_pe
             self.concept_ce = CosSim(D, nclass)
             self.trainable_params["concept_ce_centroids"] = self.concept_ce.centroids
-        self.return_concept_attention = bool(kwargs.get("return_concept_attention", False))
+        # False | True (the last layer's concept-token attention rows) | "all" (every layer's)
+        rca = kwargs.get("return_concept_attention", False)
+        self.return_concept_attention = "all" if rca == "all" else bool(rca)
         # reference forward always returns every layer's hidden state (`image_hidden_states`, coop.py:474-486, 582-598); nothing on
         # the encode-and-retrieve path reads them, so they are produced on request only -- by the per-layer parity tap
         # ch_encode_hidden, one partial run of the encoder per layer (L + 1 runs: for inspection, not for throughput)
@@ -211,7 +213,11 @@ class LGHWithoutText(nn.Module):
         eng.sync_versions()                                      # an optimizer step since the last forward -> re-derive working copies
         ctx = self.forward_hash_query()
         concept_attention = None
-        if self.return_concept_attention:      # the loss's attention-diversity term reads it (set by the trainer when that term is on)
+        concept_attention_layers = None
+        if self.return_concept_attention == "all":   # every layer's rows (the `avg_attn` form of the attention-diversity term)
+            hash_features, concept_attention_layers = EncoderFunction.apply(ctx, x, eng, eng.anchor, "all")
+            concept_attention = concept_attention_layers[-1]
+        elif self.return_concept_attention:      # the loss's attention-diversity term reads it (set by the trainer when that term is on)
             hash_features, concept_attention = EncoderFunction.apply(ctx, x, eng, eng.anchor, True)
         else:
             hash_features = EncoderFunction.apply(ctx, x, eng, eng.anchor)   # (B, Q, D): HIP forward, HIP backward
@@ -229,6 +235,8 @@ class LGHWithoutText(nn.Module):
             # = attn_cache[-1][:, :, -Q:, 1:-Q] of the reference (coop.py:481-482), (B, heads, Q, Np), differentiable; the full
             # per-layer (B, heads, N, N) maps are never materialised
             outputs["concept_attention"] = concept_attention
+        if concept_attention_layers is not None:     # (L, B, heads, Q, Np) = torch.stack(attn_cache)[:, :, :, -Q:, 1:-Q]
+            outputs["concept_attention_layers"] = concept_attention_layers
         # image_features (pooled CLS -> post-LN -> projection, reference :498-501) feeds no term of the shipped loss
         # (loss_scales.logits = 0): not computed in training mode
         return None, outputs
@@ -260,6 +268,8 @@ class LGHWithoutText(nn.Module):
         want = ["codes", "logits_cont", "logits_bin", "hash_features"]
         if self.return_concept_attention:
             want.append("concept_attn")
+        if self.return_concept_attention == "all":
+            want.append("concept_attn_layers")
         if self.concept_reg:
             want.append("logits_concept")
         if eng.has_pooled:
@@ -274,6 +284,8 @@ class LGHWithoutText(nn.Module):
         if self.return_concept_attention:
             # what the reference's consumers slice out of attn_cache[-1]: [:, :, -Q:, 1:-Q]  (B, heads, Q, Np)
             outputs["concept_attention"] = out["concept_attn"]
+        if self.return_concept_attention == "all":   # every layer's: torch.stack(attn_cache)[:, :, :, -Q:, 1:-Q]  (L, B, heads, Q, Np)
+            outputs["concept_attention_layers"] = out["concept_attn_layers"]
         if self.concept_reg:
             outputs["logits_concept"] = out["logits_concept"]
         return out.get("image_features"), outputs

@@ -5,8 +5,9 @@ The reference's trainer calls the criterion during inference to fill the loss/ac
 (`bin_logits`, `cont_logits`, `concept_logits`: margin-cosine cross-entropy with `scale`/`margin`; plus the `quan`
 diagnostic) on the small (B, C) logits the HIP head produces.  It is a few KB per batch; plain torch ops, differentiable (the training step, trainers/coop.py train_one_batch, backpropagates
 through it into the HIP encoder's backward).  `hash_logits` (mixture of
-softmaxes) is included for completeness; `attn_div_loss` reads the last layer's concept-token attention rows
-(`outputs['concept_attention']`, tapped from the fused attention kernel and differentiable through `ch_train_backward`).
+softmaxes) is included for completeness; `attn_div_loss` reads the concept tokens' attention rows -- the last layer's
+(`outputs['concept_attention']`) or, with `avg_attn`, every layer's (`outputs['concept_attention_layers']`) -- tapped from the fused
+attention kernel and differentiable through `ch_train_backward`.
 """
 from __future__ import annotations
 
@@ -22,9 +23,9 @@ class LGHLoss(nn.Module):
         self.scale, self.margin, self.lmbd = scale, margin, lmbd
         self.loss_scales = dict(loss_scales) if loss_scales is not None else {
             "logits": 1, "hash_logits": 1, "bin_logits": 1, "cont_logits": 1, "concept_logits": 0, "attn_div_loss": 0}
-        if self.loss_scales.get("attn_div_loss", 0) and (kwargs.get("avg_attn") or kwargs.get("nregs")):
-            raise NotImplementedError("attn_div_loss with avg_attn / nregs needs every layer's full attention maps; the MI355X path emits "
-                                      "the last layer's concept-token rows only (outputs['concept_attention'])")
+        if kwargs.get("nregs"):
+            raise NotImplementedError("nregs != 0 (register tokens) is not built: the model has none")
+        self.avg_attn = bool(kwargs.get("avg_attn", False))   # reference :164-167: the layer mean of the attention maps instead of the last
         self.div_method, self.div_min = div_method, float(kwargs.get("div_min", 0))
         if exponential_scale:
             raise NotImplementedError("exponential_scale != 0 is not built")
@@ -97,10 +98,14 @@ class LGHLoss(nn.Module):
             # reference :161-187 on attn_cache[-1][:, :, -Q:, 1:-Q], which this path hands over directly as
             # outputs["concept_attention"] (B, heads, Q, Np): head mean, l2 over the patches, pairwise cosine between the Q concept
             # tokens, (div_method 0: relu(cos - div_min)), batch mean, mean of the strict upper triangle
-            if outputs.get("concept_attention") is None:
-                raise RuntimeError("attn_div_loss needs outputs['concept_attention']: set model.return_concept_attention = True "
-                                   "(COOPTrainer does it when the term is enabled)")
-            a = F.normalize(outputs["concept_attention"].mean(dim=1), dim=-1, p=2)
+            key = "concept_attention_layers" if self.avg_attn else "concept_attention"
+            if outputs.get(key) is None:
+                want = '"all"' if self.avg_attn else "True"
+                raise RuntimeError(f"attn_div_loss needs outputs['{key}']: set model.return_concept_attention = {want} "
+                                   f"(COOPTrainer does it when the term is enabled)")
+            # avg_attn: torch.stack(attn_cache).mean(0) sliced to the concept rows == the layer mean of every layer's concept rows
+            att = outputs[key].mean(dim=0) if self.avg_attn else outputs[key]
+            a = F.normalize(att.mean(dim=1), dim=-1, p=2)
             cos = a @ a.transpose(1, 2)
             if self.div_method == 0:
                 cos = (cos - self.div_min).relu()

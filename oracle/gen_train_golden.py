@@ -118,6 +118,28 @@ def main():
     with torch.no_grad():
         model.hash_bn.running_mean.copy_(rm)
         model.hash_bn.running_var.copy_(rv)
+    # ---- and with `avg_attn: True` (models/loss/coop.py:164-167): the loss averages EVERY layer's attention map before slicing out the
+    # concept tokens' rows, so its gradient enters the attention of every layer.  `attnavg/concept_attention_layers` =
+    # torch.stack(attn_cache)[:, :, :, -Q:, 1:-Q]  (L, B, heads, Q, Np)
+    model.zero_grad()
+    crit3 = LGHLoss(margin=0.2, scale=8, loss_scales=dict(logits=0, hash_logits=0, bin_logits=1, cont_logits=1, l2=0, attn_div_loss=25,
+                                                          concept_logits=1), avg_before_softmax=False, lmbd=0.5, div_method=1, ncontext=4,
+                    avg_attn=True)
+    feats3, out3 = model(x)
+    loss3 = crit3(out3, labels)
+    loss3.backward()
+    payload["attnavg/loss"] = loss3.detach().numpy()
+    payload["attnavg/loss_attn_div"] = crit3.losses["attn_div"].detach().numpy()
+    payload["attnavg/concept_attention_layers"] = torch.stack(out3["attn_cache"], dim=0)[:, :, :, -4:, 1:-4].detach().numpy()
+    for k, p in named.items():
+        if k.startswith(("adapter_params.", "trainable_params.")) or p.grad is None:
+            continue
+        if ".adapt_mlp_" in k or k.startswith("hash_attention."):
+            payload["attnavggrad/" + k] = p.grad.detach().numpy()
+    payload["attnavggrad/hash_queries"] = model.hash_queries.grad.detach().numpy()
+    with torch.no_grad():
+        model.hash_bn.running_mean.copy_(rm)
+        model.hash_bn.running_var.copy_(rv)
     # BatchNorm running statistics after the step (momentum 0.1)
     payload["out/bn_running_mean"] = bn_after[0]
     payload["out/bn_running_var"] = bn_after[1]

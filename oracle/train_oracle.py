@@ -67,9 +67,10 @@ def forward_train(sd: Dict[str, torch.Tensor], images, heads, upt_heads=8, act="
     x = eo.embeddings(sd, images, R)
     x = torch.cat([x, ctx.expand(x.shape[0], -1, -1)], dim=1)
     h = eo.layer_norm(x, sd[VM + "pre_layrnorm.weight"].float(), sd[VM + "pre_layrnorm.bias"].float())
-    probs = None
+    probs, rows = None, []
     for i in range(dims["L"]):
-        h, probs = eo.encoder_layer(sd, i, h, heads, R, act, want_probs=(i == dims["L"] - 1))
+        h, probs = eo.encoder_layer(sd, i, h, heads, R, act, want_probs=True)
+        rows.append(probs[:, :, -Q:, 1:-Q])
     hf = h[:, -Q:, :]
     B = hf.shape[0]
     v = ((hf + sd["hash_pe"].float()) @ sd["hash_fc.weight"].float().t()).reshape(B, -1)
@@ -78,6 +79,7 @@ def forward_train(sd: Dict[str, torch.Tensor], images, heads, upt_heads=8, act="
     lc, lb = eo.center_logits(sd, codes)
     return dict(codes=codes, hash_features=hf, logits_cont=lc, logits_bin=lb, logits_concept=eo.concept_logits(sd, hf),
                 concept_attention=probs[:, :, -Q:, 1:-Q],       # attn_cache[-1][:, :, -Q:, 1:-Q] (coop.py:481-482)
+                concept_attention_layers=torch.stack(rows, dim=0),   # torch.stack(attn_cache)[:, :, :, -Q:, 1:-Q]  (L, B, heads, Q, Np)
                 bn_batch_mean=mean.detach(), bn_batch_var_unbiased=v.var(0, unbiased=True).detach(), concept_tokens=ctx)
 
 
@@ -94,7 +96,7 @@ def attn_div(concept_attention, div_method=1, div_min=0.0):
 
 
 def train_step_grads(sd, images, labels, heads, upt_heads=8, act="quick_gelu", scale=8.0, margin=0.2, attn_div_scale=0.0,
-                     div_method=1) -> dict:
+                     div_method=1, avg_attn=False) -> dict:
     """loss terms + gradient of every trainable tensor for one batch (labels: int64 class indices)."""
     sd = {k: v.clone() for k, v in sd.items()}
     keys = trainable_keys(sd)
@@ -106,7 +108,8 @@ def train_step_grads(sd, images, labels, heads, upt_heads=8, act="quick_gelu", s
                   bin=margin_ce(out["logits_bin"], labels, scale, margin))
     total = losses["concept"] + losses["cont"] + losses["bin"]
     if attn_div_scale:
-        losses["attn_div"] = attn_div(out["concept_attention"], div_method)
+        # avg_attn (models/loss/coop.py:164-167): the layer mean of the maps, then the concept rows == the layer mean of the rows
+        losses["attn_div"] = attn_div(out["concept_attention_layers"].mean(dim=0) if avg_attn else out["concept_attention"], div_method)
         total = total + attn_div_scale * losses["attn_div"]
     total.backward()
     return dict(loss=total.detach(), losses={k: v.detach() for k, v in losses.items()},

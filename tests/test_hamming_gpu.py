@@ -520,3 +520,39 @@ def test_record_form_equals_two_scan_form_and_survives_overflow(dev, nbit):
         got = rt.evaluate(_t(q, dev), _t(g, dev), _t(qlab, dev), _t(glab, dev), R=-1, ks=(1, 5, 10), **kw)
         assert np.array_equal(got["S"].cpu().numpy().view(np.uint64), ref["S"]), kw
         assert np.array_equal(got["nrel"].cpu().numpy().astype(np.uint32), ref["nrel"]), kw
+
+
+def test_evaluate_picks_the_two_scan_form_where_the_lists_would_overflow(dev, monkeypatch):
+    """evaluate() left to its defaults predicts -- exactly, from the labels -- in how many (query tile, segment) workgroups a record
+    list would overflow, and runs two scans where most would (a gallery listed class by class under shuffled queries: every list of
+    the class's segment overflows; the one-scan form then pays its recording scan AND the redo).  The choice never changes a bit."""
+    from concepthash_amd import retrieval as rt
+    monkeypatch.setattr(rt, "OVERFLOW_MIN_PAIRS", 1)            # predict at this test's size too
+    gen = torch.Generator(device=dev).manual_seed(3)
+    Qn, G, ncls = 2048, 120_000, 12
+    q = torch.randint(-2 ** 63, 2 ** 63 - 1, (Qn, 2), dtype=torch.int64, device=dev, generator=gen)
+    g = torch.randint(-2 ** 63, 2 ** 63 - 1, (G, 2), dtype=torch.int64, device=dev, generator=gen)
+    ql = torch.randint(0, ncls, (Qn,), dtype=torch.int32, device=dev, generator=gen)
+    gl_sorted = (torch.arange(G, device=dev) * ncls // G).to(torch.int32)
+    gl_shuffled = gl_sorted[torch.randperm(G, device=dev, generator=gen)]
+    seg = rt.map_seg_rows(Qn, G, 2)
+    cap = rt.record_cap(Qn, G, 2, seg)
+    f_sorted, f_shuffled = rt.predicted_overflow(ql, gl_sorted, 2, seg, cap), rt.predicted_overflow(ql, gl_shuffled, 2, seg, cap)
+    print(f"segments of {seg} rows, list capacity {cap}: predicted overflowing workgroups {f_sorted:.2f} (class-sorted gallery), "
+          f"{f_shuffled:.2f} (shuffled)")
+    assert f_sorted > 0.9 and f_shuffled == 0.0
+    calls = []
+    real = rt.hamming_hist_rec
+    monkeypatch.setattr(rt, "hamming_hist_rec", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    ev_sorted = rt.evaluate(q, g, ql, gl_sorted)
+    assert not calls                                            # two scans
+    ev_shuffled = rt.evaluate(q, g, ql, gl_shuffled)
+    assert calls == [1]                                         # one scan
+    # the prediction is exact: the recording scan really overflows (almost) everywhere on the sorted listing, nowhere on the other
+    _, (_, _, _, flags) = real(q, g, ql, gl_sorted, 0, seg)
+    assert abs(float(flags.float().mean()) - f_sorted) < 1e-6
+    _, (_, _, _, flags) = real(q, g, ql, gl_shuffled, 0, seg)
+    assert int(flags.sum()) == 0
+    for ev, gl in ((ev_sorted, gl_sorted), (ev_shuffled, gl_shuffled)):
+        forced = rt.evaluate(q, g, ql, gl, records=True)
+        assert torch.equal(ev["S"], forced["S"]) and torch.equal(ev["nrel"], forced["nrel"])

@@ -175,6 +175,30 @@ def test_attention_diversity_term_matches_reference():
     assert changed >= 10
 
 
+def test_attention_diversity_term_with_avg_attn_matches_reference():
+    """train_tiny `attnavg/*`: the reference's loss with `avg_attn: True` (models/loss/coop.py:164-167) averages EVERY layer's
+    attention map; `attnavg/concept_attention_layers` is torch.stack(attn_cache)[:, :, :, -Q:, 1:-Q] of the reference's own forward."""
+    from oracle import train_oracle as to
+    sd, z = load_fixture("train_tiny")
+    x = fixture_images(z)
+    labels = torch.from_numpy(z["in/labels"])
+    res = to.train_step_grads(sd, x, labels, heads=int(z["meta/heads"]), upt_heads=8, act=str(z["meta/act"]), attn_div_scale=25.0,
+                              avg_attn=True)
+    rows = torch.from_numpy(z["attnavg/concept_attention_layers"])
+    assert rows.shape[0] == 2 and torch.allclose(res["out"]["concept_attention_layers"], rows, atol=2e-6)
+    assert torch.equal(rows[-1], torch.from_numpy(z["attn/concept_attention"]))
+    assert abs(float(res["losses"]["attn_div"]) - float(z["attnavg/loss_attn_div"])) < 2e-6
+    assert abs(float(res["loss"]) - float(z["attnavg/loss"])) < 3e-5
+    assert abs(float(z["attnavg/loss_attn_div"]) - float(z["attn/loss_attn_div"])) > 1e-4      # a different term from the last-layer one
+    keys = [k[12:] for k in z.files if k.startswith("attnavggrad/")]
+    assert len(keys) == 28 + 14 + 1
+    for k in keys:
+        ref = torch.from_numpy(z["attnavggrad/" + k])
+        got = res["grads"][k]
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 5e-5 + 2e-3 * scale, (k, float((got - ref).abs().max()), scale)
+
+
 @pytest.mark.parametrize("config", ["vit_b16", "vit_s16", "vit_l14"])
 def test_full_size_seeded_fixtures_pin_the_oracle(config):
     """tests/golden/seeded_<config>.npz: the reference's own model at the BASELINE.json model sizes (ViT-B/16 x 12 layers, 201 tokens;

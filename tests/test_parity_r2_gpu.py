@@ -183,7 +183,8 @@ def test_map_delta_and_bit_flip_rate_against_fp32_oracle_codes(dev):
          gallery's fp32 hash features -- what training does to the head).  mAP ~ 1: asserted |delta mAP@all| < 1e-3.
       B  moderate margin: noisier classes, fitted head, mAP ~ 0.85-0.9 (the range of the paper's CUB numbers).  The linear
          probe's codes are unimodal around zero (1.4 % of them within 2 % of zero -- a trained model's quantisation loss,
-         models/loss/coop.py, empties exactly that region), so this OVERSTATES a trained model's flips: reported, bounded.
+         models/loss/coop.py, empties exactly that region), so this OVERSTATES a trained model's flips: reported, bounded at
+         twice the measured value (3e-3).  The TRAINED head on the same noisy classes is tests/test_parity_r3_gpu.py.
       C  the untrained random head on the same images: near-chance ranking, the worst case: reported, bounded.
     Every flipped bit has |fp32 code| below the measured code error (checked), i.e. no bit flips for any other reason."""
     from oracle import encoder_oracle as eo
@@ -249,9 +250,9 @@ def test_map_delta_and_bit_flip_rate_against_fp32_oracle_codes(dev):
     # ---- B, C: moderate margin / untrained head on 512 noisier images
     x, labels, hf = dataset(32, (0.5, 0.87), 2025)
     d, m, rate, e = measure("B fitted head, noisy classes", fitted_head(hf, labels, 128), x, labels, hf, 128)
-    assert 0.6 < m < 0.99 and d < 2.5e-2 and rate < 1e-2 and e < 0.15
+    assert 0.6 < m < 0.99 and d < 3e-3 and rate < 1e-2 and e < 0.15      # measured 1.5e-3 (round 2): bound = 2x, not 17x
     d, m, rate, e = measure("C random head, noisy classes", sd, x, labels, hf, 128)
-    assert 1.0 / ncls < m < 1.0 and d < 2e-2 and rate < 5e-3 and e < 4e-2
+    assert 1.0 / ncls < m < 1.0 and d < 6e-3 and rate < 5e-3 and e < 4e-2  # measured 2.8e-3 (round 2): bound = 2x
 
 
 # ---- (f) ---------------------------------------------------------------------------------------------------------

@@ -8,7 +8,8 @@ groups the same dispatch rows by (short kernel name, grid work-items, workgroup 
     python tools/kernel_stats_by_shape.py <*_kernel_trace.csv> [--bench <bench.json>] [--skip-before <kernel substring>] > by_shape.csv
 
 --bench: the JSON line the traced `bench.py` run printed.  Appends, for every `roofline_per_kernel` row of it, the agreement check
-the profile has to pass: CSV average duration x launches per step against the bench's own `ms_per_step` (HIP events), in percent.
+the profile has to pass: CSV average duration x launches per step against the bench's own `ms_per_step` (HIP events), in percent
+(rows within EVENT_US microseconds per launch of each other pass whatever their ratio: see EVENT_US).
 Launches of the model build / warm-up that use other grids simply show up as rows of their own.
 """
 import argparse
@@ -17,6 +18,13 @@ import json
 import re
 import sys
 from collections import defaultdict
+
+
+# The bench brackets every GEMM / attention dispatch with the start / stop events of hipExtLaunchKernelGGL.  Their timestamps sit
+# on the command processor's side of the dispatch and read 0.3-3.2 us longer than rocprofv3's begin -> end of the kernel itself
+# (measured: +3.0 us on 53-111 us launches, +0.3-1.4 us on 200-270 us ones), so two figures agree when they are within 3 % OR
+# within this many microseconds per launch.
+EVENT_US = 3.5
 
 
 def short_name(k: str) -> str:
@@ -70,12 +78,13 @@ def main():
             avg = sum(rows[key]) / len(rows[key])
             ms = avg * r["launches_per_step"] * 1e-3
             d = 100.0 * (ms - r["ms_per_step"]) / r["ms_per_step"]
-            worst = max(worst, abs(d))
+            if abs(avg - r["avg_launch_us"]) > EVENT_US:       # beyond what the start / stop events themselves add to a launch
+                worst = max(worst, abs(d))
             w.writerow([r["rocprof_name"], r["grid"], r["launches_per_step"], round(avg, 2), r["avg_launch_us"], round(ms, 3),
                         r["ms_per_step"], round(d, 2)])
-        print(f"# worst |delta| {worst:.2f} % (bound: 3 %)")
+        print(f"# worst |delta| {worst:.2f} % of the rows that exceed {EVENT_US} us per launch in absolute terms (bound: 3 %)")
         if worst > 3.0:
-            sys.exit(f"kernel_stats_by_shape: rocprofv3 and the bench's HIP events disagree by {worst:.2f} % (> 3 %)")
+            sys.exit(f"kernel_stats_by_shape: rocprofv3 and the bench's HIP events disagree by {worst:.2f} % (> 3 % and > {EVENT_US} us per launch)")
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ class COOPTrainer(BaseTrainer):
         exactly when that term is on (reference models/loss/coop.py:161-187 reads outputs['attn_cache'])."""
         if self.model is not None and self.criterion is not None and hasattr(self.model, "return_concept_attention"):
             if getattr(self.criterion, "loss_scales", {}).get("attn_div_loss", 0):
-                self.model.return_concept_attention = True
+                self.model.return_concept_attention = "all" if getattr(self.criterion, "avg_attn", False) else True
 
     def load_dataset(self, load_db=True):
         ds = self.config.dataset
