@@ -170,6 +170,8 @@ struct HeadParams {
     float *out_logits_concept; // [Q, B, C] or nullptr
     float *out_hash_features;  // [B, Q, D] or nullptr
     float *out_image_features; // [B, P] or nullptr
+    float *ws_xn;              // workspace [B*Q, D]: l2(hash_features + concept_pe), left operand of the concept logits (head_dense_kernel)
+    float *ws_cls;             // workspace [B, D]: post_layernorm(CLS), left operand of the image features
 };
 int ch_head(const HeadParams &p, hipStream_t s);
 int ch_pack_sign_launch(const float *codes, int64_t rows, int nbit, float thr, uint64_t *out, hipStream_t s);

@@ -324,6 +324,8 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
         CH_CHECK_HIP(hipMemset(m->splitk_cnt[i], 0, CH_SPLITK_CNT_BYTES));
     }
     m->Hc = (float *)B.alloc(sizeof(float) * ((size_t)c.max_batch * (1 + c.ncontext) + 512) * D);
+    m->head_xn = (float *)B.alloc(sizeof(float) * ((size_t)c.max_batch * c.ncontext + 16) * D);
+    m->head_cls = (float *)B.alloc(sizeof(float) * ((size_t)c.max_batch + 16) * D);
     m->statsA = (float *)B.alloc(sizeof(float) * rows * (D / 64) * 2);
     m->statsH = (float *)B.alloc(sizeof(float) * rows * (D / 64) * 2);
     m->QKV = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * 3 * D);
@@ -685,6 +687,7 @@ extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, i
     p.out_codes = out_codes; p.out_packed = out_packed; p.out_logits_cont = out_logits_cont;
     p.out_logits_bin = out_logits_bin; p.out_logits_concept = out_logits_concept;
     p.out_hash_features = out_hash_features; p.out_image_features = out_image_features;
+    p.ws_xn = m->head_xn; p.ws_cls = m->head_cls;
     mark(m, 0, CH_CAT_HEAD, 2.0 * B * (double)c.dim * c.nbit, s);
     if (int e = ch_head(p, s)) return e;
     mark(m, 0, CH_CAT_END, 0.0, s);

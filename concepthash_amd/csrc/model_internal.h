@@ -80,6 +80,7 @@ struct ch_model {
     int small_kernel = 0;  // CH_GEMM_SMALL at creation: 2 = 128x128x32 four-stage ring, experiments build only (0 = dispatcher default)
     int pp_min_k = 0;  // CH_GEMM_PP_MIN_K at creation (tests: sends small-K GEMMs of a small fixture to the 256x256 kernel)
     float *Hc = nullptr;
+    float *head_xn = nullptr, *head_cls = nullptr;  // head.hip: left operands of the two dense optional outputs
     float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn
     bf16_t *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *A = nullptr, *AD = nullptr, *F1 = nullptr, *PATCH = nullptr;
 };
