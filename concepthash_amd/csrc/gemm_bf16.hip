@@ -215,6 +215,11 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
         q.pp_sched = 1;
         return ch_gemm_bf16_pp(q, epi, s);
     }
+    if (g_gemm_variant == 8) {  // 256x256 kernel, free tail
+        GemmParams q = p;
+        q.pp_sched = 2;
+        return ch_gemm_bf16_pp(q, epi, s);
+    }
     if (g_gemm_variant == 3) return ch_gemm_bf16_dp(p, epi, s);
     // Short-K GEMMs (the adapter up-projection, K = 384) are epilogue/HBM bound: two 128x128 workgroups per CU overlap one's
     // read-modify-write epilogue with the other's K loop and win there (measured: 152 -> 97 us per launch in the pipeline);

@@ -51,6 +51,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
         __builtin_amdgcn_s_barrier();      \
         __builtin_amdgcn_sched_barrier(0); \
     } while (0)
+// SCHED 2 (free tail): the barriers of the LAST K-tile's four phases are skipped (see the block in front of the K loop)
+#define PP_BARRIER_T()                     \
+    do {                                   \
+        if (!free_tail || more) PP_BARRIER(); \
+    } while (0)
 #define PP_WAIT_LGKM0()                                       \
     do {                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     const int J = split ? (nk >> 1) / p.split_s : (nk >> 1);  // iterations (pairs of K-tiles) of this block
     const int j0 = slice * J;
     const int kb0 = 2 * j0;  // first K-tile (even, so the buffer parity of the schedule is unchanged)
+    const bool free_tail = SCHED == 2 && ch_epi::traits<EPI>::bf16_only && !split;  // workgroup-uniform
 
     if constexpr (SCHED == 1) {
         // ---- coarse schedule: per K-tile kt (buffer b = kt & 1) two phases of 32 MFMAs
@@ -289,6 +295,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
         if constexpr (DBG & 8) stamp[2] = __builtin_amdgcn_s_memtime();
         if (wr == 1) PP_BARRIER();  // stagger: waves 4-7 run one barrier behind waves 0-3
 
+        // ---- SCHED 2, "free tail" (bf16-output epilogues, no split): in the block's last K-tile nothing is staged any more and every
+        // byte of the odd buffer landed behind phase 4's vmcnt(0) + barrier, so its four phases need no barrier for any hazard --
+        // the barriers only keep the ping-pong cadence.  Here they are dropped: waves 0-3 take their balancing barrier right after
+        // phase 4 (waves 4-7 meet it as their phase-4 closing barrier), then every wave runs phases 5-8 and its epilogue at its own
+        // pace.  The epilogue stages through the EVEN buffer (last read in phase 3, i.e. >= 2 barriers ago for every wave; 8 KB per
+        // wave, two passes of 64 rows), so a wave that is done starts storing while its SIMD partner still issues MFMAs.
         for (int jj = 0; jj < J; ++jj) {
             const bool more = (jj + 1 < J);  // K-tiles ke+2 / ke+3 belong to this block
             const int ke = 2 * (j0 + jj), ko = ke + 1;
@@ -325,39 +337,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
             PP_BARRIER();
             PP_MFMA(Wa, 0, 1);
             PP_BARRIER();
+            if (free_tail && !more && wr == 0) PP_BARRIER();  // the balancing barrier of the stagger, taken early
             // ================= odd buffer, K-tile ko =================
             // phase 5
             read_w(Wa, 1, 0);
             read_x(1, 0);
             if (more) issue(1, ke + 2);
             PP_WAIT_LGKM0();
-            PP_BARRIER();
+            PP_BARRIER_T();
             PP_MFMA(Wa, 0, 0);
-            PP_BARRIER();
+            PP_BARRIER_T();
             // phase 6
             read_w(Wbf, 1, 1);
             if (more) issue(0, ko + 2);
             PP_WAIT_LGKM0();
-            PP_BARRIER();
+            PP_BARRIER_T();
             PP_MFMA(Wbf, 1, 0);
-            PP_BARRIER();
+            PP_BARRIER_T();
             // phase 7
             read_x(1, 1);
             if (more) issue(2, ko + 2);
             PP_WAIT_LGKM0();
-            PP_BARRIER();
+            PP_BARRIER_T();
             PP_MFMA(Wbf, 1, 1);
-            PP_BARRIER();
+            PP_BARRIER_T();
             // phase 8: retire the even buffer of the next iteration (everything issued up to phase 5)
             if (more) {
                 issue(3, ko + 2);
                 PP_WAIT_VM(6);
             }
-            PP_BARRIER();
+            PP_BARRIER_T();
             PP_MFMA(Wa, 0, 1);
-            PP_BARRIER();
+            PP_BARRIER_T();
         }
-        if (wr == 0) PP_BARRIER();  // balance the stagger barrier
+        if (!free_tail && wr == 0) PP_BARRIER();  // balance the stagger barrier
     }
 
     // ---- split-K tail: publish this slice's partial tile; the LAST arriver (agent-scope ticket) sums all slices in slice
@@ -413,6 +426,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     // ---- epilogue (gemm_epilogue.h): every wave has passed the balance barrier, so no wave still reads staged operands
     // and no LDS-DMA is in flight (vmcnt(0) in the last iteration); each wave transposes through its own 16 KB.
     if constexpr (DBG & 8) stamp[3] = __builtin_amdgcn_s_memtime();
+    if constexpr (SCHED == 2 && ch_epi::traits<EPI>::bf16_only) {
+        if (free_tail) {  // no barrier behind the K loop: stage through this wave's 8 KB of the even buffer, 64 rows per pass
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                f32x4 half[4][4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) half[nt][mt] = acc[nt][pass * 4 + mt];
+                ch_epi::store_tile<EPI, 4>(p, half, smem + wid * 8192, m0 + wr * 128 + pass * 64, n0 + wc * 64, lane,
+                                           (const float *)(smem + 2 * BUF_BYTES) + 2 * (wr * 128 + pass * 64));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // pass 0 fully read back before pass 1 restages the slice
+            }
+            return;
+        }
+    }
     ch_epi::store_tile<EPI, 8>(p, acc, smem + wid * 16384, m0 + wr * 128, n0 + wc * 64, lane,
                                (const float *)(smem + 2 * BUF_BYTES) + 2 * (wr * 128));
     if constexpr (DBG & 8) {
@@ -491,6 +520,14 @@ int launch_pp(const GemmParams &p0, hipStream_t s) {
         p.split_full = tiles;
         p.split_s = 1;
         return launch_pp_sched<EPI, 1>(p, tiles, s);
+#else
+        return ch_experiments_not_built();
+#endif
+    }
+    if (p.pp_sched == 2) {  // free tail (experiment): barrier-free last K-tile, epilogue staged through the even buffer
+#ifdef CH_EXPERIMENTS
+        ch_pp_choose_split(p, tiles);
+        return launch_pp_sched<EPI, 2>(p, tiles, s);
 #else
         return ch_experiments_not_built();
 #endif

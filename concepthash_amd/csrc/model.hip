@@ -601,7 +601,7 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
     if (const char *e = getenv("CH_GEMM_SMALL")) m->small_kernel = atoi(e);
     if (const char *e = getenv("CH_SERPENTINE")) m->serpentine = atoi(e) != 0;
 #ifdef CH_EXPERIMENTS
-    if (const char *e = getenv("CH_GEMM_PP_SCHED")) m->pp_sched = atoi(e) == 1 ? 1 : 0;
+    if (const char *e = getenv("CH_GEMM_PP_SCHED")) m->pp_sched = (atoi(e) == 1 || atoi(e) == 2) ? atoi(e) : 0;
 #endif
     if (const char *e = getenv("CH_STREAMS")) m->nstreams = std::max(1, std::min(atoi(e), CH_MAX_STREAMS));
     bool aux_ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -817,8 +817,8 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
     if (int e = debug_attach_splitk(p)) return e;
     if (variant == 1) return ch_gemm_bf16_v1(p, epi, s);
     if (variant == 2) return ch_gemm_bf16_pp(p, epi, s);
-    if (variant == 4) {
-        p.pp_sched = 1;
+    if (variant == 4 || variant == 8) {
+        p.pp_sched = variant == 4 ? 1 : 2;
         return ch_gemm_bf16_pp(p, epi, s);
     }
     if (variant == 3) return ch_gemm_bf16_dp(p, epi, s);
@@ -844,9 +844,9 @@ extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_a
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
     if (variant == 7) return ch_gemm_bf16_r4(p, epi, s);
-    if (variant == 1 || variant == 2 || variant == 4) ch_gemm_set_variant(variant);
+    if (variant == 1 || variant == 2 || variant == 4 || variant == 8) ch_gemm_set_variant(variant);
     const int rc = ch_gemm_bf16(p, epi, s);
-    if (variant == 1 || variant == 2 || variant == 4) ch_gemm_set_variant(0);
+    if (variant == 1 || variant == 2 || variant == 4 || variant == 8) ch_gemm_set_variant(0);
     return rc;
 }
 extern "C" void ch_debug_set_gemm_variant(int32_t v) { ch_gemm_set_variant(v); }

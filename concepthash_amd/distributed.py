@@ -168,6 +168,9 @@ class ShardedRetrieval:
         self.counts = [int(c.item()) for c in counts]
         self.base = sum(self.counts[: self.rank])       # global index of this shard's first row
         self.total = sum(self.counts)
+        # CH_FORCE_COLLECTIVES=1: run every collective also in a one-rank group (they are then identities) -- lets a single GPU
+        # exercise the RCCL backend with this module's dtypes and shapes (tests/test_parity_r3_gpu.py)
+        self.coll = self.world > 1 or os.environ.get("CH_FORCE_COLLECTIVES") == "1"
 
     # ---- queries -------------------------------------------------------------------------------------------------
     def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
@@ -179,7 +182,7 @@ class ShardedRetrieval:
     def topk(self, q_all: torch.Tensor, k: int):
         """q_all: the SAME [Qn, W] on every rank.  Returns the global (idx int64 [Qn,k], dist int32 [Qn,k]) on every rank."""
         idx, dst = self.ops.hamming_topk(q_all, self.gallery, k, g_index_base=self.base)
-        if self.world == 1:
+        if not self.coll:
             return idx, dst
         li = _all_gather_rows(idx.unsqueeze(0), self.group)   # [world, Qn, k]
         ld = _all_gather_rows(dst.unsqueeze(0), self.group)
@@ -199,7 +202,7 @@ class ShardedRetrieval:
         # one-hot rows -> class ids only if EVERY shard's rows (and the queries) are single-label: the ranks must agree on the form
         single = None
         ql, gl = q_labels.to(dev), self.labels.to(dev)
-        if self.world > 1 and ql.dim() == 2 and gl.dim() == 2 and hasattr(ops, "labels_single"):
+        if self.coll and ql.dim() == 2 and gl.dim() == 2 and hasattr(ops, "labels_single"):
             flag = torch.tensor([1 if ops.labels_single(ql, gl) else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             single = bool(flag.item())
@@ -212,7 +215,7 @@ class ShardedRetrieval:
         first_rel = None
         if remove_first:      # relevance of the global rank-1 row of every query
             idx, _ = self.topk(q_all, 1)
-            g_lab_all, _ = _all_gather_ragged(g_lab, self.group) if self.world > 1 else (g_lab, None)
+            g_lab_all, _ = _all_gather_ragged(g_lab, self.group) if self.coll else (g_lab, None)
             safe = idx.clamp_min(0)
             if LW == 0:
                 rel = (g_lab_all[safe] == q_lab[:, None]) & (idx >= 0)
@@ -233,7 +236,7 @@ class ShardedRetrieval:
             hist, recs = ops.hamming_hist_rec(q_all, self.gallery, q_lab, g_lab, LW, seg)
         else:
             hist = ops.hamming_hist(q_all, self.gallery, q_lab, g_lab, LW, seg)        # [nseg_local, Qn, nb, 2]
-        if self.world > 1:
+        if self.coll:
             # "ranked before" bases of THIS shard's segments need, per (query, bucket), the rows of all lower buckets anywhere plus
             # the same bucket's rows in earlier shards and earlier local segments: only per-SHARD totals travel ([Qn, nb, 2] per
             # rank -- 17 MB at 16,384 queries x 128 bit -- instead of every segment's histogram, 16x that at the 1M-row size), and
@@ -251,7 +254,7 @@ class ShardedRetrieval:
             S, nrel = ops.hamming_ap_rec(q_all, self.gallery, q_lab, g_lab, LW, seg, base, recs, limits, first_rel=first_rel)
         else:
             S, nrel = ops.hamming_ap_multi(q_all, self.gallery, q_lab, g_lab, LW, seg, base, limits, first_rel=first_rel)
-        if self.world > 1:
+        if self.coll:
             dist.all_reduce(S, op=dist.ReduceOp.SUM, group=self.group)       # int64 wrap-around sum == uint64 sum
             dist.all_reduce(nrel, op=dist.ReduceOp.SUM, group=self.group)
         total = totals[:, 1].clone()

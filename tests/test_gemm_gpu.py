@@ -224,6 +224,40 @@ def test_statistics_producers(variant, M, N, K):
     assert bool(torch.isnan(stats[M:]).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(51456, 768, 768), (4096, 2304, 768), (3000, 3072, 768), (2500, 768, 3072), (700, 256, 128), (515, 512, 256)])
+def test_free_tail_schedule_is_bit_identical_and_race_free(M, N, K):
+    """gemm_pp_kernel<EPI, 0, 2> (variant 8 of the taps, experiments build): the last K-tile's phases run without barriers and the
+    epilogue stages through the even operand buffer in two 64-row passes, so that a wave that is done stores while its SIMD
+    partner still issues MFMAs.  Same MFMA order: bit-identical to the dispatched schedule for every bf16-output epilogue --
+    plain, quick_gelu, with row statistics, LayerNorm-folded -- with L2 / MALL warm and evicted, K = 128 (a single iteration)
+    included."""
+    _need_experiments()
+    X, W, bias, _ = _inputs(M, N, K, seed=9)
+    junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    Mp = X.shape[0]
+    stats = torch.zeros(Mp, K // 64, 2, device="cuda")
+    stats[:M] = _slice_stats(X, M).float()
+    fold_c = torch.randn(N, device="cuda")
+    for epi in (EPI_BIAS, 1, EPI_BIAS_STATS, 9):
+        outs = []
+        for variant, it in ((2, 0), (8, 0), (8, 1), (8, 2), (8, 3)):
+            out = torch.full((Mp, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            st = torch.zeros(Mp, N // 64, 2, device="cuda")
+            if it % 2:
+                junk.fill_(float(it))
+            if epi in (EPI_BIAS_STATS, 9):
+                if epi == 9 and K > 1280:
+                    break
+                _gemm_ln(variant, X, W, bias, M, epi, out=out, stats_in=stats, fold_c=fold_c, eps=1e-5, stats_out=st)
+            else:
+                _gemm(variant, X, W, bias, M, epi, out=out)
+            torch.cuda.synchronize()
+            outs.append((out, st))
+        for out, st in outs[1:]:
+            assert torch.equal(out[:M].view(torch.int16), outs[0][0][:M].view(torch.int16)), (epi, M, N, K)
+            assert torch.equal(st[:M], outs[0][1][:M]), (epi, M, N, K)
+
+
 @pytest.mark.parametrize("variant", [1, 2, 4, 7])
 @pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (700, 3072, 768), (515, 384, 768), (300, 256, 128), (257, 512, 1280)])
 def test_layernorm_folded_consumers(variant, M, N, K):

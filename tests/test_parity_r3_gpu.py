@@ -23,27 +23,31 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_map_delta_on_a_head_trained_with_the_reference_loss(dev):
-    """ViT-B/16 x 12 layers, 64 bit, 16 classes of class-structured synthetic images (prototype + noise, the NOISY mix of regime B
-    of tests/test_parity_r2_gpu.py): 300 SGD steps of batch 128 through ch_train_forward / ch_train_backward with the reference's
-    LGHLoss (concept + cont + bin margin-cosine terms, scale 8, margin 0.2); then the held-out queries / gallery encoded by the HIP
-    path and by the fp32 oracle FROM THE SAME CHECKPOINT, mAP@all of both from the integer oracle.
-    Asserted: the north-star bound |delta mAP@all| < 1e-3; every flipped bit has a |fp32 code| inside the measured encode error;
-    training moved the loss and the quantisation term (so the codes are a trained model's, not a random head's)."""
+@pytest.mark.parametrize("mix,map_range", [((0.5, 0.87), (0.99, 1.0)), ((0.2, 0.98), (0.85, 0.995))])
+def test_map_delta_on_a_head_trained_with_the_reference_loss(dev, mix, map_range):
+    """ViT-B/16 x 12 layers, 64 bit, 16 classes of class-structured synthetic images (prototype + noise): 300 SGD steps of batch 128
+    through ch_train_forward / ch_train_backward with the reference's LGHLoss (concept + cont + bin margin-cosine terms, scale 8,
+    margin 0.2); then the held-out queries / gallery encoded by the HIP path and by the fp32 oracle FROM THE SAME CHECKPOINT, mAP@all
+    of both from the integer oracle.  Two image mixes: the noisy mix of regime B of tests/test_parity_r2_gpu.py (the trained model
+    separates it completely: mAP 1.000) and prototypes at a fifth of the noise amplitude (trained mAP ~0.95, the range of the
+    paper's CUB numbers).  Asserted: the north-star bound |delta mAP@all| < 1e-3; every flipped bit has a |fp32 code| inside the
+    measured encode error; training moved the loss and the quantisation term (the codes are a trained model's, not a random
+    head's).  Measured (profiles/r03_trained_head_map.txt): delta 0 / 3.7e-4, bit-flip rate 1.2e-4 / 2.8e-4 -- against 4.1e-3 for
+    the fitted linear probe of regime B; the under-trained third regime of that file (mAP 0.70) is reported there, not asserted."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import trained_head_map as thm
-    r = thm.run(dev, steps=300, batch=128, per_eval=24, mix=(0.5, 0.87))
-    print(f"trained head: loss {r['loss_first']:.3f} -> {r['loss_last']:.3f}; quantisation term {r['quan_first']:.4f} -> {r['quan_last']:.4f}; "
-          f"{r['train_seconds']:.1f} s of training, {r['oracle_seconds']:.1f} s of fp32 oracle")
+    r = thm.run(dev, steps=300, batch=128, per_eval=24, mix=mix)
+    print(f"trained head, mix {mix}: loss {r['loss_first']:.3f} -> {r['loss_last']:.3f}; quantisation term {r['quan_first']:.4f} -> "
+          f"{r['quan_last']:.4f}; {r['train_seconds']:.1f} s of training, {r['oracle_seconds']:.1f} s of fp32 oracle")
     print(f"mAP@all HIP {r['mAP_hip']:.6f} vs fp32 oracle {r['mAP_fp32']:.6f}: |delta| {r['delta']:.2e}; bit flips {r['flips']} / {r['bits']} "
           f"= {r['flip_rate']:.3e}; codes max err / rms {r['err_max_over_rms']:.2e} (rms err / rms {r['err_rms_over_rms']:.2e}); largest "
           f"|fp32 code| / rms among flipped bits {r['flipped_max_abs_over_rms']:.2e}")
     print("fraction of fp32 codes with |code| < f x rms: " + ", ".join(f"f={b}: {v:.2e}" for b, v in r["near_zero"].items()))
     assert r["loss_last"] < r["loss_first"] - 1.0 and r["quan_last"] < r["quan_first"]
-    assert r["mAP_fp32"] > 0.5
+    assert map_range[0] <= r["mAP_fp32"] <= map_range[1], r["mAP_fp32"]
     assert r["delta"] < 1e-3, r
     assert r["flipped_max_abs_over_rms"] <= r["err_max_over_rms"] + 1e-9
-    assert r["err_max_over_rms"] < 0.15 and r["flip_rate"] < 1e-2
+    assert r["err_max_over_rms"] < 0.15 and r["flip_rate"] < 2e-3
 
 
 @pytest.mark.parametrize("streams,max_batch", [(1, 8), (2, 8), (1, 3)])
@@ -78,3 +82,85 @@ def test_every_layers_concept_attention_rows_against_the_oracle(dev, monkeypatch
     rms = float(ref["codes"].pow(2).mean().sqrt())
     assert float((out["codes"].cpu() - ref["codes"]).abs().max()) / rms < 4e-2
     enc.close()
+
+
+def test_baseline_config_1_at_its_own_batch_size(dev):
+    """BASELINE.json configs[0]: CUB-200 16-bit concept_hash, ViT-S/16 (12 layers), batch = 8 -- the reference runs it on PyTorch
+    CPU; here it runs on the GPU (the CPU plumbing of this tree is the oracle, by design: the product path has no CPU fallback)
+    and is checked against that oracle at the SAME batch size, all 8 images, codes + centre logits + the packed 16-bit codes."""
+    from concepthash_amd.encoder import ConceptHashEncoder
+    from oracle import encoder_oracle as eo
+    from oracle import hamming_oracle as ho
+    cfg = dict(eo.CONFIGS["vit_s16"])
+    sd = eo.synthetic_state_dict(cfg, nbit=16, nclass=200)
+    x = eo.synthetic_images(8, cfg["image"], seed=81)
+    enc = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=8, device=dev)
+    out = enc.encode(x.to(dev), want=("codes", "packed", "logits_cont", "logits_bin"))
+    torch.cuda.synchronize()
+    ref = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False)
+    for key in ("codes", "logits_cont", "logits_bin"):
+        got, want = out[key].cpu(), ref[key]
+        e = float((got - want).abs().max() / want.pow(2).mean().sqrt())
+        print(f"config 1 (ViT-S/16 x 12, 16 bit, batch 8) {key}: max-abs / RMS vs the fp32 oracle {e:.2e}")
+        assert e < 4e-2, key
+    packed = out["packed"].cpu().numpy().view(np.uint64)
+    assert packed.shape == (8, 1) and np.array_equal(packed, ho.pack(out["codes"].cpu().numpy()))
+    assert int(packed.max()) < (1 << 16)                      # 16 bits in one word, the rest zero
+    enc.close()
+
+
+_RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], HSA_ENABLE_IPC_MODE_LEGACY="0", CH_FORCE_COLLECTIVES="1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # nccl == RCCL on ROCm
+from concepthash_amd import retrieval as rt
+from concepthash_amd.distributed import RowShard, ShardedRetrieval
+from oracle import hamming_oracle as ho
+q, ql = ho.synthetic_codes(300, 128, seed=1, nclass=9)
+g, gl = ho.synthetic_codes(5000, 128, seed=2, nclass=9)
+t = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev)
+sr = ShardedRetrieval(t(g), t(gl))
+allq = sr.gather_queries(t(q))                                           # all_gather (ragged form) of packed int64 codes
+assert torch.equal(allq, t(q))
+idx, dst = sr.topk(allq, 10)
+ridx, rdst = ho.topk(q, g, 10)
+assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(dst.cpu().numpy(), rdst)
+ev = sr.evaluate(allq, t(ql), R=[-1, 50], ks=(1, 5, 10), remove_first=True)
+for i, R in enumerate((-1, 50)):
+    ref = ho.mean_ap(q, g, ql, gl, R=R, ks=(1, 5, 10), remove_first=True)
+    assert np.array_equal(ev["S"][i].cpu().numpy().view(np.uint64), ref["S"])
+    assert np.array_equal(ev["nrel"][i].cpu().numpy().astype(np.uint32), ref["nrel"])
+onehot = torch.nn.functional.one_hot(t(gl).long(), 9).float()
+sr2 = ShardedRetrieval(t(g), onehot)                                     # indicator labels: the ranks agree on the label form (all_reduce MIN)
+ev2 = sr2.evaluate(allq, torch.nn.functional.one_hot(t(ql).long(), 9).to(torch.uint8), R=-1)
+assert torch.equal(ev2["S"], sr.evaluate(allq, t(ql), R=-1)["S"])
+codes = torch.randn(37, 64, device=dev)
+rs = RowShard(codes)                                                     # all_gather of row counts, gather, broadcast_object_list
+assert rs.counts == [37] and torch.equal(rs.gather(0), codes.cpu()) and torch.equal(rs.mean(0, keepdim=True), codes.cpu().mean(0, keepdim=True))
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_backend_runs_the_sharded_retrieval_collectives(tmp_path):
+    """One GPU box: the multi-rank paths are otherwise rehearsed over gloo only.  Here the process group is REAL RCCL (backend
+    "nccl", one rank): every collective form the sharded evaluator and the RowShard outputs use -- all_gather of int64 / int32 /
+    uint8 tensors (equal-sized and ragged), all_gather_into_tensor, all_reduce of int64 / int32 (SUM, MIN), broadcast_object_list,
+    barrier -- goes through the RCCL library with this project's dtypes and shapes, and the results are bit-exact vs the oracle.
+    (A scaling number needs the driver's 8-GPU node; two ranks cannot share one GPU under RCCL.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    r = subprocess.run([sys.executable, str(script), ROOT, str(port)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

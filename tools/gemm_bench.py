@@ -62,7 +62,7 @@ def main():
                 os.environ["CH_PPP_SKEW_NS"], os.environ["CH_PPP_FLAGS"] = skew, flags
                 if v == 6 and (N % 128 or K % 128):
                     continue
-                if v in (2, 4, 5, 21, 22, 23, 24, 25, 26, 27) and (N % 256 or K % 128):
+                if v in (2, 4, 5, 8, 21, 22, 23, 24, 25, 26, 27) and (N % 256 or K % 128):
                     continue
                 if v == 5 and ep not in (0, 1, 2, 6, 8, 9, 10):
                     continue
