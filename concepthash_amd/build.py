@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libconcepthash_hip.so")
-SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip",
+SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_rows.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip",
            "preprocess.hip", "train_kernels.hip", "attention_bwd.hip", "train.hip"]
 # kernels that lost to the dispatched ones: kept in the tree with their parity tests, compiled only
 # into an experiments build (CH_BUILD_EXPERIMENTS=1), never into the product library

@@ -71,6 +71,8 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);      // dispatche
 int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s);   // gemm_bf16.hip: 128x128x64, two-phase
 int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s);   // gemm_pp.hip: 256x256x64, ping-pong 8-phase
 bool ch_gemm_pp_supported(const GemmParams &p);
+int ch_gemm_bf16_rows(const GemmParams &p, int epi, hipStream_t s); // gemm_rows.hip: 128 rows x N = 384 per workgroup (adapter down-projection)
+bool ch_gemm_rows_supported(const GemmParams &p, int epi);
 // Experiment kernels that did not beat the dispatched ones: built only with CH_BUILD_EXPERIMENTS=1
 // (-DCH_EXPERIMENTS); the product library does not contain them and their taps say so.
 #ifdef CH_EXPERIMENTS

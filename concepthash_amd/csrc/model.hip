@@ -822,6 +822,7 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
         return ch_gemm_bf16_pp(p, epi, s);
     }
     if (variant == 3) return ch_gemm_bf16_dp(p, epi, s);
+    if (variant == 9) return ch_gemm_bf16_rows(p, epi, s);
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
     if (variant == 7) return ch_gemm_bf16_r4(p, epi, s);
@@ -844,9 +845,9 @@ extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_a
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
     if (variant == 7) return ch_gemm_bf16_r4(p, epi, s);
-    if (variant == 1 || variant == 2 || variant == 4 || variant == 8) ch_gemm_set_variant(variant);
+    if (variant == 1 || variant == 2 || variant == 4 || variant == 8 || variant == 9) ch_gemm_set_variant(variant);
     const int rc = ch_gemm_bf16(p, epi, s);
-    if (variant == 1 || variant == 2 || variant == 4 || variant == 8) ch_gemm_set_variant(0);
+    if (variant == 1 || variant == 2 || variant == 4 || variant == 8 || variant == 9) ch_gemm_set_variant(0);
     return rc;
 }
 extern "C" void ch_debug_set_gemm_variant(int32_t v) { ch_gemm_set_variant(v); }

@@ -258,6 +258,38 @@ def test_free_tail_schedule_is_bit_identical_and_race_free(M, N, K):
             assert torch.equal(st[:M], outs[0][1][:M]), (epi, M, N, K)
 
 
+@pytest.mark.parametrize("M,K", [(51456, 768), (25728, 768), (1000, 768), (130, 1024), (515, 384), (77, 64)])
+def test_whole_row_kernel_is_bit_identical_and_race_free(M, K):
+    """gemm_rows_kernel (gemm_rows.hip, variant 9 of the taps; dispatched for the adapter down-projection from 16,384 rows up): a
+    workgroup owns 128 whole rows x N = 384, a wave 32 full rows.  Same MFMA and the same ascending-k order as the 128x128 kernel:
+    bit-identical to it for every epilogue it takes -- bias, exact GELU, LayerNorm-folded (+ GELU / quick_gelu) -- with caches
+    warm and evicted, ragged row counts, K = 64 (two K-steps) included."""
+    N = 384
+    X, W, bias, _ = _inputs(M, N, K, seed=11)
+    junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    Mp = X.shape[0]
+    stats = torch.zeros(Mp, max(1, K // 64), 2, device="cuda")
+    stats[:M] = _slice_stats(X, M).float()
+    fold_c = torch.randn(N, device="cuda")
+    epis = [EPI_BIAS, EPI_GELU] + ([8, 9, 10] if K % 128 == 0 and K <= 1280 else [])
+    for epi in epis:
+        outs = []
+        for variant, it in ((1, 0), (9, 0), (9, 1), (9, 2), (9, 3)):
+            out = torch.full((Mp, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            if it % 2:
+                junk.fill_(float(it))
+            if epi >= 8:
+                _gemm_ln(variant, X, W, bias, M, epi, out=out, stats_in=stats, fold_c=fold_c, eps=1e-5)
+            else:
+                _gemm(variant, X, W, bias, M, epi, out=out)
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert not torch.isnan(outs[1][:M].float()).any()
+        for out in outs[1:]:
+            assert torch.equal(out[:M].view(torch.int16), outs[0][:M].view(torch.int16)), (epi, M, K)
+            assert torch.isnan(out[M:].float()).all()          # rows past M are never written
+
+
 @pytest.mark.parametrize("variant", [1, 2, 4, 7])
 @pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (700, 3072, 768), (515, 384, 768), (300, 256, 128), (257, 512, 1280)])
 def test_layernorm_folded_consumers(variant, M, N, K):

@@ -32,8 +32,9 @@ def test_map_delta_on_a_head_trained_with_the_reference_loss(dev, mix, map_range
     separates it completely: mAP 1.000) and prototypes at a fifth of the noise amplitude (trained mAP ~0.95, the range of the
     paper's CUB numbers).  Asserted: the north-star bound |delta mAP@all| < 1e-3; every flipped bit has a |fp32 code| inside the
     measured encode error; training moved the loss and the quantisation term (the codes are a trained model's, not a random
-    head's).  Measured (profiles/r03_trained_head_map.txt): delta 0 / 3.7e-4, bit-flip rate 1.2e-4 / 2.8e-4 -- against 4.1e-3 for
-    the fitted linear probe of regime B; the under-trained third regime of that file (mAP 0.70) is reported there, not asserted."""
+    head's).  Measured here: delta 0 / 3.7e-4, bit-flip rate 1.2e-4 / 2.8e-4 -- against 4.1e-3 for the fitted linear probe of
+    regime B; profiles/r03_trained_head_map.txt has the same on twice the evaluation set (0 / 2.4e-4) plus an under-trained mix
+    (mAP 0.66, delta 1.1e-3: reported there, not asserted)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import trained_head_map as thm
     r = thm.run(dev, steps=300, batch=128, per_eval=24, mix=mix)
