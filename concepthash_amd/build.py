@@ -10,11 +10,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libconcepthash_hip.so")
-SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_rows.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip",
+SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip",
            "preprocess.hip", "train_kernels.hip", "attention_bwd.hip", "train.hip"]
-# kernels that lost to the dispatched ones: kept in the tree with their parity tests, compiled only
-# into an experiments build (CH_BUILD_EXPERIMENTS=1), never into the product library
-EXPERIMENT_SOURCES = ["gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "gemm_r4.hip", "adapter_fused.hip"]
+# kernels that lost to the dispatched ones (DESIGN.md sections 3.8-3.9): kept in csrc/experiments/ with their parity tests, compiled
+# only into an experiments build (CH_BUILD_EXPERIMENTS=1), never into the product library
+EXPERIMENT_SOURCES = [os.path.join("experiments", f) for f in ("gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "gemm_r4.hip",
+                                                                "adapter_fused.hip", "gemm_rows.hip")]
 HEADERS = ["ch_common.h", "kernels.h", "gemm_epilogue.h", "model_internal.h", os.path.join("..", "..", "include", "concepthash_hip.h"),
            os.path.join("..", "..", "include", "concepthash_hip_debug.h")]
 # attention post-processes every MFMA result on the VALU: keep accumulators in VGPRs (no v_accvgpr_read round trips)
@@ -53,10 +54,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in sources:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        op = os.path.join(OBJDIR, os.path.basename(src).replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + hdrs):
-            jobs.append([hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op])
+            jobs.append([hipcc] + flags + ["-I", CSRC] + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:

@@ -15,6 +15,10 @@
 // chunk ^ (((row >> 3) & 1) << 1) (conflict free for ds_read_b128's 16-lane groups: four LDS rows share one 256-B bank row; same
 // proof as gemm_dp.hip), applied on the per-lane global SOURCE address (the LDS-DMA image is lane-linear) and on the read address.
 // Same MFMA, same ascending-k accumulation order as gemm_bf16.hip: bit-identical to it (tests/test_gemm_gpu.py).
+// MEASURED (round 3, profiles/r03_gemm_rows_ab.txt): 61.3 us vs 58.6 us for the 128x128 kernel at 51,456 rows, 46.2 vs 39.9 us at
+// 25,728 rows (201 workgroups do not fill 256 CUs), end to end 12.52-12.69 vs 12.50-12.55 ms per step: NOT faster -- a two-stage
+// loop with one 48-MFMA step of prefetch distance waits for its LDS-DMA (MFMA duty 0.32), and a third 32 KB stage costs the second
+// workgroup per CU.  Experiment (variant 9 of the taps, CH_GEMM_ROWS=1), not dispatched.
 // K must be a multiple of 32, N == 384, X padded to a multiple of 128 rows.
 #include "ch_common.h"
 #include "kernels.h"

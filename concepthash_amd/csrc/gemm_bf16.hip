@@ -233,9 +233,9 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s) {
     const bool pp = ch_gemm_pp_supported(p) && p.K >= min_k && (p.pp_min_k > 0 || tiles_pp >= 128);
     g_dispatch_count[pp ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
     if (pp) return ch_gemm_bf16_pp(p, epi, s);
-    // N = 384 (the adapter bottleneck): whole-row workgroups, one round of the chip instead of 2.36 rounds of 128x128 tiles
-    // (gemm_rows.hip); small problems (the pruned final layer) stay on the 128x128 kernel.  CH_GEMM_ROWS=0 switches it off.
-    static const int rows_on = getenv("CH_GEMM_ROWS") ? atoi(getenv("CH_GEMM_ROWS")) : 1;
+    // N = 384 (the adapter bottleneck) as whole-row workgroups (experiments/gemm_rows.hip): one round of the chip instead of 2.36
+    // rounds of 128x128 tiles, bit-identical -- and no faster (61 vs 59 us).  Opt-in: CH_GEMM_ROWS=1, experiments build.
+    static const int rows_on = getenv("CH_GEMM_ROWS") ? atoi(getenv("CH_GEMM_ROWS")) : 0;
     if (rows_on && p.small_kernel == 0 && p.M >= 128 * 128 && ch_gemm_rows_supported(p, epi)) return ch_gemm_bf16_rows(p, epi, s);
     const bool ring = (p.small_kernel == 2 || g_gemm_variant == 7) && ch_gemm_r4_supported(p);
     return ring ? ch_gemm_bf16_r4(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);

@@ -71,8 +71,7 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);      // dispatche
 int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s);   // gemm_bf16.hip: 128x128x64, two-phase
 int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s);   // gemm_pp.hip: 256x256x64, ping-pong 8-phase
 bool ch_gemm_pp_supported(const GemmParams &p);
-int ch_gemm_bf16_rows(const GemmParams &p, int epi, hipStream_t s); // gemm_rows.hip: 128 rows x N = 384 per workgroup (adapter down-projection)
-bool ch_gemm_rows_supported(const GemmParams &p, int epi);
+
 // Experiment kernels that did not beat the dispatched ones: built only with CH_BUILD_EXPERIMENTS=1
 // (-DCH_EXPERIMENTS); the product library does not contain them and their taps say so.
 #ifdef CH_EXPERIMENTS
@@ -84,6 +83,8 @@ int ch_gemm_bf16_dp(const GemmParams &p, int epi, hipStream_t s);   // gemm_dp.h
 bool ch_gemm_dp_supported(const GemmParams &p);
 int ch_gemm_bf16_r4(const GemmParams &p, int epi, hipStream_t s);   // gemm_r4.hip: 128x128x32, 4-stage ring, 2 workgroups/CU
 bool ch_gemm_r4_supported(const GemmParams &p);
+int ch_gemm_bf16_rows(const GemmParams &p, int epi, hipStream_t s); // gemm_rows.hip: 128 whole rows x N = 384 per workgroup (adapter down-projection)
+bool ch_gemm_rows_supported(const GemmParams &p, int epi);
 #else
 static inline int ch_experiments_not_built() {
     ch_set_error("experiment kernels are not part of this build (rebuild with CH_BUILD_EXPERIMENTS=1)");
@@ -94,6 +95,8 @@ static inline int ch_gemm_bf16_ppp(const GemmParams &, int, hipStream_t) { retur
 static inline int ch_gemm_bf16_dp(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
 static inline int ch_gemm_bf16_r4(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
 static inline bool ch_gemm_r4_supported(const GemmParams &) { return false; }
+static inline int ch_gemm_bf16_rows(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
+static inline bool ch_gemm_rows_supported(const GemmParams &, int) { return false; }
 #endif
 int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s);  // timing-only builds (garbage results)
 void ch_gemm_set_variant(int v);

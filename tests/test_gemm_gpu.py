@@ -260,10 +260,11 @@ def test_free_tail_schedule_is_bit_identical_and_race_free(M, N, K):
 
 @pytest.mark.parametrize("M,K", [(51456, 768), (25728, 768), (1000, 768), (130, 1024), (515, 384), (77, 64)])
 def test_whole_row_kernel_is_bit_identical_and_race_free(M, K):
-    """gemm_rows_kernel (gemm_rows.hip, variant 9 of the taps; dispatched for the adapter down-projection from 16,384 rows up): a
-    workgroup owns 128 whole rows x N = 384, a wave 32 full rows.  Same MFMA and the same ascending-k order as the 128x128 kernel:
-    bit-identical to it for every epilogue it takes -- bias, exact GELU, LayerNorm-folded (+ GELU / quick_gelu) -- with caches
-    warm and evicted, ragged row counts, K = 64 (two K-steps) included."""
+    """gemm_rows_kernel (experiments/gemm_rows.hip, variant 9 of the taps, experiments build; measured no faster than the 128x128
+    kernel, not dispatched): a workgroup owns 128 whole rows x N = 384, a wave 32 full rows.  Same MFMA and the same ascending-k
+    order as the 128x128 kernel: bit-identical to it for every epilogue it takes -- bias, exact GELU, LayerNorm-folded (+ GELU /
+    quick_gelu) -- with caches warm and evicted, ragged row counts, K = 64 (two K-steps) included."""
+    _need_experiments()
     N = 384
     X, W, bias, _ = _inputs(M, N, K, seed=11)
     junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
