@@ -17,6 +17,17 @@
 
 namespace ch_epi {
 
+// The fp32 residual stream is read once and written once per adapter (158 MB each way at batch 256) and not touched again before
+// ~800 MB of other traffic has passed: with -DCH_RESID_NT its read-modify-write of the scale+residual epilogues goes non-temporal
+// (A/B build, profiles/r03_resid_nt_ab.txt).
+#ifdef CH_RESID_NT
+__device__ __forceinline__ f32x4 ld_resid(const float *p) { return __builtin_nontemporal_load((const f32x4 *)p); }
+__device__ __forceinline__ void st_resid(float *p, f32x4 v) { __builtin_nontemporal_store(v, (f32x4 *)p); }
+#else
+__device__ __forceinline__ f32x4 ld_resid(const float *p) { return *(const f32x4 *)p; }
+__device__ __forceinline__ void st_resid(float *p, f32x4 v) { *(f32x4 *)p = v; }
+#endif
+
 // quick_gelu(x) = x * sigmoid(1.702 x) (HF QuickGELUActivation): one v_exp_f32 + one v_rcp_f32 (1 ulp) instead of an IEEE
 // division -- the epilogue of fc1 evaluates 128 of these per lane per tile.
 __device__ __forceinline__ float quick_gelu_f(float x) {
@@ -137,7 +148,7 @@ __device__ __forceinline__ void resid_prefetch(const GemmParams &p, int m_base, 
         const int m = m_base + row;
         const int mc = m < p.M ? m : p.M - 1;
         const int n = n_base + (pos ^ (row & 15)) * 4;
-        r.hv[j] = *(const f32x4 *)(p.resid + (size_t)mc * p.ldr + n);
+        r.hv[j] = ld_resid(p.resid + (size_t)mc * p.ldr + n);
         r.av[j] = make_uint2(0u, 0u);
         if (p.addend) r.av[j] = *(const uint2 *)(p.addend + (size_t)mc * p.ld_addend + n);
     }
@@ -306,7 +317,7 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                         if (PREF && batch == 0)
                             hv[i] = pf->hv[i];
                         else
-                            hv[i] = *(const f32x4 *)(p.resid + off[i]);
+                            hv[i] = EPI == EPI_BIAS_RESID ? *(const f32x4 *)(p.resid + off[i]) : ld_resid(p.resid + off[i]);
                         if constexpr (T::scale_resid) {
                             if (PREF && batch == 0) {
                                 av[i] = pf->av[i];
@@ -338,7 +349,7 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                         h[1] += bf2f((bf16_t)(av[i].x >> 16));
                         h[2] += bf2f((bf16_t)(av[i].y & 0xffff));
                         h[3] += bf2f((bf16_t)(av[i].y >> 16));
-                        *(f32x4 *)(p.resid + off[i]) = h;
+                        st_resid(p.resid + off[i], h);
                         if constexpr (T::stats) {  // bf16 copy for the next (LN-folded) GEMM + its row statistics
                             const int row = (batch * 8 + i) * 4 + lrow;
                             const int m = m_base + pass * 64 + row;
