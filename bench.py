@@ -297,18 +297,23 @@ def roofline_block(prof, args, enc, B, prof_ms_per_step, codes_same):
 
     pp_grid = lambda N: -(-rows_tok // 256) * (N // 256) * 512
     v1_grid = lambda N: -(-rows_tok // 128) * (N // 128) * 256
+    # cache-policy instances the dispatcher picks by size (gemm_bf16.hip: resid_nt_choice / out_nt_choice; CH_RESID_NT / CH_NT_OUT force)
+    def _pick(env, nbytes, limit):
+        return os.environ[env] != "0" if env in os.environ else nbytes >= limit
+    nt_resid = _pick("CH_RESID_NT", rows_tok * D_ * 4, 48 << 20)
+    pp_tag = lambda N: 2 if _pick("CH_NT_OUT", rows_tok * N * 2, 128 << 20) else 0
     instances = [  # (label, rocprof name, category, grid, algorithmic bytes per launch, bound)
         ("gemm_pp_kernel<EPI_BIAS_STATS> out_proj (K = D, 256x256 ping-pong)", "gemm_pp_kernel<6, 0, 0, 0>", "gemm_out",
          pp_grid(D_), gemm_bytes(D_, D_, rows_tok * D_ * 2 + st), "mfma"),
         ("gemm_pp_kernel<EPI_BIAS_STATS, TAG 1> fc2 (K = 4 D)", "gemm_pp_kernel<6, 0, 0, 1>", "gemm_fc2",
          pp_grid(D_), gemm_bytes(D_, F_, rows_tok * D_ * 2 + st), "mfma"),
-        ("gemm_pp_kernel<EPI_FOLD_QUICKGELU> fc1", f"gemm_pp_kernel<{9 if enc.cfg['act'] == 0 else 10}, 0, 0, 0>", "gemm_fc1",
+        ("gemm_pp_kernel<EPI_FOLD_QUICKGELU> fc1", f"gemm_pp_kernel<{9 if enc.cfg['act'] == 0 else 10}, 0, 0, {pp_tag(F_)}>", "gemm_fc1",
          pp_grid(F_), gemm_bytes(F_, D_, rows_tok * F_ * 2 + st), "mfma"),
-        ("gemm_pp_kernel<EPI_FOLD_BIAS> qkv (layers >= 1; layer 0 runs <EPI_BIAS>)", "gemm_pp_kernel<8, 0, 0, 0>", "gemm_qkv",
+        ("gemm_pp_kernel<EPI_FOLD_BIAS> qkv (layers >= 1; layer 0 runs <EPI_BIAS>)", f"gemm_pp_kernel<8, 0, 0, {pp_tag(3 * D_)}>", "gemm_qkv",
          pp_grid(3 * D_), gemm_bytes(3 * D_, D_, rows_tok * 3 * D_ * 2 + st), "mfma"),
-        ("gemm_bf16_kernel<EPI_SCALE_RESID_STATS> adapter up (128x128)", "gemm_bf16_kernel<7>", "gemm_up",
+        ("gemm_bf16_kernel<EPI_SCALE_RESID_STATS> adapter up (128x128)", "gemm_bf16_kernel<7, true>" if nt_resid else "gemm_bf16_kernel<7, false>", "gemm_up",
          v1_grid(D_), gemm_bytes(D_, b_pad, rows_tok * D_ * (4 * 2 + 2 + 2) + st), "hbm"),   # fp32 RMW + bf16 addend + bf16 copy
-        ("gemm_bf16_kernel<EPI_FOLD_GELU> adapter down (128x128)", "gemm_bf16_kernel<10>", "gemm_down",
+        ("gemm_bf16_kernel<EPI_FOLD_GELU> adapter down (128x128)", "gemm_bf16_kernel<10, false>", "gemm_down",
          v1_grid(b_pad), gemm_bytes(b_pad, D_, rows_tok * b_pad * 2 + st), "hbm"),
     ]
     per_kernel = []

@@ -22,6 +22,10 @@
 namespace {
 
 constexpr int HD = 64;
+// cache policy of the K / V / Q reads (each element is read exactly once): aux 2 (nt) measured, no gain
+// (profiles/r03_cache_policy_ab.txt) -> default policy
+constexpr int QKV_AUX = 0;
+#define LDQ(p) (*(const bf16x8 *)(p))
 constexpr int NW = 8;  // waves per workgroup: 13 query tiles (201 tokens) take two rounds instead of four with 4 waves; K/V staged once
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
@@ -56,8 +60,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__r
             int row = i * 8 + lrow;
             row = row < ntok ? row : ntok - 1;
             const bf16_t *src = base + (size_t)row * ld + src_chunk * 8;
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + D), (lds_void_t *)(Ks + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + 2 * D), (lds_void_t *)(Vs + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + D), (lds_void_t *)(Ks + i * 1024), 16, 0, QKV_AUX);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + 2 * D), (lds_void_t *)(Vs + i * 1024), 16, 0, QKV_AUX);
         }
     }
     const int fr = lane & 15, fq = lane >> 4;
@@ -77,8 +81,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__r
     bool qvalid;
     int qslot = wid * 16 + fr;
     int q = query_of(qslot, qvalid);
-    bf16x8 qf0 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8);
-    bf16x8 qf1 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8 + 32);
+    bf16x8 qf0 = LDQ(base + (size_t)q * ld + fq * 8);
+    bf16x8 qf1 = LDQ(base + (size_t)q * ld + fq * 8 + 32);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -127,8 +131,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const bf16_t *__r
         if (qt + NW < QT) {
             qslot = (qt + NW) * 16 + fr;
             q = query_of(qslot, qvalid);
-            qf0 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8);
-            qf1 = *(const bf16x8 *)(base + (size_t)q * ld + fq * 8 + 32);
+            qf0 = LDQ(base + (size_t)q * ld + fq * 8);
+            qf1 = LDQ(base + (size_t)q * ld + fq * 8 + 32);
         }
         // ---- softmax over keys for query (lane & 15): lane holds keys kt*16 + 4*fq + r
         // keys >= ntok exist only in the last (KP - ntok + 15) / 16 <= 2 key tiles: mask those under a wave-uniform test

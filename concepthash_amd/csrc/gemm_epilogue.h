@@ -18,15 +18,23 @@
 namespace ch_epi {
 
 // The fp32 residual stream is read once and written once per adapter (158 MB each way at batch 256) and not touched again before
-// ~800 MB of other traffic has passed: with -DCH_RESID_NT its read-modify-write of the scale+residual epilogues goes non-temporal
-// (A/B build, profiles/r03_resid_nt_ab.txt).
-#ifdef CH_RESID_NT
-__device__ __forceinline__ f32x4 ld_resid(const float *p) { return __builtin_nontemporal_load((const f32x4 *)p); }
-__device__ __forceinline__ void st_resid(float *p, f32x4 v) { __builtin_nontemporal_store(v, (f32x4 *)p); }
-#else
-__device__ __forceinline__ f32x4 ld_resid(const float *p) { return *(const f32x4 *)p; }
-__device__ __forceinline__ void st_resid(float *p, f32x4 v) { *(f32x4 *)p = v; }
-#endif
+// ~800 MB of other traffic has passed: when it is larger than what the 256 MB Infinity Cache can usefully keep (the dispatcher
+// decides from the tensor's size and launches the NT instance) the read-modify-write of the scale+residual epilogues goes
+// NON-TEMPORAL.  A template parameter, not a run-time flag: with a uniform branch around the two flavours the compiler hoists the
+// common load out of both arms and the cache-policy bits are lost (measured: no effect at all).  Measured
+// at batch 256: adapter up-projection 101.7 -> 94.0 us, encode step 12.51 -> 12.23 ms (profiles/r03_resid_nt_ab.txt); at batch 32
+// (20 MB, cache resident) the default policy is 1.6 % faster, hence the size test.
+typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ f32x4 ld_resid(const float *ptr) {
+    if constexpr (NT) return __builtin_nontemporal_load((const f32x4 *)ptr);
+    else return *(const f32x4 *)ptr;
+}
+template <bool NT>
+__device__ __forceinline__ void st_resid(float *ptr, f32x4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, (f32x4 *)ptr);
+    else *(f32x4 *)ptr = v;
+}
 
 // quick_gelu(x) = x * sigmoid(1.702 x) (HF QuickGELUActivation): one v_exp_f32 + one v_rcp_f32 (1 ulp) instead of an IEEE
 // division -- the epilogue of fc1 evaluates 128 of these per lane per tile.
@@ -129,7 +137,7 @@ __device__ __forceinline__ void fold_stats_finish(const GemmParams &p, int tid, 
     const float inv = 1.0f / (float)p.K;
     const float mean = sm * inv;
     const float var = fmaxf(sq * inv - mean * mean, 0.f);
-    if (!(tid & 1)) *(ch_f32x2_t *)(row_ms + (tid & ~1)) = ch_f32x2_t{mean, rsqrtf(var + p.ln_eps)};
+    if (!(tid & 1)) *(ch_f32x2_t *)(row_ms + (tid & ~1)) = ch_f32x2_t{rsqrtf(var + p.ln_eps), mean};   // (rstd, mean): see store_tile
 }
 
 // Residual read-modify-write epilogues of a 64x64 wave tile (MT = 4): the fp32 residual values a lane will
@@ -139,7 +147,7 @@ struct ResidPrefetch {
     f32x4 hv[8];  // the first of the two read-back batches
     uint2 av[8];
 };
-template <int EPI>
+template <int EPI, bool NT = false>
 __device__ __forceinline__ void resid_prefetch(const GemmParams &p, int m_base, int n_base, int lane, ResidPrefetch &r) {
     const int lrow = lane >> 4, pos = lane & 15;
 #pragma unroll
@@ -148,7 +156,7 @@ __device__ __forceinline__ void resid_prefetch(const GemmParams &p, int m_base, 
         const int m = m_base + row;
         const int mc = m < p.M ? m : p.M - 1;
         const int n = n_base + (pos ^ (row & 15)) * 4;
-        r.hv[j] = ld_resid(p.resid + (size_t)mc * p.ldr + n);
+        r.hv[j] = ld_resid<NT>(p.resid + (size_t)mc * p.ldr + n);
         r.av[j] = make_uint2(0u, 0u);
         if (p.addend) r.av[j] = *(const uint2 *)(p.addend + (size_t)mc * p.ld_addend + n);
     }
@@ -157,7 +165,7 @@ __device__ __forceinline__ void resid_prefetch(const GemmParams &p, int m_base, 
 // wave_lds: this wave's 16 KB staging region; m_base / n_base: global row / column of the wave's sub-tile origin;
 // row_ms: (EPI_FOLD_*) the block tile's (mean, rstd) table in LDS, already offset to this wave's first row;
 // pf: (PREF) the residual / addend values loaded by resid_prefetch.
-template <int EPI, int MT, bool PREF = false>
+template <int EPI, int MT, bool PREF = false, bool NT = false, bool NTOUT = false>
 __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][MT], char *wave_lds, int m_base, int n_base,
                                            int lane, const float *row_ms = nullptr, const ResidPrefetch *pf = nullptr) {
     static_assert(!PREF || (MT == 4 && traits<EPI>::scale_resid), "prefetched residual: 64-row wave tiles, scale+residual epilogues");
@@ -201,9 +209,14 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
             const int row = mt * 16 + fr;
             float rs = 1.0f, nm = 0.f;
             if constexpr (T::fold) {
+                // The table holds (rstd, mean), rstd FIRST: the scalar every accumulator is multiplied by then sits in the LOW half of
+                // the loaded register pair and the compiler broadcasts it with op_sel_hi = 0.  With (mean, rstd) it selects the high
+                // half with op_sel = 1, and `v_pk_fma_f32 D, acc, ms, C op_sel:[0,1,0]` (high half of SRC1 into the low lane) returns,
+                // intermittently, a wrong low lane for 16 lanes when another kernel shares the CU -- measured on MI355X, not cured
+                // by wait states (tools/check_dpp_hazards.py rejects the form in every built kernel).
                 const ch_f32x2_t ms = *(const ch_f32x2_t *)(row_ms + 2 * row);
-                rs = ms[1];
-                nm = -ms[0] * ms[1];
+                rs = ms[0];
+                nm = -ms[1] * ms[0];
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -245,7 +258,11 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                 }
                 v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             }
-            if (m < p.M) *(uint4 *)(p.out_bf16 + (size_t)m * p.ldo + n_base + chunk * 8) = v;
+            if (m < p.M) {
+                uint4 *dst = (uint4 *)(p.out_bf16 + (size_t)m * p.ldo + n_base + chunk * 8);
+                if constexpr (NTOUT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), (u32x4_nt *)dst);
+                else *dst = v;
+            }
             if constexpr (T::act2) {  // training: the activation of the (bf16-rounded) pre-activation as a second output
                 const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
                 uint32_t ow[4];
@@ -317,7 +334,7 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                         if (PREF && batch == 0)
                             hv[i] = pf->hv[i];
                         else
-                            hv[i] = EPI == EPI_BIAS_RESID ? *(const f32x4 *)(p.resid + off[i]) : ld_resid(p.resid + off[i]);
+                            hv[i] = EPI == EPI_BIAS_RESID ? *(const f32x4 *)(p.resid + off[i]) : ld_resid<NT>(p.resid + off[i]);
                         if constexpr (T::scale_resid) {
                             if (PREF && batch == 0) {
                                 av[i] = pf->av[i];
@@ -349,7 +366,7 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                         h[1] += bf2f((bf16_t)(av[i].x >> 16));
                         h[2] += bf2f((bf16_t)(av[i].y & 0xffff));
                         h[3] += bf2f((bf16_t)(av[i].y >> 16));
-                        st_resid(p.resid + off[i], h);
+                        st_resid<NT>(p.resid + off[i], h);
                         if constexpr (T::stats) {  // bf16 copy for the next (LN-folded) GEMM + its row statistics
                             const int row = (batch * 8 + i) * 4 + lrow;
                             const int m = m_base + pass * 64 + row;

@@ -73,8 +73,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // (tools/tile_timeline.py)
 // SCHED 0: four phases of 16 MFMAs per K-tile (the guide's 8-phase template); SCHED 1: two phases of 32 MFMAs per K-tile
 // (section "coarse schedule" below): same buffers, same fragments, half the barriers.
-// TAG: no effect on the code -- a second symbol name for launches the caller marks (GemmParams::tag), so that per-kernel
+// TAG 1: no effect on the code -- a second symbol name for launches the caller marks (GemmParams::tag), so that per-kernel
 // profiles (rocprofv3 --stats groups by name) keep fc2 (K = 4 N) apart from out_proj, which shares its epilogue and grid.
+// TAG 2: out_bf16 is stored non-temporally (GemmParams::nt_out, set by ch_gemm_bf16 for outputs past the cache size; a template
+// parameter because behind a run-time branch the compiler merges the two stores and drops the cache-policy bits).
 template <int EPI, int DBG = 0, int SCHED = 0, int TAG = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
         const char *base = which < 2 ? Xb : Wb;
         const uint32_t o0 = which == 0 ? xoff[0][0] : which == 1 ? xoff[1][0] : which == 2 ? woff[0][0] : woff[1][0];
         const uint32_t o1 = which == 0 ? xoff[0][1] : which == 1 ? xoff[1][1] : which == 2 ? woff[0][1] : woff[1][1];
+        // (aux 2 = nt on fc2's activation panel, fc1's 316 MB output: measured, no gain -- profiles/r03_cache_policy_ab.txt)
         __builtin_amdgcn_global_load_lds((gbl_void_t *)(base + (o0 + kb)), (lds_void_t *)(dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void_t *)(base + (o1 + kb)), (lds_void_t *)(dst + 1024), 16, 0, 0);
     };
@@ -435,14 +438,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) half[nt][mt] = acc[nt][pass * 4 + mt];
-                ch_epi::store_tile<EPI, 4>(p, half, smem + wid * 8192, m0 + wr * 128 + pass * 64, n0 + wc * 64, lane,
+                ch_epi::store_tile<EPI, 4, false, false, TAG == 2>(p, half, smem + wid * 8192, m0 + wr * 128 + pass * 64, n0 + wc * 64, lane,
                                            (const float *)(smem + 2 * BUF_BYTES) + 2 * (wr * 128 + pass * 64));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // pass 0 fully read back before pass 1 restages the slice
             }
             return;
         }
     }
-    ch_epi::store_tile<EPI, 8>(p, acc, smem + wid * 16384, m0 + wr * 128, n0 + wc * 64, lane,
+    ch_epi::store_tile<EPI, 8, false, false, TAG == 2>(p, acc, smem + wid * 16384, m0 + wr * 128, n0 + wc * 64, lane,
                                (const float *)(smem + 2 * BUF_BYTES) + 2 * (wr * 128));
     if constexpr (DBG & 8) {
         stamp[4] = __builtin_amdgcn_s_memtime();
@@ -500,6 +503,16 @@ int launch_pp_sched(GemmParams &p, int tiles, hipStream_t s) {
             if (int e = ch_func_max_lds((const void *)gemm_pp_kernel<EPI, 0, SCHED, 1>, lds, lds_once_t)) return e;
             CH_LAUNCH((gemm_pp_kernel<EPI, 0, SCHED, 1>), grid, dim3(NTHREADS), lds, s, p);
             CH_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if constexpr ((EPI == EPI_BIAS || EPI == EPI_FOLD_BIAS || EPI == EPI_FOLD_QUICKGELU || EPI == EPI_FOLD_GELU) && SCHED == 0) {
+        if (p.nt_out) {  // TAG 2: out_bf16 stored non-temporally (an output larger than the caches that is read once)
+            static ch_once_per_device lds_once_n;
+            if (int e = ch_func_max_lds((const void *)gemm_pp_kernel<EPI, 0, SCHED, 2>, lds, lds_once_n)) return e;
+            CH_LAUNCH((gemm_pp_kernel<EPI, 0, SCHED, 2>), grid, dim3(NTHREADS), lds, s, p);
+            CH_LAUNCH_CHECK();
+            ch_gemm_count_nt_launch(1);
             return 0;
         }
     }

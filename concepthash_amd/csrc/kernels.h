@@ -61,6 +61,8 @@ struct GemmParams {
     int rev;                 // 1: walk the m-tiles from the last row tile to the first (serpentine launch order)
     int pp_sched;            // 256x256 kernel: 0 = four phases of 16 MFMAs per K-tile, 1 = two phases of 32 (gemm_pp.hip)
     int pp_min_k;            // dispatcher: smallest K that goes to the 256x256 ping-pong kernel (0 = default 512)
+    int nt_resid;            // 1 = launch the instance with the non-temporal read-modify-write of the fp32 residual (set by the dispatcher)
+    int nt_out;              // 1 = store out_bf16 non-temporally (an output larger than the Infinity Cache that is read once, much later)
     int tag;                 // profiling only: 1 = launch the 256x256 kernel under its second symbol name (gemm_pp.hip, TAG)
     int small_kernel;        // dispatcher, GEMMs that do not go to the 256x256 kernel: 0 = default, 1 = 128x128x64 two-phase, 2 = 128x128x32 ring (experiments build)
 };
@@ -99,6 +101,7 @@ static inline int ch_gemm_bf16_rows(const GemmParams &, int, hipStream_t) { retu
 static inline bool ch_gemm_rows_supported(const GemmParams &, int) { return false; }
 #endif
 int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s);  // timing-only builds (garbage results)
+void ch_gemm_count_nt_launch(int kind);  // test tap counters: 0 = non-temporal residual instance, 1 = non-temporal output instance
 void ch_gemm_set_variant(int v);
 // n-tiles per weight group for a block tile of bn columns: minimises X re-fetches + W re-fetches
 int ch_gemm_group_n(int M, int N, int K, int bm, int bn);

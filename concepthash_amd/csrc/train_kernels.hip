@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t *__restrict__ 
 #pragma unroll
     for (int j = 0; j < MAXP; ++j)
         if (j < npass) {
-            float2 d = *(const float2 *)(dres_in + row * D + (j * 64 + lane) * 2);
+            float2 d = *(const float2 *)(dres_in + row * D + (j * 64 + lane) * 2);   // (non-temporal here: measured, no gain)
             d.x += rstd * (g[j].x - s1 - xh[j].x * s2);
             d.y += rstd * (g[j].y - s1 - xh[j].y * s2);
             if (dres_out) *(float2 *)(dres_out + row * D + (j * 64 + lane) * 2) = d;

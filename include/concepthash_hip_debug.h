@@ -34,7 +34,8 @@ void ch_debug_set_gemm_variant(int32_t variant);
  * those taps return an error. */
 int32_t ch_debug_experiments_built(void);
 /* How many GEMMs the dispatcher has sent to the 128x128 (which = 0) / 256x256 ping-pong (which = 1) kernel since the
- * library was loaded: lets a parity test prove which kernel produced the output it compared. */
+ * library was loaded, and how many launches ran the instance with the non-temporal fp32-residual read-modify-write (which = 2) /
+ * the non-temporal bf16 output store (which = 3): lets a parity test prove which kernel produced the output it compared. */
 int64_t ch_debug_gemm_dispatch_count(int32_t which);
 /* Copy the first nbytes of one activation buffer of the model's workspace, as the last ch_encode / ch_encode_hidden call left
  * it, to `out` (device): which = 0 H fp32 [rows, D] | 1 Xn | 2 QKV [rows, 3D] | 3 AO | 4 A | 5 AD [rows, max(bpad, 128)] |

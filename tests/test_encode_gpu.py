@@ -116,6 +116,31 @@ def test_batching_dtype_and_determinism(dev):
     enc.close()
 
 
+def test_forty_encodes_over_two_launch_chains_are_bit_identical(dev, monkeypatch):
+    """Run-to-run determinism under CONCURRENT launch chains (two streams share the CUs: the condition under which the
+    `v_pk_fma_f32 ... op_sel:[0,1,0]` form of the LN-fold epilogue returned wrong quarter-wave lanes in round 3 -- 40 of 40 calls
+    differed then).  ViT-S/16 x 2 layers, 11 images in chunks of 4 (two chains of 2 images each), codes and
+    the hidden state after every layer, 40 calls each, all bit-identical to the first."""
+    from oracle import encoder_oracle as eo
+    monkeypatch.setenv("CH_STREAMS", "2")
+    cfg = dict(eo.CONFIGS["vit_s16"])
+    cfg["L"] = 2
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    x = eo.synthetic_images(11, cfg["image"]).to(dev)
+    enc = _encoder(sd, cfg["heads"], max_batch=4)
+    ref = enc.encode(x)["codes"].clone()
+    hid = [enc.hidden_states(x[:4], layer).clone() for layer in (1, 2)]
+    torch.cuda.synchronize()
+    bad = 0
+    for _ in range(40):
+        bad += int(not torch.equal(enc.encode(x)["codes"], ref))
+        for i, layer in enumerate((1, 2)):
+            bad += int(not torch.equal(enc.hidden_states(x[:4], layer), hid[i]))
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of 120 calls differ from the first"
+    enc.close()
+
+
 def test_errors_are_loud(dev):
     from oracle import encoder_oracle as eo
     cfg = dict(eo.CONFIGS["vit_s16"])

@@ -95,6 +95,49 @@ def test_reference_golden_at_201_tokens(dev, monkeypatch, pp_min_k):
     assert bool((refc[flips].abs() < 2e-2 * refc.pow(2).mean().sqrt()).all())
 
 
+@pytest.mark.parametrize("pp_min_k", [None, 256])
+def test_cache_policy_instances_are_bit_identical(dev, monkeypatch, pp_min_k):
+    """The dispatcher picks, by tensor size, GEMM instances whose fp32-residual read-modify-write (gemm_bf16_kernel<EPI, true>) or bf16
+    output store (gemm_pp_kernel<EPI, 0, 0, 2>) is non-temporal (gemm_bf16.hip: resid_nt_choice / out_nt_choice; at BASELINE
+    sizes they are the default: 158 MB residual, 316 / 237 MB fc1 / qkv outputs).  A cache policy is not arithmetic: forced on
+    (CH_RESID_NT=1, CH_NT_OUT=1) on the reference's 201-token fixture every output is BIT-identical to the default instances', under
+    both dispatches -- all 128x128 (the adapter up-projection's residual instance) and all 256x256 (qkv / fc1 output instance)."""
+    from concepthash_amd import _lib
+    sd, z = load_fixture("encode_n201")
+    heads = int(z["meta/heads"])
+    if pp_min_k:
+        monkeypatch.setenv("CH_GEMM_PP_MIN_K", str(pp_min_k))
+    monkeypatch.setenv("CH_STREAMS", "1")
+    monkeypatch.setenv("CH_RESID_NT", "0")
+    monkeypatch.setenv("CH_NT_OUT", "0")
+    enc = _encoder(sd, heads, max_batch=2)
+    lib = _lib.load()
+    x = fixture_images(z).to(dev)
+    want = ("codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features", "image_features", "concept_attn")
+    count = lambda: (lib.ch_debug_gemm_dispatch_count(2), lib.ch_debug_gemm_dispatch_count(3))
+    c0 = count()
+    base = {k: v.clone() for k, v in enc.encode(x, want=want).items()}
+    h_base = enc.hidden_states(x, 2).clone()
+    torch.cuda.synchronize()
+    assert count() == c0                                     # forced off: default instances only
+    monkeypatch.setenv("CH_RESID_NT", "1")
+    monkeypatch.setenv("CH_NT_OUT", "1")
+    out = enc.encode(x, want=want)
+    h = enc.hidden_states(x, 2)
+    torch.cuda.synchronize()
+    c1 = count()
+    n_resid, n_out = c1[0] - c0[0], c1[1] - c0[1]
+    print(f"pp_min_k={pp_min_k}: {n_resid} launches of the non-temporal residual instance, {n_out} of the non-temporal output instance")
+    if pp_min_k:
+        assert n_out >= 2 * 2 * 2                            # qkv + fc1 of 2 layers, two calls
+    else:
+        assert n_resid >= 2 * 2 * 2 and n_out == 0           # two adapters of 2 layers, two calls; no 256x256 launch
+    for k in want:
+        assert torch.equal(out[k], base[k]), k
+    assert torch.equal(h, h_base)
+    enc.close()
+
+
 def test_non_pretrain_resolution_against_reference_golden(dev):
     """inputs other than the pretrain resolution.  tests/golden/encode_interp.npz = the reference model
     pretrained at 64 px evaluated at 96 px (interpolate_pos_encoding, models/arch/coop.py:429-450); here the interpolated table

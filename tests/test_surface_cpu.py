@@ -149,7 +149,9 @@ def test_loss_meters_match_a_direct_formula():
     assert torch.allclose(total, ce(out["logits_cont"]) + ce(out["logits_bin"]) + concept, atol=1e-6)
     assert set(crit.losses) == {"quan", "concept", "cont", "bin"}
     with pytest.raises(NotImplementedError):
-        LGHLoss(loss_scales={"attn_div_loss": 1}, avg_attn=True)     # needs every layer's full maps
+        LGHLoss(loss_scales={"attn_div_loss": 1}, nregs=2)           # register tokens: the model has none
+    with pytest.raises(RuntimeError, match="concept_attention_layers"):
+        LGHLoss(loss_scales={"attn_div_loss": 1}, avg_attn=True)(out, y)   # avg_attn reads every layer's concept rows
     with pytest.raises(RuntimeError, match="concept_attention"):
         LGHLoss(loss_scales={"attn_div_loss": 1})(out, y)            # the term is built, but the model must hand the rows over
 

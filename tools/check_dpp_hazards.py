@@ -16,6 +16,16 @@ inline-asm VMEM ring behind counted `s_waitcnt vmcnt(N)`), over the control-flow
    ones.  ANY instruction that reads or writes such a register before the wait that covers it is reported -- a compiler copy,
    spill or re-use of a ring register, or a compiler wait that counted only its own loads.
 4. No scratch traffic (register spills) in any `map_scan_kernel` instantiation.
+5. (every object, `--all` / check_pk_opsel) No packed-fp32 VALU instruction (`v_pk_fma_f32`, `v_pk_mul_f32`, `v_pk_add_f32`) whose
+   `op_sel` routes the HIGH half of SRC1 or SRC2 into the low lane (`op_sel:[x,1,x]` / `[x,x,1]`).  Measured on MI355X in round 3
+   (profiles/r03_pk_opsel_hazard.txt): `v_pk_fma_f32 D, acc, ms, C op_sel:[0,1,0]` in the LN-fold epilogue
+   of the 128x128 GEMM returned a wrong low lane for one quarter-wave (16 lanes x 1 VGPR), intermittently, whenever a second
+   launch chain shared the CUs -- 40 of 40 encode calls differed run to run -- with or without wait states in front of it; the
+   same product written `ms, acc op_sel:[1,0,0]`, with a splat pair and no op_sel, or with the scalar in the low half and
+   op_sel_hi = 0 never failed.  Which form the compiler picks for `vector * pair.hi` follows its operand canonicalisation (it flipped
+   when the kernel body moved into an inlined function), so the product sources keep such scalars in LOW halves and this check
+   rejects the form in whatever the compiler emitted.  The SRC2 position is rejected unmeasured; `op_sel:[1,0,0]` (676 instances in
+   the product library) and every `op_sel_hi = 0` broadcast are the forms all GPU tests run on.
 """
 import os
 import re
@@ -229,6 +239,38 @@ def check_all(obj):
     return res
 
 
+PK_F32 = re.compile(r"^(v_pk_(?:fma|mul|add)_f32)\b.*\bop_sel:\[(\d),(\d)(?:,(\d))?\]")
+
+
+def check_pk_opsel(obj):
+    """Rule 5 on one object -> (packed-fp32 instructions seen, [(kernel, address, instruction)] with op_sel set on SRC1 / SRC2)."""
+    total, bad = 0, []
+    for name, rows in functions(disassemble(obj)).items():
+        for addr, ins, _ in rows:
+            if not ins.startswith("v_pk_") or "_f32" not in ins.split()[0]:
+                continue
+            total += 1
+            m = PK_F32.match(ins)
+            if m and (m.group(3) == "1" or m.group(4) == "1"):
+                bad.append((name, addr, ins))
+    return total, bad
+
+
+def product_objects():
+    build = os.path.join(ROOT, "concepthash_amd", "csrc", "build")
+    sys.path.insert(0, ROOT)
+    from concepthash_amd.build import SOURCES
+    return [os.path.join(build, os.path.basename(s).replace(".hip", ".o")) for s in SOURCES]
+
+
+def has_device_code(obj):
+    try:
+        disassemble(obj)
+        return True
+    except RuntimeError:
+        return False
+
+
 def check(obj):
     """(number of DPP instructions checked, hazards): the round-2 interface, now over the CFG and with the EXEC rule."""
     r = check_all(obj)
@@ -236,6 +278,17 @@ def check(obj):
 
 
 if __name__ == "__main__":
+    if "--all" in sys.argv:      # rule 5 over every object of the product library
+        n_bad = 0
+        for o in product_objects():
+            if not has_device_code(o):
+                continue
+            t, b = check_pk_opsel(o)
+            for x in b[:10]:
+                print("PK OP_SEL:", x)
+            print(f"{os.path.basename(o)}: {t} packed-fp32 instructions, {len(b)} with op_sel on SRC1 / SRC2")
+            n_bad += len(b)
+        sys.exit(1 if n_bad else 0)
     obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "concepthash_amd", "csrc", "build", "hamming.o")
     r = check_all(obj)
     for x in r["dpp_bad"][:20]:
