@@ -220,15 +220,17 @@ void ch_gemm_set_variant(int v) { g_gemm_variant = v; }
 static int resid_nt_choice(const GemmParams &p, int epi) {
     if (epi != EPI_SCALE_RESID && epi != EPI_SCALE_RESID_STATS) return 0;
     if (const char *e = getenv("CH_RESID_NT")) return atoi(e) != 0;   // per call: the parity tests switch it inside one process
-    return (int64_t)p.M * p.N * 4 >= (48ll << 20);
+    return std::max<int64_t>(p.M, p.footprint_rows) * p.N * 4 >= (48ll << 20);
 }
 // bf16 outputs of the plain / LN-folded epilogues from this size up (fc1's 316 MB and qkv's 237 MB at batch 256: read once, by the
 // next kernel, out of HBM whatever the policy) are stored non-temporally by the 256x256 kernel, which leaves the caches to the
 // operands: 12.15 -> 11.99 ms per encode step (profiles/r03_cache_policy_ab.txt).  CH_NT_OUT=0 / 1 forces the choice.
 static int out_nt_choice(const GemmParams &p, int epi) {
-    if (epi != EPI_BIAS && epi != EPI_FOLD_BIAS && epi != EPI_FOLD_QUICKGELU && epi != EPI_FOLD_GELU) return 0;
+    if (epi != EPI_BIAS && epi != EPI_FOLD_BIAS && epi != EPI_FOLD_QUICKGELU && epi != EPI_FOLD_GELU && epi != EPI_FOLD_ACT2_QUICK &&
+        epi != EPI_FOLD_ACT2_GELU && epi != EPI_BIAS_DACT_QUICK && epi != EPI_BIAS_DACT_GELU)
+        return 0;
     if (const char *e = getenv("CH_NT_OUT")) return atoi(e) != 0;
-    return (int64_t)p.M * p.N * 2 >= (128ll << 20);
+    return std::max<int64_t>(p.M, p.footprint_rows) * p.N * 2 >= (128ll << 20);
 }
 int ch_gemm_bf16(const GemmParams &p0, int epi, hipStream_t s) {
     GemmParams p = p0;

@@ -272,7 +272,12 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
                     ow[j] = EPI == EPI_FOLD_ACT2_QUICK ? pack_bf16x2(quick_gelu_f(x0), quick_gelu_f(x1))
                                                        : pack_bf16x2(gelu_erf_f(x0), gelu_erf_f(x1));
                 }
-                if (m < p.M) *(uint4 *)(p.hb_out + (size_t)m * p.ld_hb + n_base + chunk * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                if (m < p.M) {
+                    uint4 *dst2 = (uint4 *)(p.hb_out + (size_t)m * p.ld_hb + n_base + chunk * 8);
+                    const uint4 w2 = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                    if constexpr (NTOUT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, w2), (u32x4_nt *)dst2);
+                    else *dst2 = w2;
+                }
             }
             if constexpr (T::stats) {  // partial (sum, sumsq) of this row's 64 rounded outputs: 8 lanes x 8 values
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};

@@ -506,7 +506,8 @@ int launch_pp_sched(GemmParams &p, int tiles, hipStream_t s) {
             return 0;
         }
     }
-    if constexpr ((EPI == EPI_BIAS || EPI == EPI_FOLD_BIAS || EPI == EPI_FOLD_QUICKGELU || EPI == EPI_FOLD_GELU) && SCHED == 0) {
+    if constexpr ((EPI == EPI_BIAS || EPI == EPI_FOLD_BIAS || EPI == EPI_FOLD_QUICKGELU || EPI == EPI_FOLD_GELU || EPI == EPI_FOLD_ACT2_QUICK ||
+                   EPI == EPI_FOLD_ACT2_GELU || EPI == EPI_BIAS_DACT_QUICK || EPI == EPI_BIAS_DACT_GELU) && SCHED == 0) {
         if (p.nt_out) {  // TAG 2: out_bf16 stored non-temporally (an output larger than the caches that is read once)
             static ch_once_per_device lds_once_n;
             if (int e = ch_func_max_lds((const void *)gemm_pp_kernel<EPI, 0, SCHED, 2>, lds, lds_once_n)) return e;

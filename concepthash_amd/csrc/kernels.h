@@ -61,6 +61,8 @@ struct GemmParams {
     int rev;                 // 1: walk the m-tiles from the last row tile to the first (serpentine launch order)
     int pp_sched;            // 256x256 kernel: 0 = four phases of 16 MFMAs per K-tile, 1 = two phases of 32 (gemm_pp.hip)
     int pp_min_k;            // dispatcher: smallest K that goes to the 256x256 ping-pong kernel (0 = default 512)
+    int64_t footprint_rows;  // rows of the same tensor that CONCURRENT launches (the other micro-batch chains) cover, this launch included; 0 = M.
+                             // What the cache-policy choice below is sized on: two chains of 128 images put the tensors of 256 images in flight
     int nt_resid;            // 1 = launch the instance with the non-temporal read-modify-write of the fp32 residual (set by the dispatcher)
     int nt_out;              // 1 = store out_bf16 non-temporally (an output larger than the Infinity Cache that is read once, much later)
     int tag;                 // profiling only: 1 = launch the 256x256 kernel under its second symbol name (gemm_pp.hip, TAG)

@@ -436,6 +436,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         GemmParams p{};
         p.tag = cat == CH_CAT_GEMM_FC2 ? 1 : 0;   // fc2 runs out_proj's kernel instance: second symbol name for per-kernel profiles
         p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi]; p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.small_kernel = mm->small_kernel; p.rev = next_dir();
+        p.footprint_rows = (int64_t)cur_rows * Btot / B;   // all concurrent chains of this call: what the cache-policy choice is sized on
         p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
         p.X = X; p.W = W; p.M = cur_rows; p.N = N; p.K = K; p.X_rows_alloc = m->rows_alloc; p.bias = bias;
