@@ -116,14 +116,19 @@ def test_batching_dtype_and_determinism(dev):
     enc.close()
 
 
-def test_forty_encodes_over_two_launch_chains_are_bit_identical(dev, monkeypatch):
+@pytest.mark.parametrize("cfg_name,pp_min_k", [("vit_s16", None), ("vit_b16", 256)])
+def test_forty_encodes_over_two_launch_chains_are_bit_identical(dev, monkeypatch, cfg_name, pp_min_k):
     """Run-to-run determinism under CONCURRENT launch chains (two streams share the CUs: the condition under which the
     `v_pk_fma_f32 ... op_sel:[0,1,0]` form of the LN-fold epilogue returned wrong quarter-wave lanes in round 3 -- 40 of 40 calls
-    differed then).  ViT-S/16 x 2 layers, 11 images in chunks of 4 (two chains of 2 images each), codes and
-    the hidden state after every layer, 40 calls each, all bit-identical to the first."""
+    differed then).  Two layers, 11 images in chunks of 4 (two chains of 2 images each), codes and the
+    hidden state after every layer, 40 calls each, all bit-identical to the first: ViT-S/16 on the 128x128 GEMM kernel (the
+    dispatcher's choice at this size) and ViT-B/16 with CH_GEMM_PP_MIN_K=256, which sends qkv / out_proj / fc1 / fc2 / the adapter
+    up-projections to the 256x256 ping-pong kernel."""
     from oracle import encoder_oracle as eo
     monkeypatch.setenv("CH_STREAMS", "2")
-    cfg = dict(eo.CONFIGS["vit_s16"])
+    if pp_min_k:
+        monkeypatch.setenv("CH_GEMM_PP_MIN_K", str(pp_min_k))
+    cfg = dict(eo.CONFIGS[cfg_name])
     cfg["L"] = 2
     sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
     x = eo.synthetic_images(11, cfg["image"]).to(dev)
