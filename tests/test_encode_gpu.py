@@ -146,6 +146,53 @@ def test_forty_encodes_over_two_launch_chains_are_bit_identical(dev, monkeypatch
     enc.close()
 
 
+def test_the_benchmark_batch_is_bit_identical_across_policies_chains_and_repeats(dev, monkeypatch):
+    """BASELINE.json's measured configuration at its full size -- ViT-B/16 x 12 layers, 64 bit, 256 images -- through size-independent
+    properties (an oracle run of this size takes minutes): the dispatcher's default here is the non-temporal residual instance for
+    the 24 up-projections and the non-temporal output instance for qkv / fc1 (counted through the dispatch taps); the same batch
+    with both policies forced off, as one launch chain instead of two, and twice more under the default must give the SAME codes,
+    packed words and pooled outputs bit for bit; and the packed words are the signs of the codes."""
+    from concepthash_amd import _lib
+    from oracle import encoder_oracle as eo
+    from oracle import hamming_oracle as ho
+    cfg = dict(eo.CONFIGS["vit_b16"])
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=200)
+    x = eo.synthetic_images(256, cfg["image"], seed=3).to(dev).to(torch.bfloat16)
+    lib = _lib.load()
+    want = ("codes", "packed", "logits_cont", "hash_features")
+    count = lambda: (lib.ch_debug_gemm_dispatch_count(2), lib.ch_debug_gemm_dispatch_count(3))
+    enc = _encoder(sd, cfg["heads"], max_batch=256)
+    c0 = count()
+    ref = {k: v.clone() for k, v in enc.encode(x, want=want).items()}
+    torch.cuda.synchronize()
+    c1 = count()
+    # two chains x (2 up-projections x 12 layers, the last layer's on compact rows falls below the size rule) ; qkv + fc1 per layer
+    assert c1[0] - c0[0] >= 2 * 22 and c1[1] - c0[1] >= 2 * 22, (c0, c1)
+    for _ in range(2):
+        again = enc.encode(x, want=want)
+        for k in want:
+            assert torch.equal(again[k], ref[k]), k
+    monkeypatch.setenv("CH_RESID_NT", "0")
+    monkeypatch.setenv("CH_NT_OUT", "0")
+    c2 = count()
+    off = enc.encode(x, want=want)
+    torch.cuda.synchronize()
+    assert count() == c2                                     # forced off: the default instances only
+    for k in want:
+        assert torch.equal(off[k], ref[k]), k
+    enc.close()
+    monkeypatch.delenv("CH_RESID_NT")
+    monkeypatch.delenv("CH_NT_OUT")
+    monkeypatch.setenv("CH_STREAMS", "1")
+    one = _encoder(sd, cfg["heads"], max_batch=256)
+    single = one.encode(x, want=want)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(single[k], ref[k]), k
+    one.close()
+    assert np.array_equal(ref["packed"].cpu().numpy().view(np.uint64), ho.pack(ref["codes"].cpu().numpy()))
+
+
 def test_errors_are_loud(dev):
     from oracle import encoder_oracle as eo
     cfg = dict(eo.CONFIGS["vit_s16"])
