@@ -30,7 +30,9 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 16 KiB
-constexpr int NSTAGE = 4;
+// NS (template): 4 = the ring above (64 KB, two workgroups per CU); 2 = one K-step in flight, 32 KB of LDS and <= 128 VGPRs so that FOUR
+// workgroups share a CU (bf16-output epilogues only: their staging is 8 KB per wave) -- the occupancy experiment of round 3
+// (CH_R4_STAGES=2; the bandwidth-bound adapter launches lose 24-34 % when a CU holds one workgroup instead of two).
 constexpr int NTHREADS = 256;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -42,8 +44,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + local;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_r4_kernel(GemmParams p) {
+template <int EPI, int NSTAGE>
+__global__ __launch_bounds__(NTHREADS, NSTAGE == 2 ? 4 : 2) void gemm_r4_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,12 +98,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_r4_kernel(GemmParams p) {
     ch_epi::ResidPrefetch rp;
     if constexpr (PREF) ch_epi::resid_prefetch<EPI>(p, m0 + wm * 64, n0 + wn * 64, lane, rp);  // arrives under the K loop
     stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (nk > 2) stage(2, 2);
+    if (NSTAGE > 2 && nk > 1) stage(1, 1);
+    if (NSTAGE > 2 && nk > 2) stage(2, 2);
     if constexpr (ch_epi::traits<EPI>::fold) {
-        // the statistics loads are older than the three stages: retire them (and nothing else) with a counted wait
-        if (nk > 2)
+        // the statistics loads are older than the stages: retire them (and nothing else) with a counted wait
+        if (NSTAGE > 2 && nk > 2)
             asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (NSTAGE == 2)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -110,17 +114,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_r4_kernel(GemmParams p) {
 
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = nk - 1 - kt;  // stages issued after stage kt that may still be in flight: min(2, ahead)
-        if (ahead >= 2)
+        const int ahead = nk - 1 - kt;  // stages issued after stage kt that may still be in flight: min(NSTAGE - 2, ahead)
+        if (NSTAGE > 2 && ahead >= 2)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1)
+        else if (NSTAGE > 2 && ahead == 1)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 3 < nk) stage((buf + 3) & 3, kt + 3);
+        if (kt + NSTAGE - 1 < nk) stage((buf + NSTAGE - 1) & (NSTAGE - 1), kt + NSTAGE - 1);
         const char *sb = smem + buf * STAGE_BYTES;
         bf16x8 wf[4], xf[4];
 #pragma unroll
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_r4_kernel(GemmParams p) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        buf = (buf + 1) & 3;
+        buf = (buf + 1) & (NSTAGE - 1);
     }
     // every LDS-DMA has landed (vmcnt(0) in the last iteration); wait until every wave has finished its last fragment reads
     // (and, PREF, until the prefetched residual has arrived: it is older than the stages and was retired by the loop's waits)
@@ -141,19 +145,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_r4_kernel(GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    ch_epi::store_tile<EPI, 4, PREF>(p, acc, smem + wid * 16384, m0 + wm * 64, n0 + wn * 64, lane,
+    ch_epi::store_tile<EPI, 4, PREF>(p, acc, smem + wid * (NSTAGE == 2 ? 8192 : 16384), m0 + wm * 64, n0 + wn * 64, lane,
                                      (const float *)(smem + NSTAGE * STAGE_BYTES) + 2 * (wm * 64), &rp);
 }
 
-template <int EPI>
+template <int EPI, int NSTAGE = 4>
 int launch_r4(const GemmParams &p0, hipStream_t s) {
     GemmParams p = p0;
     p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     constexpr int lds = NSTAGE * STAGE_BYTES + (ch_epi::traits<EPI>::fold ? CH_FOLD_LDS_BYTES : 0);
     static ch_once_per_device lds_once;
-    if (int e = ch_func_max_lds((const void *)gemm_r4_kernel<EPI>, lds, lds_once)) return e;
-    hipLaunchKernelGGL(gemm_r4_kernel<EPI>, dim3(tiles), dim3(NTHREADS), lds, s, p);
+    if (int e = ch_func_max_lds((const void *)gemm_r4_kernel<EPI, NSTAGE>, lds, lds_once)) return e;
+    hipLaunchKernelGGL((gemm_r4_kernel<EPI, NSTAGE>), dim3(tiles), dim3(NTHREADS), lds, s, p);
     CH_LAUNCH_CHECK();
     return 0;
 }
@@ -168,6 +172,17 @@ int ch_gemm_bf16_r4(const GemmParams &p, int epi, hipStream_t s) {
     CH_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem");
     CH_REQUIRE(epi == EPI_PATCH || p.bias != nullptr, "gemm: bias is required");
     CH_REQUIRE(ch_gemm_r4_supported(p), "gemm_r4: needs N % 128 == 0, K % 32 == 0, K >= 96, X padded to 128 rows");
+    static const int two = getenv("CH_R4_STAGES") && atoi(getenv("CH_R4_STAGES")) == 2;
+    if (two && ch_epi::traits<EPI_BIAS>::bf16_only) {   // bf16-output epilogues: the four-workgroups-per-CU instance
+        switch (epi) {
+            case EPI_BIAS: return launch_r4<EPI_BIAS, 2>(p, s);
+            case EPI_BIAS_GELU: return launch_r4<EPI_BIAS_GELU, 2>(p, s);
+            case EPI_BIAS_STATS: return launch_r4<EPI_BIAS_STATS, 2>(p, s);
+            case EPI_FOLD_BIAS: return launch_r4<EPI_FOLD_BIAS, 2>(p, s);
+            case EPI_FOLD_GELU: return launch_r4<EPI_FOLD_GELU, 2>(p, s);
+            default: break;
+        }
+    }
     switch (epi) {
         case EPI_BIAS: return launch_r4<EPI_BIAS>(p, s);
         case EPI_BIAS_QUICKGELU: return launch_r4<EPI_BIAS_QUICKGELU>(p, s);
