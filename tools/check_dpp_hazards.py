@@ -2,7 +2,8 @@
 """Static checks of the hand-placed instructions of csrc/hamming.hip on the BUILT object (the mAP scans: DPP row-broadcast xor,
 inline-asm VMEM ring behind counted `s_waitcnt vmcnt(N)`), over the control-flow graph of every kernel, not the listing order.
 
-    python tools/check_dpp_hazards.py [path/to/hamming.o]          exit status 0 = clean
+    python tools/check_dpp_hazards.py [path/to/hamming.o]          exit status 0 = clean   (rules 1-4)
+    python tools/check_dpp_hazards.py --all                        rules 1-4 on hamming.o + rule 5 on every object of the product library
 
 1. DPP read after VALU write (gfx9: 2 wait states, no hardware interlock): no VALU instruction writes a DPP instruction's source
    VGPR within the two wait states in front of it, along ANY path into it (branch targets and loop back-edges included).  The
@@ -288,7 +289,10 @@ if __name__ == "__main__":
                 print("PK OP_SEL:", x)
             print(f"{os.path.basename(o)}: {t} packed-fp32 instructions, {len(b)} with op_sel on SRC1 / SRC2")
             n_bad += len(b)
-        sys.exit(1 if n_bad else 0)
+        r = check_all(os.path.join(ROOT, "concepthash_amd", "csrc", "build", "hamming.o"))      # rules 1-4 on the map scans
+        print(f"hamming.o: {r['dpp_total']} DPP instructions, {len(r['dpp_bad'])} hazards; {r['vmem_loads']} ring loads, {len(r['vmem_bad'])} "
+              f"uses before the covering wait; {len(r['scratch_bad'])} scratch instructions in the map scans")
+        sys.exit(1 if (n_bad or r["dpp_bad"] or r["vmem_bad"] or r["scratch_bad"]) else 0)
     obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "concepthash_amd", "csrc", "build", "hamming.o")
     r = check_all(obj)
     for x in r["dpp_bad"][:20]:
