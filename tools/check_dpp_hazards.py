@@ -18,15 +18,15 @@ inline-asm VMEM ring behind counted `s_waitcnt vmcnt(N)`), over the control-flow
    spill or re-use of a ring register, or a compiler wait that counted only its own loads.
 4. No scratch traffic (register spills) in any `map_scan_kernel` instantiation.
 5. (every object, `--all` / check_pk_opsel) No packed-fp32 VALU instruction (`v_pk_fma_f32`, `v_pk_mul_f32`, `v_pk_add_f32`) whose
-   `op_sel` routes the HIGH half of SRC1 or SRC2 into the low lane (`op_sel:[x,1,x]` / `[x,x,1]`).  Measured on MI355X in round 3
-   (profiles/r03_pk_opsel_hazard.txt): `v_pk_fma_f32 D, acc, ms, C op_sel:[0,1,0]` in the LN-fold epilogue
-   of the 128x128 GEMM returned a wrong low lane for one quarter-wave (16 lanes x 1 VGPR), intermittently, whenever a second
-   launch chain shared the CUs -- 40 of 40 encode calls differed run to run -- with or without wait states in front of it; the
-   same product written `ms, acc op_sel:[1,0,0]`, with a splat pair and no op_sel, or with the scalar in the low half and
-   op_sel_hi = 0 never failed.  Which form the compiler picks for `vector * pair.hi` follows its operand canonicalisation (it flipped
-   when the kernel body moved into an inlined function), so the product sources keep such scalars in LOW halves and this check
-   rejects the form in whatever the compiler emitted.  The SRC2 position is rejected unmeasured; `op_sel:[1,0,0]` (676 instances in
-   the product library) and every `op_sel_hi = 0` broadcast are the forms all GPU tests run on.
+   `op_sel` routes the HIGH half of SRC1 into the low lane (`op_sel:[x,1]` / `[x,1,x]`).  Measured on MI355X in round 3 (DESIGN.md
+   section 3.10, profiles/r03_pk_opsel_hazard.txt, tools/pk_opsel_repro.py): that spelling returns a wrong LOW lane, intermittently,
+   whenever a wave of ANOTHER kernel executes MFMAs on the same SIMD -- first seen as one wrong output column x 16 rows of the LN-fold
+   GEMM epilogues under two launch chains, then reproduced stand-alone (a VALU-only victim kernel next to an MFMA-only co-tenant:
+   ~1e5 wrong results per 1e12; 0 alone; 0 next to LDS-DMA / ds_read / VALU / global-memory / barrier co-tenants), for all three
+   opcodes, with or without op_sel_hi.  SRC0's and SRC2's high half (`op_sel:[1,0,0]`, `[0,0,1]`) and every `op_sel_hi = 0` broadcast
+   are exact under the same co-tenant (tests/test_isa_forms_gpu.py).  Which spelling the compiler picks for `vector * pair.hi` follows
+   its operand canonicalisation (it flipped when a kernel body moved into an inlined function), so the product sources keep such
+   scalars in LOW halves and this check rejects the spelling in whatever the compiler emitted.
 """
 import os
 import re
@@ -244,7 +244,7 @@ PK_F32 = re.compile(r"^(v_pk_(?:fma|mul|add)_f32)\b.*\bop_sel:\[(\d),(\d)(?:,(\d
 
 
 def check_pk_opsel(obj):
-    """Rule 5 on one object -> (packed-fp32 instructions seen, [(kernel, address, instruction)] with op_sel set on SRC1 / SRC2)."""
+    """Rule 5 on one object -> (packed-fp32 instructions seen, [(kernel, address, instruction)] with op_sel set on SRC1)."""
     total, bad = 0, []
     for name, rows in functions(disassemble(obj)).items():
         for addr, ins, _ in rows:
@@ -252,7 +252,7 @@ def check_pk_opsel(obj):
                 continue
             total += 1
             m = PK_F32.match(ins)
-            if m and (m.group(3) == "1" or m.group(4) == "1"):
+            if m and m.group(3) == "1":
                 bad.append((name, addr, ins))
     return total, bad
 
@@ -287,7 +287,7 @@ if __name__ == "__main__":
             t, b = check_pk_opsel(o)
             for x in b[:10]:
                 print("PK OP_SEL:", x)
-            print(f"{os.path.basename(o)}: {t} packed-fp32 instructions, {len(b)} with op_sel on SRC1 / SRC2")
+            print(f"{os.path.basename(o)}: {t} packed-fp32 instructions, {len(b)} with op_sel on SRC1")
             n_bad += len(b)
         r = check_all(os.path.join(ROOT, "concepthash_amd", "csrc", "build", "hamming.o"))      # rules 1-4 on the map scans
         print(f"hamming.o: {r['dpp_total']} DPP instructions, {len(r['dpp_bad'])} hazards; {r['vmem_loads']} ring loads, {len(r['vmem_bad'])} "

@@ -1,0 +1,152 @@
+// Victim kernel of tools/pk_opsel_repro.py: the packed-fp32 FMA of the LN-fold epilogue in isolation.
+//   form 1: v_pk_fma_f32 D, acc, ms, C op_sel:[0,1,0]   (high half of SRC1 into the low lane: the form measured wrong)
+//   form 2: v_pk_fma_f32 D, ms, acc, C op_sel:[1,0,0]   (high half of SRC0 into the low lane: the form that never failed)
+//   forms 3-8: SRC2 high half, v_pk_mul / v_pk_add with SRC1 high half, SRC1 low broadcast (op_sel_hi = 0), SRC1 halves swapped,
+//              v_pk_mul with SRC0 high half -- see the kernel
+// Every result is compared, bit for bit, with two scalar v_fma_f32 of the same operands; mismatching lane-iterations are counted.
+// Light on purpose (no MFMA, 8 KB of LDS, < 64 VGPRs): its workgroups co-reside with whatever else runs on the CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int FORM>
+__global__ __launch_bounds__(256) void victim_kernel(int iters, unsigned long long *mism, unsigned long long *first_bad) {
+    __shared__ f32x2 table[1024];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 1024; i += 256) {
+        const float mean = 0.001f * (float)((i * 37) % 997) - 0.5f, rstd = 0.5f + 0.002f * (float)((i * 61) % 1009);
+        table[i] = f32x2{mean, rstd};
+    }
+    __syncthreads();
+    f32x2 a = {1.0f + 0.001f * tid, -0.5f + 0.002f * tid}, c = {0.25f, -0.75f};
+    unsigned long long bad = 0, bad_lo = 0;
+    uint32_t idx = tid * 7u + blockIdx.x * 13u;
+    for (int it = 0; it < iters; ++it) {
+        const f32x2 ms = table[idx & 1023u];            // ds_read_b64: (mean, rstd) as the epilogue reads it
+        idx = idx * 1664525u + 1013904223u;
+        // the register pair as a 64-bit scalar operand (element extraction from a 2-vector asm output read the low register twice)
+        unsigned long long r;
+        const unsigned long long a64 = __builtin_bit_cast(unsigned long long, a), ms64 = __builtin_bit_cast(unsigned long long, ms),
+                                 c64 = __builtin_bit_cast(unsigned long long, c);
+        float e0, e1;
+        if (FORM == 1) {          // SRC1 high half -> low lane
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(r) : "v"(a64), "v"(ms64), "v"(c64));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e0) : "v"(a[0]), "v"(ms[1]), "v"(c[0]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e1) : "v"(a[1]), "v"(ms[1]), "v"(c[1]));
+        } else if (FORM == 2) {   // SRC0 high half -> low lane (same values)
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(r) : "v"(ms64), "v"(a64), "v"(c64));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e0) : "v"(a[0]), "v"(ms[1]), "v"(c[0]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e1) : "v"(a[1]), "v"(ms[1]), "v"(c[1]));
+        } else if (FORM == 3) {   // SRC2 high half -> low lane
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(r) : "v"(a64), "v"(c64), "v"(ms64));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e0) : "v"(a[0]), "v"(c[0]), "v"(ms[1]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e1) : "v"(a[1]), "v"(c[1]), "v"(ms[1]));
+        } else if (FORM == 4) {   // v_pk_mul_f32, SRC1 high half -> low lane
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a64), "v"(ms64));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(e0) : "v"(a[0]), "v"(ms[1]));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(e1) : "v"(a[1]), "v"(ms[1]));
+        } else if (FORM == 5) {   // v_pk_add_f32, SRC1 high half -> low lane
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a64), "v"(ms64));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(e0) : "v"(a[0]), "v"(ms[1]));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(e1) : "v"(a[1]), "v"(ms[1]));
+        } else if (FORM == 6) {   // SRC1 LOW half broadcast by op_sel_hi = 0 (what the compiler emits for a scalar in a low half)
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a64), "v"(ms64), "v"(c64));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e0) : "v"(a[0]), "v"(ms[0]), "v"(c[0]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e1) : "v"(a[1]), "v"(ms[0]), "v"(c[1]));
+        } else if (FORM == 7) {   // SRC1 halves swapped: high -> low lane, low -> high lane
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a64), "v"(ms64), "v"(c64));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e0) : "v"(a[0]), "v"(ms[1]), "v"(c[0]));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(e1) : "v"(a[1]), "v"(ms[0]), "v"(c[1]));
+        } else {                  // 8: v_pk_mul_f32, SRC0 high half -> low lane
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(ms64), "v"(a64));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(e0) : "v"(a[0]), "v"(ms[1]));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(e1) : "v"(a[1]), "v"(ms[1]));
+        }
+        const bool b = (uint32_t)r != __builtin_bit_cast(uint32_t, e0) || (uint32_t)(r >> 32) != __builtin_bit_cast(uint32_t, e1);
+        const bool blo = (uint32_t)r != __builtin_bit_cast(uint32_t, e0);
+        bad_lo += blo ? 1ull : 0ull;
+        bad += b ? 1ull : 0ull;
+        // keep the operands moving and finite
+        a[0] = a[0] * 0.999f + 0.013f;
+        a[1] = a[1] * 0.998f - 0.007f;
+        c[0] = (FORM == 4 || FORM == 5 || FORM == 8 ? c[0] * 0.9f : e0 * 0.5f) + 0.1f;
+        c[1] = (FORM == 4 || FORM == 5 || FORM == 8 ? c[1] * 0.9f : e1 * 0.5f) - 0.1f;
+    }
+    if (bad) {
+        atomicAdd(mism, bad);
+        atomicAdd(first_bad, bad_lo);      // second counter: mismatches whose LOW lane is wrong
+    }
+}
+
+extern "C" int pk_victim_launch(int form, int blocks, int iters, unsigned long long *mism, unsigned long long *first_bad, void *stream) {
+#define PK_CASE(F) case F: hipLaunchKernelGGL(victim_kernel<F>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, mism, first_bad); break;
+    switch (form) {
+        PK_CASE(1) PK_CASE(2) PK_CASE(3) PK_CASE(4) PK_CASE(5) PK_CASE(6) PK_CASE(7) PK_CASE(8)
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+
+// ---- synthetic co-tenants (tools/pk_opsel_repro.py --synthetic): one instruction class each, 256 threads, 32 KB of LDS, < 128 VGPRs, so that
+// their workgroups share CUs (and SIMDs) with the victim's.  mode: 1 MFMA only | 2 LDS-DMA (global_load_lds) | 3 ds_read_b128 |
+// 4 packed-fp32 VALU | 5 global loads to VGPRs + stores | 6 MFMA fed by ds_read_b128 | 7 s_barrier | 8 ds_write_b64 + ds_read_b128
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__global__ __launch_bounds__(256) void cotenant_kernel(int mode, int iters, const float *__restrict__ src, float *__restrict__ dst, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const size_t base = ((size_t)blockIdx.x * 256 + tid) * 4;
+    f32x4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    bf16x8_t fa, fb;
+    for (int i = 0; i < 8; ++i) {
+        fa[i] = (__bf16)(0.01f * (tid + i));
+        fb[i] = (__bf16)(0.02f * (tid - i));
+    }
+    float4 *l4 = (float4 *)smem;
+    for (int i = tid; i < 2048; i += 256) l4[i] = make_float4(i, 1.f, 2.f, 3.f);
+    __syncthreads();
+    f32x4_t v = {1.f, 2.f, 3.f, 4.f};
+    for (int it = 0; it < iters; ++it) {
+        if (mode == 1 || mode == 6) {
+            if (mode == 6) {
+                const float4 t = l4[(tid + it * 17) & 2047];
+                fa = __builtin_bit_cast(bf16x8_t, t);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[j], 0, 0, 0);
+        } else if (mode == 2) {
+            const size_t off = (base + (size_t)it * 262144) % (n - 1024);
+            __builtin_amdgcn_global_load_lds((gbl_void_t *)(src + (off & ~(size_t)3)), (lds_void_t *)(smem + (it & 7) * 4096), 16, 0, 0);
+            if ((it & 7) == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (mode == 3) {
+            const float4 t = l4[(tid * 3 + it) & 2047];
+            v[0] += t.x;
+            v[1] += t.y;
+        } else if (mode == 4) {
+            v = v * 1.0001f + 0.5f;
+        } else if (mode == 5) {
+            const size_t off = (base + (size_t)it * 262144) % (n - 1024);
+            const float4 t = *(const float4 *)(src + (off & ~(size_t)3));
+            *(float4 *)(dst + (off & ~(size_t)3)) = make_float4(t.x + 1.f, t.y, t.z, t.w);
+        } else if (mode == 7) {
+            __syncthreads();
+            v[0] += 1.f;
+        } else if (mode == 8) {
+            *(float2 *)(smem + ((tid * 8 + it * 64) & 32767)) = make_float2(v[0], v[1]);
+            const float4 t = l4[(tid * 5 + it) & 2047];
+            v[2] += t.z;
+        }
+    }
+    if (mode == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float s = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + v[0] + v[1] + v[2] + v[3];
+    if (s == 12345.678f) dst[tid] = s;
+}
+
+extern "C" int pk_cotenant_launch(int mode, int blocks, int iters, const float *src, float *dst, size_t n, void *stream) {
+    hipLaunchKernelGGL(cotenant_kernel, dim3(blocks), dim3(256), 32768, (hipStream_t)stream, mode, iters, src, dst, n);
+    return (int)hipGetLastError();
+}
