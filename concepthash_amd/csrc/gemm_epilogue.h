@@ -211,9 +211,10 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, f32x4 (&acc)[4][
             if constexpr (T::fold) {
                 // The table holds (rstd, mean), rstd FIRST: the scalar every accumulator is multiplied by then sits in the LOW half of
                 // the loaded register pair and the compiler broadcasts it with op_sel_hi = 0.  With (mean, rstd) it selects the high
-                // half with op_sel = 1, and `v_pk_fma_f32 D, acc, ms, C op_sel:[0,1,0]` (high half of SRC1 into the low lane) returns,
-                // intermittently, a wrong low lane for 16 lanes when another kernel shares the CU -- measured on MI355X, not cured
-                // by wait states (tools/check_dpp_hazards.py rejects the form in every built kernel).
+                // half with op_sel = 1, and `v_pk_fma_f32 D, acc, ms, C op_sel:[0,1,0]` (high half of SRC1 into the low lane) returns a
+                // wrong low lane, about once per 1e7 executions, while a wave of ANOTHER kernel executes MFMAs on the same SIMD --
+                // measured on MI355X, reproduced stand-alone (tools/pk_opsel_repro.py), not cured by wait states (DESIGN.md section
+                // 3.10; tools/check_dpp_hazards.py rejects the spelling in every built kernel).
                 const ch_f32x2_t ms = *(const ch_f32x2_t *)(row_ms + 2 * row);
                 rs = ms[0];
                 nm = -ms[1] * ms[0];
