@@ -56,7 +56,8 @@ def measure(form, cotenant_mode=1, seconds=0.5, blocks=2048, iters=20000, vic=No
         if launches % 4 == 0:
             s_vic.synchronize()
     torch.cuda.synchronize()
-    return int(mism.item()), int(low.item()), launches * blocks * 256 * iters
+    checking = 0.5 if form > 10 else 1.0                     # MIX forms: half the waves check, the other half issue MFMAs
+    return int(mism.item()), int(low.item()), int(launches * blocks * 256 * iters * checking)
 
 
 def main():
@@ -64,7 +65,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--blocks", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=20000)
-    ap.add_argument("--form", type=int, default=0, help="1..8: only that spelling; -1: all eight (default: 1 and 2)")
+    ap.add_argument("--form", type=int, default=0, help="1..8: only that spelling (+10: with MFMA-issuing odd waves in the same workgroups); -1: all (default: 1 and 2)")
     ap.add_argument("--synthetic", action="store_true", help="only the synthetic single-instruction-class co-tenants")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -159,6 +160,7 @@ def main():
     todo = aggressors + singles + synth if not a.synthetic else [aggressors[0]] + synth
     if a.form < 0:
         todo = [aggressors[0], synth[0]]          # all spellings: alone and next to the MFMA-only co-tenant
+        forms = tuple(range(1, 9)) + tuple(range(11, 19))   # ... and with MFMA-issuing waves inside the victim's own workgroups
     for form in forms:
         for fn, label in todo:
             run(form, fn, label)

@@ -3,14 +3,18 @@
 //   form 2: v_pk_fma_f32 D, ms, acc, C op_sel:[1,0,0]   (high half of SRC0 into the low lane: the form that never failed)
 //   forms 3-8: SRC2 high half, v_pk_mul / v_pk_add with SRC1 high half, SRC1 low broadcast (op_sel_hi = 0), SRC1 halves swapped,
 //              v_pk_mul with SRC0 high half -- see the kernel
+//   form + 10 (MIX): the odd waves of every workgroup issue back-to-back MFMAs instead, so MFMA waves and checking waves share SIMDs by
+//              construction, whatever else runs on the chip
 // Every result is compared, bit for bit, with two scalar v_fma_f32 of the same operands; mismatching lane-iterations are counted.
 // Light on purpose (no MFMA, 8 KB of LDS, < 64 VGPRs): its workgroups co-reside with whatever else runs on the CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_v;
+typedef float f32x4_v __attribute__((ext_vector_type(4)));
 
-template <int FORM>
+template <int FORM, bool MIX>
 __global__ __launch_bounds__(256) void victim_kernel(int iters, unsigned long long *mism, unsigned long long *first_bad) {
     __shared__ f32x2 table[1024];
     const int tid = threadIdx.x;
@@ -19,6 +23,19 @@ __global__ __launch_bounds__(256) void victim_kernel(int iters, unsigned long lo
         table[i] = f32x2{mean, rstd};
     }
     __syncthreads();
+    if (MIX && ((tid >> 6) & 1)) {   // MIX: the odd waves of the SAME workgroup issue MFMAs, the even ones run the spelling under test
+        bf16x8_v fa, fb;
+        for (int i = 0; i < 8; ++i) {
+            fa[i] = (__bf16)(0.01f * (tid + i));
+            fb[i] = (__bf16)(0.02f * (tid - i));
+        }
+        f32x4_v acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[j], 0, 0, 0);
+        if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) atomicAdd(mism, 1ull);
+        return;
+    }
     f32x2 a = {1.0f + 0.001f * tid, -0.5f + 0.002f * tid}, c = {0.25f, -0.75f};
     unsigned long long bad = 0, bad_lo = 0;
     uint32_t idx = tid * 7u + blockIdx.x * 13u;
@@ -80,7 +97,9 @@ __global__ __launch_bounds__(256) void victim_kernel(int iters, unsigned long lo
 }
 
 extern "C" int pk_victim_launch(int form, int blocks, int iters, unsigned long long *mism, unsigned long long *first_bad, void *stream) {
-#define PK_CASE(F) case F: hipLaunchKernelGGL(victim_kernel<F>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, mism, first_bad); break;
+// form 1..8 = the spelling alone in the kernel; form + 10 = the same with MFMA-issuing odd waves in the same workgroups
+#define PK_CASE(F) case F: hipLaunchKernelGGL((victim_kernel<F, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, mism, first_bad); break; \
+                   case F + 10: hipLaunchKernelGGL((victim_kernel<F, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, mism, first_bad); break;
     switch (form) {
         PK_CASE(1) PK_CASE(2) PK_CASE(3) PK_CASE(4) PK_CASE(5) PK_CASE(6) PK_CASE(7) PK_CASE(8)
         default: return -1;
