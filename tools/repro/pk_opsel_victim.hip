@@ -169,3 +169,110 @@ extern "C" int pk_cotenant_launch(int mode, int blocks, int iters, const float *
     hipLaunchKernelGGL(cotenant_kernel, dim3(blocks), dim3(256), 32768, (hipStream_t)stream, mode, iters, src, dst, n);
     return (int)hipGetLastError();
 }
+
+// ---- exactness of OTHER instruction classes next to MFMA-issuing waves (tools/pk_opsel_repro.py --classes) -------------------------------
+// The even waves of every workgroup run `iters` iterations of one instruction class on fixed inputs and leave a 64-bit checksum per lane; the
+// odd waves either exit at once (MIX = false) or issue back-to-back MFMAs (MIX = true).  Same inputs, same instruction stream: any checksum
+// that differs between the two launches is the hardware.  OP: 1 v_pk_fma_f32 (no op_sel) | 2 v_pk_mul_f32 op_sel_hi:[1,0] + v_pk_add_f32
+// op_sel_hi:[0,1] | 3 v_cvt_pk_bf16_f32 | 4 v_exp_f32 + v_rcp_f32 | 5 DPP: v_mov_b32_dpp quad_perm + v_xor_b32_dpp row_newbcast | 6 v_bcnt_u32_b32
+// chain | 7 ds_write_b64 + ds_read_b128 round trip | 8 integer VALU (v_add_u32, v_lshl_or_b32, v_min_u32 / v_max_u32, v_cndmask) |
+// 9 scalar v_fma_f32 / v_mul / v_add | 10 POSITIVE CONTROL: v_pk_fma_f32 op_sel:[0,1,0]
+template <int OP, bool MIX>
+__global__ __launch_bounds__(256) void class_kernel(int iters, unsigned long long *__restrict__ sums) {
+    __shared__ __attribute__((aligned(16))) float lds[256 * 8];
+    const int tid = threadIdx.x;
+    if ((tid >> 6) & 1) {
+        if (!MIX) return;
+        bf16x8_v fa, fb;
+        for (int i = 0; i < 8; ++i) {
+            fa[i] = (__bf16)(0.01f * (tid + i));
+            fb[i] = (__bf16)(0.02f * (tid - i));
+        }
+        f32x4_v acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[j], 0, 0, 0);
+        if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) sums[0] = 1;
+        return;
+    }
+    unsigned long long sum = 0;
+    for (int i = 0; i < 8; ++i) lds[tid * 8 + i] = 0.5f * i;     // a lane only ever touches its own eight floats
+    f32x2 a = {1.0f + 0.001f * tid, -0.5f + 0.002f * tid}, b = {0.75f + 0.0005f * tid, 1.25f - 0.0007f * tid}, c = {0.25f, -0.75f};
+    uint32_t u = 0x9E3779B9u * (tid + 1) + blockIdx.x, w = 0x85EBCA6Bu ^ (uint32_t)tid;
+    for (int it = 0; it < iters; ++it) {
+        if (OP == 1) {
+            unsigned long long r;
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(__builtin_bit_cast(unsigned long long, a)), "v"(__builtin_bit_cast(unsigned long long, b)),
+                         "v"(__builtin_bit_cast(unsigned long long, c)));
+            sum += r;
+            c = __builtin_bit_cast(f32x2, r) * 0.5f + 0.1f;
+        } else if (OP == 2) {
+            unsigned long long r, q;
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(__builtin_bit_cast(unsigned long long, a)), "v"(__builtin_bit_cast(unsigned long long, b)));
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(q) : "v"(r), "v"(__builtin_bit_cast(unsigned long long, c)));
+            sum += q;
+            c = __builtin_bit_cast(f32x2, q) * 0.25f;
+        } else if (OP == 3) {
+            uint32_t r;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a[0]), "v"(c[1]));
+            sum += r;
+            c[1] = c[1] * 0.999f + 0.01f;
+        } else if (OP == 4) {
+            float e, r;
+            asm volatile("v_exp_f32 %0, %1" : "=v"(e) : "v"(c[0]));
+            const float d = 1.0f + e;
+            asm volatile("v_rcp_f32 %0, %1" : "=v"(r) : "v"(d));
+            sum += __builtin_bit_cast(uint32_t, r);
+            c[0] = r * 2.0f - 1.0f + 0.001f * (it & 15);
+        } else if (OP == 5) {
+            uint32_t r, q;
+            asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(u));
+            asm volatile("s_nop 1\n\tv_xor_b32_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "=v"(q) : "v"(r), "v"(w));
+            sum += q;
+            u = u * 1664525u + 1013904223u;
+            w ^= q >> 3;
+        } else if (OP == 6) {
+            uint32_t r;
+            asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(w & 255u));
+            sum += r;
+            u = u * 1664525u + 1013904223u;
+            w += r;
+        } else if (OP == 7) {
+            *(float2 *)(lds + tid * 8 + (it & 3) * 2) = make_float2(a[0], c[1]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const float4 t = *(const float4 *)(lds + tid * 8 + ((it & 1) * 4));
+            sum += __builtin_bit_cast(uint32_t, t.x) + __builtin_bit_cast(uint32_t, t.y);
+            a[0] = a[0] * 0.999f + 0.013f;
+            c[1] = c[1] * 0.998f - 0.007f;
+        } else if (OP == 8) {
+            const uint32_t k = (u << 9) | (w & 511u);
+            const uint32_t lo = k < w ? k : w, hi = k < w ? w : k;
+            sum += lo + (hi >> 1);
+            u = u * 1664525u + 1013904223u;
+            w = w * 22695477u + 1u + (lo & 1u);
+        } else if (OP == 9) {
+            float r;
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a[0]), "v"(b[1]), "v"(c[0]));
+            sum += __builtin_bit_cast(uint32_t, r);
+            c[0] = r * 0.5f + 0.1f;
+        } else {
+            unsigned long long r;
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(r) : "v"(__builtin_bit_cast(unsigned long long, a)), "v"(__builtin_bit_cast(unsigned long long, b)),
+                         "v"(__builtin_bit_cast(unsigned long long, c)));
+            sum += r;
+            c = __builtin_bit_cast(f32x2, r) * 0.5f + 0.1f;
+        }
+        a[0] = a[0] * 0.9999f + 0.0001f;
+    }
+    sums[(size_t)blockIdx.x * 256 + tid] = sum;
+}
+
+extern "C" int pk_class_launch(int op, int mix, int blocks, int iters, unsigned long long *sums, void *stream) {
+#define CL_CASE(O) case O: if (mix) hipLaunchKernelGGL((class_kernel<O, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sums); \
+                           else hipLaunchKernelGGL((class_kernel<O, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, sums); break;
+    switch (op) {
+        CL_CASE(1) CL_CASE(2) CL_CASE(3) CL_CASE(4) CL_CASE(5) CL_CASE(6) CL_CASE(7) CL_CASE(8) CL_CASE(9) CL_CASE(10)
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
