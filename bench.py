@@ -143,15 +143,16 @@ def main():
     t_setup = time.perf_counter()
     sd = syn.synthetic_state_dict(cfg, nbit=NBIT, nclass=NCLASS, seed=42)
     log(f"[bench r{rank}] synthetic weights ready ({time.perf_counter() - t_setup:.1f} s)")
-    os.environ["CH_STREAMS"] = str(args.streams)
-    enc = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=B, device=dev)
+    enc = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=B, device=dev, options={"streams": args.streams})
     log(f"[bench r{rank}] model on device: {enc.device_bytes / 2**20:.0f} MiB ({time.perf_counter() - t_setup:.1f} s)")
     images = syn.synthetic_images(B, cfg["image"], seed=42 + rank).to(dev).to(torch.bfloat16)
     g_np, gl_np = syn.synthetic_codes(GALLERY_ROWS, NBIT, seed=1234 + rank, nclass=NCLASS)
     gallery = torch.from_numpy(g_np.view(np.int64)).to(dev)
     W = gallery.shape[1]
 
-    def make_step(encoder):
+    def make_step(encoder, images=images):
+        B = images.shape[0]
+
         def step():
             out = encoder.encode(images, want=("codes", "packed"))
             q = out["packed"]
@@ -186,22 +187,28 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_info = None
     if world > 1:
+        own_elapsed = elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what each rank ran on, from the ranks themselves: the line proves its own topology (device, architecture, bus id, timing)
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device": props.name, "gcn_arch": getattr(props, "gcnArchName", ""),
+                "pci_bus_id": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:"
+                              f"{getattr(props, 'pci_device_id', 0):02x}",
+                "ms_per_step": round(own_elapsed / args.steps * 1e3, 3), "pid": os.getpid()}
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, mine)
     assert torch.isfinite(codes).all()
     log(f"[bench r{rank}] timed region: {args.steps} steps in {elapsed:.3f} s")
 
     # ---- roofline pass: the same K steps as ONE launch chain on one stream, every launch bracketed by HIP events ----------
     prof, prof_ms_per_step, codes_same = None, None, None
     if not args.no_roofline_pass:
-        if args.streams == 1:
-            enc1 = enc
-        else:
-            os.environ["CH_STREAMS"] = "1"
-            enc1 = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=B, device=dev)
-            os.environ["CH_STREAMS"] = str(args.streams)
+        enc1 = enc
+        enc.set_option("streams", 1)          # state of this handle, not of the process (include/concepthash_hip.h: ch_model_set_option)
         step1 = make_step(enc1)
         c1 = step1()[0]
         codes_same = bool(torch.equal(c1, codes))     # micro-batching never changes a bit
@@ -213,8 +220,7 @@ def main():
         torch.cuda.synchronize()
         prof_ms_per_step = (time.perf_counter() - t0) / args.steps * 1e3
         prof = enc1.profile_end()
-        if enc1 is not enc:
-            enc1.close()
+        enc.set_option("streams", args.streams)
 
     result = None
     if rank == 0:
@@ -229,13 +235,24 @@ def main():
                                    f"adapters b=384), batch={B}/GPU, top-{TOPK} Hamming vs {GALLERY_ROWS}-row gallery shard/GPU",
                        "per_gpu_batch": B, "global_batch": world * B, "gallery_rows_per_gpu": GALLERY_ROWS,
                        "hip_streams": args.streams,
-                       "parallelism": f"images x{world} (no collective), gallery rows x{world} (RCCL all_gather of packed "
+                       "parallelism": f"images x{world} (no collective), gallery rows x{world} ({backend_name(dist)} all_gather of packed "
                                       f"queries + lists)" if world > 1 else "single GPU"},
             "encode_tflops_end_to_end": round(enc.flops_per_image * B / (ms_per_step * 1e-3) / 1e12, 2),
             "encode_mfma_frac_end_to_end": round(enc.flops_per_image * B / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         }
+        if world > 1:
+            # self-verifying topology: the backend torch.distributed reports, and one record per rank gathered from the ranks
+            result["collective_backend"] = dist.get_backend()
+            result["ranks_seen"] = len({r["rank"] for r in rank_info})
+            result["ranks"] = rank_info
+            result["distinct_devices"] = len({(r["pci_bus_id"], r["device"]) for r in rank_info})
         if prof is not None:
             result.update(roofline_block(prof, args, enc, B, prof_ms_per_step, codes_same))
+
+    # ---- the batch sizes the reference evaluates / trains with (configs/val.yaml:10 batch_size 64; model yaml batch 32), outside the
+    # timed region: the same step (encode + pack + top-10 vs the gallery shard) at per-GPU batch 8 / 32 / 64 / 256, default options
+    if rank == 0 and not args.encode_only:
+        result["value_by_batch"] = by_batch_block(torch, enc, make_step, images, B)
 
     # ---- Hamming blocks (outside the timed region).  FIRST of the extra blocks: every rank takes part in its collectives, and the
     # rank-0-only blocks below would otherwise keep the other ranks waiting inside them -----------------------------------------
@@ -271,6 +288,34 @@ def main():
         dist.destroy_process_group()
 
 
+def backend_name(dist):
+    """RCCL when torch.distributed's backend is nccl (= RCCL on ROCm), otherwise the backend's own name (gloo: CPU rehearsal)."""
+    b = dist.get_backend()
+    return "RCCL" if b == "nccl" else str(b)
+
+
+def by_batch_block(torch, enc, make_step, images, B):
+    out = {}
+    for b in (8, 32, 64, 256):
+        if b > B:
+            continue
+        stp = make_step(enc, images[:b])
+        for _ in range(3):
+            stp()
+        torch.cuda.synchronize()
+        reps = 30 if b <= 64 else 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            stp()
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / reps
+        out[f"batch_{b}"] = {"images_per_s": round(b / sec, 1), "ms_per_step": round(sec * 1e3, 3),
+                             "mfma_frac": round(enc.flops_per_image * b / sec / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    out["note"] = ("the timed step (encode + pack + top-10 vs the gallery shard) at smaller per-GPU batches, wall clock incl. host launch "
+                   "time; configs/val.yaml:10 evaluates with batch_size 64; never used for `value`")
+    return out
+
+
 def roofline_block(prof, args, enc, B, prof_ms_per_step, codes_same):
     gemm_cats = [c for c in prof if c.startswith("gemm_")]
     gemm_ms = sum(prof[c]["ms"] for c in gemm_cats)
@@ -298,10 +343,11 @@ def roofline_block(prof, args, enc, B, prof_ms_per_step, codes_same):
     pp_grid = lambda N: -(-rows_tok // 256) * (N // 256) * 512
     v1_grid = lambda N: -(-rows_tok // 128) * (N // 128) * 256
     # cache-policy instances the dispatcher picks by size (gemm_bf16.hip: resid_nt_choice / out_nt_choice; CH_RESID_NT / CH_NT_OUT force)
-    def _pick(env, nbytes, limit):
-        return os.environ[env] != "0" if env in os.environ else nbytes >= limit
-    nt_resid = _pick("CH_RESID_NT", rows_tok * D_ * 4, 48 << 20)
-    pp_tag = lambda N: 2 if _pick("CH_NT_OUT", rows_tok * N * 2, 128 << 20) else 0
+    def _pick(key, nbytes, limit):
+        opt = enc.get_option(key)          # 0 = by tensor size (gemm_bf16.hip), 1 / -1 = forced on / off
+        return opt > 0 if opt else nbytes >= limit
+    nt_resid = _pick("resid_nt", rows_tok * D_ * 4, 48 << 20)
+    pp_tag = lambda N: 2 if _pick("nt_out", rows_tok * N * 2, 128 << 20) else 0
     instances = [  # (label, rocprof name, category, grid, algorithmic bytes per launch, bound)
         ("gemm_pp_kernel<EPI_BIAS_STATS> out_proj (K = D, 256x256 ping-pong)", "gemm_pp_kernel<6, 0, 0, 0>", "gemm_out",
          pp_grid(D_), gemm_bytes(D_, D_, rows_tok * D_ * 2 + st), "mfma"),
@@ -495,7 +541,8 @@ def train_block(torch, syn, sd, cfg, B, dev):
         x = syn.synthetic_images(b, cfg["image"]).to(dev, torch.bfloat16)
         dhf = torch.randn(b, 4, cfg["D"], device=dev) * 0.01
         s_f, _ = _ev_time(torch, lambda: eng.forward(x, ctx), 5)
-        s_all, _ = _ev_time(torch, lambda: (eng.forward(x, ctx), eng.backward(dhf)), 5)
+        # drop_grads: each backward OVERWRITES the gradient arena (no accumulation clone + add inside the timed calls)
+        s_all, _ = _ev_time(torch, lambda: (eng.drop_grads(), eng.forward(x, ctx), eng.backward(dhf)), 5)
         s_b = s_all - s_f
         out[f"batch_{b}"] = {"images_per_s": round(b / s_all, 1), "ms_per_step": round(s_all * 1e3, 3), "forward_ms": round(s_f * 1e3, 3),
                              "backward_ms": round(s_b * 1e3, 3), "tflops": round((fwd_f + bwd_f) * b / s_all / 1e12, 1),

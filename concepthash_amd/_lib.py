@@ -13,7 +13,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconcepthash_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ModelConfig(Structure):
@@ -39,9 +39,10 @@ SIGNATURES = {
     "ch_model_destroy": (None, [c_void_p]),
     "ch_model_device_bytes": (c_size_t, [c_void_p]),
     "ch_model_flops_per_image": (c_double, [c_void_p]),
-    "ch_model_set_concept_attn_layers": (c_int, [c_void_p, c_int32]),
+    "ch_model_set_option": (c_int, [c_void_p, c_char_p, c_int64]),
+    "ch_model_get_option": (c_int, [c_void_p, c_char_p, POINTER(c_int64)]),
     "ch_model_profile_begin": (c_int, [c_void_p, c_int32]),
-    "ch_model_profile_end": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
+    "ch_model_profile_end": (c_int, [c_void_p, c_int32, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
     "ch_debug_gemm": (c_int, [c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                               c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "ch_debug_gemm_ln": (c_int, [c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
@@ -55,7 +56,7 @@ SIGNATURES = {
     "ch_debug_adapter": (c_int, [c_void_p] * 2 + [c_int32] * 3 + [c_void_p] * 10 + [c_int32, c_void_p]),
     "ch_debug_attention": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "ch_encode": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_void_p, c_void_p]),
+                          c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "ch_encode_hidden": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "ch_preprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p,
                               c_int32, c_void_p, c_void_p]),
@@ -84,7 +85,7 @@ SIGNATURES = {
     "ch_trainer_destroy": (None, [c_void_p]),
     "ch_trainer_bytes": (c_int64, [c_void_p]),
     "ch_trainer_refresh": (c_int, [c_void_p, c_void_p]),
-    "ch_train_forward": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ch_train_forward": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "ch_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int32, c_int32, c_void_p]),
     "ch_debug_attention_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
@@ -92,7 +93,31 @@ SIGNATURES = {
     "ch_debug_ln_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ch_debug_act": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "ch_hamming_hist_prefix": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "ch_debug_set_hamming_scalar_loads": (None, [c_int32]),
 }
+
+# ch_model_set_option keys (include/concepthash_hip.h) and the DEBUG environment overrides the Python wrapper maps onto them when a
+# handle is created.  The library itself reads no environment variable; code that needs a setting passes `options=` / set_option().
+OPTION_KEYS = ("streams", "ln_fold", "prune_last", "pp_min_k", "small_kernel", "serpentine", "pp_sched", "fused_adapter", "resid_nt",
+               "nt_out", "group_n", "splitk", "gemm_rows", "train_chains", "train_chain_min_rows", "train_prune_last")
+_ENV_OVERRIDES = {  # env name -> (option key, value map)
+    "CH_STREAMS": ("streams", int), "CH_LN_FOLD": ("ln_fold", int), "CH_PRUNE_LAST": ("prune_last", int),
+    "CH_GEMM_PP_MIN_K": ("pp_min_k", int), "CH_GEMM_SMALL": ("small_kernel", int), "CH_SERPENTINE": ("serpentine", int),
+    "CH_GEMM_PP_SCHED": ("pp_sched", int), "CH_FUSED_ADAPTER": ("fused_adapter", int),
+    "CH_RESID_NT": ("resid_nt", lambda v: 1 if int(v) else -1), "CH_NT_OUT": ("nt_out", lambda v: 1 if int(v) else -1),
+    "CH_GEMM_GROUP_N": ("group_n", int), "CH_GEMM_SPLITK": ("splitk", int), "CH_GEMM_ROWS": ("gemm_rows", int),
+    "CH_TRAIN_STREAMS": ("train_chains", int), "CH_TRAIN_CHAIN_MIN_ROWS": ("train_chain_min_rows", int),
+    "CH_TRAIN_PRUNE_LAST": ("train_prune_last", int),
+}
+
+
+def env_option_overrides() -> dict:
+    """Debug overrides: CH_* environment variables of earlier rounds, read HERE (never in the library) when a handle is created."""
+    out = {}
+    for env, (key, conv) in _ENV_OVERRIDES.items():
+        if env in os.environ:
+            out[key] = conv(os.environ[env])
+    return out
 
 # launch-profiler categories, in the order of the CH_CAT_* enum; "*_pruned" = the final layer's launches on the compact head rows
 CATEGORIES = ("im2col", "gemm_patch", "rowops", "gemm_qkv", "attention", "gemm_out", "gemm_down", "gemm_up", "gemm_fc1",

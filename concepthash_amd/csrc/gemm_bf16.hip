@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmParams p) {
 template <int EPI>
 int launch(const GemmParams &p0, hipStream_t s) {
     GemmParams p = p0;
-    p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
+    p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN, p.group_n_opt);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     constexpr int lds = 2 * STAGE_BYTES + (ch_epi::traits<EPI>::fold ? CH_FOLD_LDS_BYTES : 0);
     static ch_once_per_device lds_once;
@@ -190,12 +190,11 @@ int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s) {
 
 // Estimated beyond-L2 read traffic for n-groups of gn tiles: every group re-streams X once; a group's weight panels are
 // fetched once per XCD if they fit in half of the 4 MB L2, otherwise once per round of co-resident tiles.
-int ch_gemm_group_n(int M, int N, int K, int bm, int bn) {
+int ch_gemm_group_n(int M, int N, int K, int bm, int bn, int forced) {
     const int tiles_n = N / bn, tiles_m = (M + bm - 1) / bm;
     const double xbytes = 2.0 * M * K, wpanel = 2.0 * bn * K, wbytes = 2.0 * N * K;
     const double rounds = (double)tiles_m * tiles_n / 256.0 + 1.0;
-    const char *env = getenv("CH_GEMM_GROUP_N");
-    if (env && atoi(env) > 0) return atoi(env) < tiles_n ? atoi(env) : tiles_n;
+    if (forced > 0) return forced < tiles_n ? forced : tiles_n;   // model option "group_n" (tools/gemm_bench.py sweeps)
     int best = tiles_n;
     double best_cost = 1e300;
     for (int gn = 1; gn <= tiles_n; ++gn) {
@@ -216,20 +215,20 @@ void ch_gemm_count_nt_launch(int kind) { g_dispatch_count[2 + (kind != 0)].fetch
 static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128 two-phase), 2 force pp (256x256 ping-pong), 3 force dp
 void ch_gemm_set_variant(int v) { g_gemm_variant = v; }
 // residual tensors from this size up are streamed past the caches by the scale+residual epilogues (gemm_epilogue.h: ld_resid);
-// CH_RESID_NT=0 / 1 forces the choice
+// the model option "resid_nt" (1 / -1) forces the choice
 static int resid_nt_choice(const GemmParams &p, int epi) {
     if (epi != EPI_SCALE_RESID && epi != EPI_SCALE_RESID_STATS) return 0;
-    if (const char *e = getenv("CH_RESID_NT")) return atoi(e) != 0;   // per call: the parity tests switch it inside one process
+    if (p.nt_resid_opt) return p.nt_resid_opt > 0;
     return std::max<int64_t>(p.M, p.footprint_rows) * p.N * 4 >= (48ll << 20);
 }
 // bf16 outputs of the plain / LN-folded epilogues from this size up (fc1's 316 MB and qkv's 237 MB at batch 256: read once, by the
 // next kernel, out of HBM whatever the policy) are stored non-temporally by the 256x256 kernel, which leaves the caches to the
-// operands: 12.15 -> 11.99 ms per encode step (profiles/r03_cache_policy_ab.txt).  CH_NT_OUT=0 / 1 forces the choice.
+// operands: 12.15 -> 11.99 ms per encode step (profiles/r03_cache_policy_ab.txt).  The model option "nt_out" (1 / -1) forces the choice.
 static int out_nt_choice(const GemmParams &p, int epi) {
     if (epi != EPI_BIAS && epi != EPI_FOLD_BIAS && epi != EPI_FOLD_QUICKGELU && epi != EPI_FOLD_GELU && epi != EPI_FOLD_ACT2_QUICK &&
         epi != EPI_FOLD_ACT2_GELU && epi != EPI_BIAS_DACT_QUICK && epi != EPI_BIAS_DACT_GELU)
         return 0;
-    if (const char *e = getenv("CH_NT_OUT")) return atoi(e) != 0;
+    if (p.nt_out_opt) return p.nt_out_opt > 0;
     return std::max<int64_t>(p.M, p.footprint_rows) * p.N * 2 >= (128ll << 20);
 }
 int ch_gemm_bf16(const GemmParams &p0, int epi, hipStream_t s) {
@@ -260,7 +259,7 @@ int ch_gemm_bf16(const GemmParams &p0, int epi, hipStream_t s) {
     // Short-K GEMMs (the adapter up-projection, K = 384) are epilogue/HBM bound: two 128x128 workgroups per CU overlap one's
     // read-modify-write epilogue with the other's K loop and win there (measured: 152 -> 97 us per launch in the pipeline);
     // the 256x256 ping-pong kernel wins from K = 512 up.
-    const int min_k = p.pp_min_k > 0 ? p.pp_min_k : 512;  // per model (CH_GEMM_PP_MIN_K at ch_model_create), not per process
+    const int min_k = p.pp_min_k > 0 ? p.pp_min_k : 512;  // per model (option "pp_min_k"), not per process
     // Small grids: fewer than 128 tiles of 256x256 leave more than half of the 256 CUs idle; 128x128 tiles (4x as many, two
     // workgroups per CU) win there -- measured at 6,432 rows (batch 32): out 28 vs 36 us, fc2 57 vs 73 us; at 12,864 rows and
     // N = 768 (153 tiles) the two tie.  Not applied when CH_GEMM_PP_MIN_K pins the choice (parity tests on small fixtures).
@@ -269,9 +268,8 @@ int ch_gemm_bf16(const GemmParams &p0, int epi, hipStream_t s) {
     g_dispatch_count[pp ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
     if (pp) return ch_gemm_bf16_pp(p, epi, s);
     // N = 384 (the adapter bottleneck) as whole-row workgroups (experiments/gemm_rows.hip): one round of the chip instead of 2.36
-    // rounds of 128x128 tiles, bit-identical -- and no faster (61 vs 59 us).  Opt-in: CH_GEMM_ROWS=1, experiments build.
-    static const int rows_on = getenv("CH_GEMM_ROWS") ? atoi(getenv("CH_GEMM_ROWS")) : 0;
-    if (rows_on && p.small_kernel == 0 && p.M >= 128 * 128 && ch_gemm_rows_supported(p, epi)) return ch_gemm_bf16_rows(p, epi, s);
+    // rounds of 128x128 tiles, bit-identical -- and no faster (61 vs 59 us).  Opt-in: model option "gemm_rows", experiments build.
+    if (p.rows_opt && p.small_kernel == 0 && p.M >= 128 * 128 && ch_gemm_rows_supported(p, epi)) return ch_gemm_bf16_rows(p, epi, s);
     const bool ring = (p.small_kernel == 2 || g_gemm_variant == 7) && ch_gemm_r4_supported(p);
     return ring ? ch_gemm_bf16_r4(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
 }

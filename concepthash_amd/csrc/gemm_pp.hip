@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pp_kernel(GemmParams p) {
 // Tail split: with G compute units, tiles = full rounds * G + R.  The R tiles of the last round would keep R units busy for
 // a whole tile time; cut along K into S slices they keep R * S <= G units busy for 1/S of it.  S must divide the K-loop's
 // iteration count.
-// OPT-IN (CH_GEMM_SPLITK=1, or the debug tap): measured on MI355X at M = 51456 the fix-up costs more than the shorter tail
+// OPT-IN (model option "splitk", or the debug tap): measured on MI355X at M = 51456 the fix-up costs more than the shorter tail
 // saves -- one workgroup moves its 256 KB fp32 slab at only ~25-30 GB/s (write-through stores 3-11 us per slice, sc1 loads
 // 9.5 us per slab), against 8 us (K = 768) to 24 us (K = 3072) saved: qkv 206 -> 223 us (S = 2) / 252 us (S = 6),
 // fc2 223 -> 229 us.  With agent-scope release/acquire fences instead of sc1 accesses it is another 5-20 us slower (the
@@ -479,10 +479,9 @@ void ch_pp_choose_split(GemmParams &p, int tiles) {
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    static const int enabled = getenv("CH_GEMM_SPLITK") ? atoi(getenv("CH_GEMM_SPLITK")) : 0;
     p.split_full = tiles;
     p.split_s = 1;
-    if (!(enabled || p.force_split) || !p.splitk_ws || !p.splitk_cnt) return;
+    if (!(p.splitk_opt || p.force_split) || !p.splitk_ws || !p.splitk_cnt) return;
     const int R = tiles % ncu, J = p.K / (2 * BK);
     if (R == 0) return;
     int S = 1;
@@ -527,7 +526,7 @@ int launch_pp_sched(GemmParams &p, int tiles, hipStream_t s) {
 template <int EPI>
 int launch_pp(const GemmParams &p0, hipStream_t s) {
     GemmParams p = p0;
-    p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN);
+    p.group_n = ch_gemm_group_n(p.M, p.N, p.K, BM, BN, p.group_n_opt);
     const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     if (p.pp_sched == 1) {  // coarse schedule (experiment, DESIGN.md section 3.8: bit-identical, no faster): no split-K
 #ifdef CH_EXPERIMENTS

@@ -21,8 +21,13 @@
 #include <type_traits>
 
 #include "../../include/concepthash_hip.h"
+#include "../../include/concepthash_hip_debug.h"
 #include "ch_common.h"
 #include "kernels.h"
+
+// test tap (include/concepthash_hip_debug.h): 1 = the mAP passes take the gallery through scalar loads instead of VMEM blocks + DPP
+static std::atomic<int> g_scalar_loads{0};
+extern "C" void ch_debug_set_hamming_scalar_loads(int32_t on) { g_scalar_loads.store(on != 0, std::memory_order_relaxed); }
 
 namespace {
 
@@ -778,9 +783,8 @@ template <int W, int BLK, int MODE, int NR>
 int launch_scan_nr(const ScanArgs &a, hipStream_t s) {
     // All passes take the gallery through VMEM in 16-row blocks spread over the lanes + DPP broadcast (at 16,384 x 1M x 128 bit:
     // histogram pass 18.9 ms with scalar loads -> 14.4 ms with same-address VMEM loads -> 8.0 ms; AP pass 39 -> 16 ms together
-    // with the parked accounting).  CH_HAMMING_VMEM=0 = the scalar-load form (same results; kept as the cross-check).
-    static const bool vm_env = !(getenv("CH_HAMMING_VMEM") && atoi(getenv("CH_HAMMING_VMEM")) == 0);
-    if (vm_env) return launch_scan_vm<W, BLK, MODE, NR, true>(a, s);
+    // with the parked accounting).  ch_debug_set_hamming_scalar_loads(1) = the scalar-load form (same results; kept as the cross-check).
+    if (!g_scalar_loads.load(std::memory_order_relaxed)) return launch_scan_vm<W, BLK, MODE, NR, true>(a, s);
     return launch_scan_vm<W, BLK, MODE, NR, false>(a, s);
 }
 

@@ -57,7 +57,7 @@ struct GemmParams {
     float *splitk_ws;
     unsigned *splitk_cnt;
     int split_full, split_s;
-    int force_split;         // debug taps: split even though CH_GEMM_SPLITK is off
+    int force_split;         // debug taps: split even though the model's "splitk" option is off
     int rev;                 // 1: walk the m-tiles from the last row tile to the first (serpentine launch order)
     int pp_sched;            // 256x256 kernel: 0 = four phases of 16 MFMAs per K-tile, 1 = two phases of 32 (gemm_pp.hip)
     int pp_min_k;            // dispatcher: smallest K that goes to the 256x256 ping-pong kernel (0 = default 512)
@@ -67,6 +67,12 @@ struct GemmParams {
     int nt_out;              // 1 = store out_bf16 non-temporally (an output larger than the Infinity Cache that is read once, much later)
     int tag;                 // profiling only: 1 = launch the 256x256 kernel under its second symbol name (gemm_pp.hip, TAG)
     int small_kernel;        // dispatcher, GEMMs that do not go to the 256x256 kernel: 0 = default, 1 = 128x128x64 two-phase, 2 = 128x128x32 ring (experiments build)
+    // per-model options handed down by the launch chain (ch_model_set_option); zero = the dispatcher's own choice
+    int nt_resid_opt;        // 0 = by tensor size, 1 = non-temporal residual instance, -1 = default-policy instance
+    int nt_out_opt;          // the same for the non-temporal bf16 output instance
+    int group_n_opt;         // > 0: n-tiles per weight group instead of the ch_gemm_group_n heuristic
+    int splitk_opt;          // 1 = split-K tail of the 256x256 kernel (needs splitk_ws / splitk_cnt)
+    int rows_opt;            // 1 = whole-row kernel for N = 384 where supported (experiments build)
 };
 constexpr size_t CH_SPLITK_WS_BYTES = (size_t)256 * 256 * 256 * 4;  // 64 MiB: at most 256 tail units of one 256x256 fp32 slab
 constexpr size_t CH_SPLITK_CNT_BYTES = 256 * sizeof(unsigned);
@@ -106,7 +112,7 @@ int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s);  // timing
 void ch_gemm_count_nt_launch(int kind);  // test tap counters: 0 = non-temporal residual instance, 1 = non-temporal output instance
 void ch_gemm_set_variant(int v);
 // n-tiles per weight group for a block tile of bn columns: minimises X re-fetches + W re-fetches
-int ch_gemm_group_n(int M, int N, int K, int bm, int bn);
+int ch_gemm_group_n(int M, int N, int K, int bm, int bn, int forced = 0);
 
 // ---- adapter_fused.hip --------------------------------------------------------------------------------------------
 struct AdapterParams {

@@ -316,13 +316,7 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
     m->prow_alloc = prows;
     m->H = (float *)B.alloc(sizeof(float) * rows * D);
     m->Xn = (bf16_t *)B.alloc(sizeof(bf16_t) * rows * D);
-    const bool want_splitk = getenv("CH_GEMM_SPLITK") && atoi(getenv("CH_GEMM_SPLITK")) != 0;  // opt-in, see gemm_pp.hip
-    for (int i = 0; want_splitk && i < m->nstreams; ++i) {
-        m->splitk_ws[i] = (float *)B.alloc(CH_SPLITK_WS_BYTES);
-        m->splitk_cnt[i] = (unsigned *)B.alloc(CH_SPLITK_CNT_BYTES);
-        if (!B.ok) return 4;
-        CH_CHECK_HIP(hipMemset(m->splitk_cnt[i], 0, CH_SPLITK_CNT_BYTES));
-    }
+    // (the split-K tail's slabs are allocated when ch_model_set_option switches "splitk" on)
     m->Hc = (float *)B.alloc(sizeof(float) * ((size_t)c.max_batch * (1 + c.ncontext) + 512) * D);
     m->head_xn = (float *)B.alloc(sizeof(float) * ((size_t)c.max_batch * c.ncontext + 16) * D);
     m->head_cls = (float *)B.alloc(sizeof(float) * ((size_t)c.max_batch + 16) * D);
@@ -372,7 +366,7 @@ inline void mark(ch_model *m, int pi, int cat, double flops, hipStream_t s) {
 // prune: (ch_encode) in the final layer only the rows the hashing head reads -- CLS and the Q concept tokens of every image --
 // are carried past the attention (whose keys / values still cover all tokens); their residual lives in mm->Hc afterwards
 int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int img0, int B, int nlayers, hipStream_t s,
-              float *concept_attn, bool prune, int Btot) {
+              float *concept_attn, bool attn_all_layers, bool prune, int Btot) {
     const ch_model_config &c = mm->cfg;
     const int D = c.dim, M = c.ffn, ntok = mm->ntok, np = mm->np;
     const int rows = B * ntok;
@@ -398,7 +392,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         GemmParams p{};
         p.X = m->PATCH; p.W = mm->patch_w; p.M = B * np; p.N = D; p.K = mm->Kp; p.X_rows_alloc = m->prow_alloc;
         p.bias = nullptr; p.resid = m->H; p.ldr = D; p.pos = mm->pos; p.tokens_per_img = ntok; p.patches_per_img = np;
-        p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.small_kernel = mm->small_kernel;
+        p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.small_kernel = mm->small_kernel; p.group_n_opt = mm->group_n;
         if (int e = ch_gemm_bf16(p, EPI_PATCH, s)) return e;
     }
     const LayerW &w0 = mm->layers[0];
@@ -436,6 +430,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         GemmParams p{};
         p.tag = cat == CH_CAT_GEMM_FC2 ? 1 : 0;   // fc2 runs out_proj's kernel instance: second symbol name for per-kernel profiles
         p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi]; p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.small_kernel = mm->small_kernel; p.rev = next_dir();
+        p.nt_resid_opt = mm->resid_nt; p.nt_out_opt = mm->nt_out; p.group_n_opt = mm->group_n; p.splitk_opt = mm->splitk; p.rows_opt = mm->gemm_rows;
         p.footprint_rows = (int64_t)cur_rows * Btot / B;   // all concurrent chains of this call: what the cache-policy choice is sized on
         p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
@@ -498,9 +493,9 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         const bool pruned = prune && fold && mm->prune_last && i == nlayers - 1 && nlayers == c.layers;
         const int nq = 1 + c.ncontext;
         mark(mm, pi, pruned ? CH_CAT_ATTENTION_PRUNED : CH_CAT_ATTENTION, 4.0 * B * (double)(pruned ? nq : ntok) * ntok * D, s);
-        // concept-token attention tap: the last layer's rows, or (ch_model_set_concept_attn_layers) every layer's, [L, Btot, heads, Q, Np]
+        // concept-token attention tap: the last layer's rows, or (the call's concept_attn_all_layers) every layer's, [L, Btot, heads, Q, Np]
         float *cattn = !concept_attn ? nullptr
-                       : mm->attn_all_layers ? concept_attn + (size_t)i * Btot * c.heads * c.ncontext * np
+                       : attn_all_layers ? concept_attn + (size_t)i * Btot * c.heads * c.ncontext * np
                        : i == nlayers - 1 ? concept_attn : nullptr;
         if (int e = ch_attention(m->QKV, B, ntok, c.heads, m->AO, s, cattn, c.ncontext, pruned, next_dir() != 0))
             return e;
@@ -536,16 +531,16 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
 // encoder up to `nlayers` layers; leaves the residual stream in m->H.  With two streams the batch is split into two
 // micro-batches whose chains run concurrently (fork/join by events on the caller's stream).
 int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nlayers, hipStream_t s,
-                float *concept_attn = nullptr, bool prune = false) {
+                float *concept_attn = nullptr, bool attn_all_layers = false, bool prune = false) {
     const int ns = std::min(m->nstreams, B);
-    if (ns < 2) return run_chain(m, 0, images, image_dtype, 0, B, nlayers, s, concept_attn, prune, B);
+    if (ns < 2) return run_chain(m, 0, images, image_dtype, 0, B, nlayers, s, concept_attn, attn_all_layers, prune, B);
     // micro-batch i = images [i*B/ns, (i+1)*B/ns); chain 0 on the caller's stream, the others fork from / join it
     CH_CHECK_HIP(hipEventRecord(m->ev_fork, s));
     for (int i = 0; i < ns; ++i) {
         const int b0 = (int)((int64_t)B * i / ns), b1 = (int)((int64_t)B * (i + 1) / ns);
         hipStream_t si = i == 0 ? s : m->aux_stream[i - 1];
         if (i > 0) CH_CHECK_HIP(hipStreamWaitEvent(si, m->ev_fork, 0));
-        if (int e = run_chain(m, i, images, image_dtype, b0, b1 - b0, nlayers, si, concept_attn, prune, B)) return e;
+        if (int e = run_chain(m, i, images, image_dtype, b0, b1 - b0, nlayers, si, concept_attn, attn_all_layers, prune, B)) return e;
         if (i > 0) {
             CH_CHECK_HIP(hipEventRecord(m->ev_join[i - 1], si));
             CH_CHECK_HIP(hipStreamWaitEvent(s, m->ev_join[i - 1], 0));
@@ -588,23 +583,6 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
     m->np = grid * grid;
     m->ntok = 1 + m->np + cfg->ncontext;
     m->Kp = (int)round_up64(3 * cfg->patch * cfg->patch, 64);
-    if (const char *e = getenv("CH_FUSED_ADAPTER")) m->use_fused_adapter = atoi(e) != 0;
-#ifndef CH_EXPERIMENTS
-    if (m->use_fused_adapter) {
-        ch_set_error("CH_FUSED_ADAPTER=1: the fused adapter kernel is an experiment and not part of this build (CH_BUILD_EXPERIMENTS=1)");
-        delete m;
-        return 2;
-    }
-#endif
-    if (const char *e = getenv("CH_LN_FOLD")) m->ln_fold = atoi(e) != 0;
-    if (const char *e = getenv("CH_PRUNE_LAST")) m->prune_last = atoi(e) != 0;
-    if (const char *e = getenv("CH_GEMM_PP_MIN_K")) m->pp_min_k = atoi(e);
-    if (const char *e = getenv("CH_GEMM_SMALL")) m->small_kernel = atoi(e);
-    if (const char *e = getenv("CH_SERPENTINE")) m->serpentine = atoi(e) != 0;
-#ifdef CH_EXPERIMENTS
-    if (const char *e = getenv("CH_GEMM_PP_SCHED")) m->pp_sched = (atoi(e) == 1 || atoi(e) == 2) ? atoi(e) : 0;
-#endif
-    if (const char *e = getenv("CH_STREAMS")) m->nstreams = std::max(1, std::min(atoi(e), CH_MAX_STREAMS));
     bool aux_ok = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; aux_ok && i < CH_MAX_STREAMS - 1; ++i)
         aux_ok = hipStreamCreateWithFlags(&m->aux_stream[i], hipStreamNonBlocking) == hipSuccess &&
@@ -646,9 +624,89 @@ extern "C" void ch_model_destroy(ch_model *m) {
 
 extern "C" size_t ch_model_device_bytes(const ch_model *m) { return m ? m->bytes : 0; }
 
-extern "C" int ch_model_set_concept_attn_layers(ch_model *m, int32_t all_layers) {
-    CH_REQUIRE(m != nullptr, "set_concept_attn_layers: null model");
-    m->attn_all_layers = all_layers != 0;
+// ---- per-handle options (include/concepthash_hip.h: ch_model_set_option).  The library reads no environment variable: every knob of the
+// launch chain is state of ONE opaque handle, set through this entry point (the Python wrapper maps its debug environment overrides onto it).
+namespace {
+struct OptionRef {
+    const char *key;
+    int kind;   // 0 int field, 1 bool field, 2 int64 field
+    void *(*field)(ch_model *);
+    int64_t lo, hi;
+};
+#define CH_OPT_FIELD(name) [](ch_model *m) -> void * { return &m->name; }
+const OptionRef g_options[] = {
+    {"streams", 0, CH_OPT_FIELD(nstreams), 1, CH_MAX_STREAMS},
+    {"ln_fold", 1, CH_OPT_FIELD(ln_fold), 0, 1},
+    {"prune_last", 1, CH_OPT_FIELD(prune_last), 0, 1},
+    {"pp_min_k", 0, CH_OPT_FIELD(pp_min_k), 0, 1 << 20},
+    {"small_kernel", 0, CH_OPT_FIELD(small_kernel), 0, 2},
+    {"serpentine", 1, CH_OPT_FIELD(serpentine), 0, 1},
+    {"pp_sched", 0, CH_OPT_FIELD(pp_sched), 0, 2},
+    {"fused_adapter", 1, CH_OPT_FIELD(use_fused_adapter), 0, 1},
+    {"resid_nt", 0, CH_OPT_FIELD(resid_nt), -1, 1},
+    {"nt_out", 0, CH_OPT_FIELD(nt_out), -1, 1},
+    {"group_n", 0, CH_OPT_FIELD(group_n), 0, 64},
+    {"splitk", 0, CH_OPT_FIELD(splitk), 0, 1},
+    {"gemm_rows", 0, CH_OPT_FIELD(gemm_rows), 0, 1},
+    {"train_chains", 0, CH_OPT_FIELD(train_chains), 1, 2},
+    {"train_chain_min_rows", 2, CH_OPT_FIELD(train_chain_min_rows), 1, (int64_t)1 << 40},
+    {"train_prune_last", 1, CH_OPT_FIELD(train_prune_last), 0, 1},
+};
+#undef CH_OPT_FIELD
+const OptionRef *find_option(const char *key) {
+    if (!key) return nullptr;
+    for (const OptionRef &o : g_options)
+        if (std::string(o.key) == key) return &o;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int ch_model_set_option(ch_model *m, const char *key, int64_t value) {
+    CH_REQUIRE(m != nullptr, "set_option: null model");
+    const OptionRef *o = find_option(key);
+    if (!o) {
+        ch_set_error(std::string("invalid argument: set_option: unknown key '") + (key ? key : "(null)") + "'");
+        return 2;
+    }
+    if (value < o->lo || value > o->hi) {
+        ch_set_error(std::string("invalid argument: set_option: '") + key + "' must be in [" + std::to_string(o->lo) + ", " +
+                     std::to_string(o->hi) + "], got " + std::to_string(value));
+        return 2;
+    }
+#ifndef CH_EXPERIMENTS
+    const std::string k = key;
+    if (value != 0 && (k == "fused_adapter" || k == "pp_sched" || k == "gemm_rows" || (k == "small_kernel" && value == 2))) {
+        ch_set_error("set_option: '" + k + "' selects an experiment kernel that is not part of this build (CH_BUILD_EXPERIMENTS=1)");
+        return 2;
+    }
+#endif
+    if (std::string(key) == "splitk" && value != 0) {   // the tail's slabs + tickets, one set per chain: allocated on first use
+        for (int i = 0; i < CH_MAX_STREAMS; ++i) {
+            if (m->splitk_ws[i]) continue;
+            CH_CHECK_HIP(hipMalloc((void **)&m->splitk_ws[i], CH_SPLITK_WS_BYTES));
+            m->allocs.push_back(m->splitk_ws[i]);
+            CH_CHECK_HIP(hipMalloc((void **)&m->splitk_cnt[i], CH_SPLITK_CNT_BYTES));
+            m->allocs.push_back(m->splitk_cnt[i]);
+            CH_CHECK_HIP(hipMemset(m->splitk_cnt[i], 0, CH_SPLITK_CNT_BYTES));
+            m->bytes += CH_SPLITK_WS_BYTES + CH_SPLITK_CNT_BYTES;
+        }
+    }
+    void *f = o->field(m);
+    if (o->kind == 0) *(int *)f = (int)value;
+    else if (o->kind == 1) *(bool *)f = value != 0;
+    else *(int64_t *)f = value;
+    return 0;
+}
+
+extern "C" int ch_model_get_option(ch_model *m, const char *key, int64_t *value) {
+    CH_REQUIRE(m != nullptr && value != nullptr, "get_option: null model / value");
+    const OptionRef *o = find_option(key);
+    if (!o) {
+        ch_set_error(std::string("invalid argument: get_option: unknown key '") + (key ? key : "(null)") + "'");
+        return 2;
+    }
+    void *f = o->field(m);
+    *value = o->kind == 0 ? (int64_t) * (int *)f : o->kind == 1 ? (int64_t) * (bool *)f : *(int64_t *)f;
     return 0;
 }
 
@@ -669,14 +727,15 @@ extern "C" double ch_model_flops_per_image(const ch_model *m) {
 
 extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, float *out_codes,
                          uint64_t *out_packed, float *out_logits_cont, float *out_logits_bin, float *out_logits_concept,
-                         float *out_hash_features, float *out_image_features, float *out_concept_attn, void *stream) {
+                         float *out_hash_features, float *out_image_features, float *out_concept_attn,
+                         int32_t concept_attn_all_layers, void *stream) {
     CH_REQUIRE(m != nullptr && images != nullptr && out_codes != nullptr, "null model / images / out_codes");
     CH_REQUIRE(image_dtype == 0 || image_dtype == 1, "image_dtype must be 0 (fp32) or 1 (bf16)");
     CH_REQUIRE(B >= 1 && B <= m->cfg.max_batch, "batch outside [1, max_batch]");
     CH_REQUIRE(!out_logits_concept || m->concept_cent_l2, "model has no concept classifier (concept_ce.centroids)");
     CH_REQUIRE(!out_image_features || m->vis_proj, "model has no post_layernorm / visual_projection");
     hipStream_t s = (hipStream_t)stream;
-    if (int e = run_encoder(m, images, image_dtype, B, m->cfg.layers, s, out_concept_attn, true)) return e;
+    if (int e = run_encoder(m, images, image_dtype, B, m->cfg.layers, s, out_concept_attn, concept_attn_all_layers != 0, true)) return e;
     const ch_model_config &c = m->cfg;
     const bool pruned = m->prune_last && m->ln_fold && c.adapter_dim > 0 && !m->use_fused_adapter;  // as run_chain decides
     HeadParams p{};
@@ -756,8 +815,9 @@ extern "C" int ch_model_profile_begin(ch_model *m, int32_t max_launches) {
     return 0;
 }
 
-extern "C" int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *launches_per_cat, double *flops_per_cat) {
+extern "C" int ch_model_profile_end(ch_model *m, int32_t ncat, double *ms_per_cat, int64_t *launches_per_cat, double *flops_per_cat) {
     CH_REQUIRE(m != nullptr && ms_per_cat && launches_per_cat && flops_per_cat, "profile_end: null pointer");
+    CH_REQUIRE(ncat >= CH_NCAT, "profile_end: the caller's arrays hold fewer than CH_NCAT entries (built against an older header?)");
     m->prof_on = false;
     for (int i = 0; i < CH_NCAT; ++i) {
         ms_per_cat[i] = 0.0;

@@ -8,7 +8,7 @@
 #include "ch_common.h"
 #include "kernels.h"
 
-constexpr int CH_MAX_STREAMS = 4;  // micro-batch chains that may run concurrently (CH_STREAMS)
+constexpr int CH_MAX_STREAMS = 4;  // micro-batch chains that may run concurrently (option "streams")
 
 struct AdapterW {
     const float *ln_w = nullptr, *ln_b = nullptr, *down_b = nullptr, *up_b = nullptr, *scale = nullptr;
@@ -47,7 +47,6 @@ struct ch_model {
     // LayerNorm folded into the consumer GEMMs: no LayerNorm launches inside the layer loop.
     // Needs adapters (their up-projection epilogue is where the bf16 copy of the residual and its row statistics are made).
     bool ln_fold = true;
-    bool attn_all_layers = false;  // ch_model_set_concept_attn_layers: the concept-token attention tap covers every layer
     bool prof_on = false;
     struct Prof {
         std::vector<hipEvent_t> ev;          // interval form: one event in front of every launch (+ one behind the last)
@@ -57,10 +56,10 @@ struct ch_model {
         std::vector<double> flops;
         size_t n = 0;
     } prof[CH_MAX_STREAMS];  // one per micro-batch stream
-    // CH_STREAMS micro-batches (default 2) on as many HIP streams: memory-bound launches of one chain (adapter up-projection,
+    // option "streams" micro-batches (default 2) on as many HIP streams: memory-bound launches of one chain (adapter up-projection,
     // attention, epilogue-heavy GEMM tails) co-run with MFMA-bound launches of the other, and partly filled last rounds of
     // tiles get filled.  Rows are independent, so the outputs are bit-identical for every value.  Measured at B = 256:
-    // 1 -> 2 streams +8 % images/s, 3 and 4 no better.  CH_STREAMS=1 is what a per-kernel profile wants:
+    // 1 -> 2 streams +8 % images/s, 3 and 4 no better.  streams = 1 is what a per-kernel profile wants:
     // per-launch durations stop describing single kernels once launches overlap.
     int nstreams = 2;
     hipStream_t aux_stream[CH_MAX_STREAMS - 1] = {};
@@ -72,13 +71,22 @@ struct ch_model {
     unsigned *splitk_cnt[CH_MAX_STREAMS] = {};
     // final-layer row pruning: compact fp32 copy of the residual rows the head reads, [max_batch * (1 + Q) (+pad), D]
     bool prune_last = true;
-    // Serpentine launch order (CH_SERPENTINE=1): every row-streaming launch of a chain walks its row
+    // Serpentine launch order (option "serpentine"): every row-streaming launch of a chain walks its row
     // tiles in the direction opposite to its predecessor's, so that it starts on the rows the predecessor wrote LAST -- the
     // ones that should still be in the 256 MB Infinity Cache.  Measured: no gain (12.44 vs 12.39 ms per step) -> off.
     bool serpentine = false;
-    int pp_sched = 0;  // CH_GEMM_PP_SCHED: schedule of the 256x256 GEMM (gemm_pp.hip)
-    int small_kernel = 0;  // CH_GEMM_SMALL at creation: 2 = 128x128x32 four-stage ring, experiments build only (0 = dispatcher default)
-    int pp_min_k = 0;  // CH_GEMM_PP_MIN_K at creation (tests: sends small-K GEMMs of a small fixture to the 256x256 kernel)
+    int pp_sched = 0;  // option "pp_sched": schedule of the 256x256 GEMM (gemm_pp.hip)
+    int small_kernel = 0;  // option "small_kernel": 2 = 128x128x32 four-stage ring, experiments build only (0 = dispatcher default)
+    int pp_min_k = 0;  // option "pp_min_k" (tests: sends small-K GEMMs of a small fixture to the 256x256 kernel)
+    // ---- per-handle tuning / test options (ch_model_set_option; the library reads no environment variable)
+    int resid_nt = 0, nt_out = 0;   // cache policy of the fp32 residual read-modify-write / of large bf16 outputs: 0 = by tensor size, 1 = on, -1 = off
+    int group_n = 0;                // n-tiles per L2-resident weight group of the GEMM tile order (0 = host heuristic)
+    int splitk = 0;                 // split-K tail of the 256x256 GEMM (opt-in, measured slower: DESIGN.md section 3.8)
+    int gemm_rows = 0;              // whole-row kernel for N = 384 (experiments build)
+    // read by ch_trainer_create from the model it is created on
+    int train_chains = 1;
+    int64_t train_chain_min_rows = 12000;
+    bool train_prune_last = true;
     float *Hc = nullptr;
     float *head_xn = nullptr, *head_cls = nullptr;  // head.hip: left operands of the two dense optional outputs
     float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn

@@ -49,7 +49,7 @@ constexpr int TR_CHAINS = 2;
 struct ch_trainer {
     ch_model *m = nullptr;
     int max_batch = 0, B = 0;
-    // Two micro-batch chains on two streams (as ch_encode does), CH_TRAIN_STREAMS=2: chain 1 owns its own row
+    // Two micro-batch chains on two streams (as ch_encode does), model option "train_chains" = 2: chain 1 owns its own row
     // region of every activation buffer (so that padding rows never alias the other chain's data), its own weight-gradient
     // scratch and its own gradient arena; the two arenas are added once at the end (the assembly is linear in the weight-gradient
     // products).  Correct (tests run both), but MEASURED SLOWER than one chain for training -- 47.2 vs 42.5 ms at batch 256, 27.0
@@ -80,6 +80,7 @@ struct ch_trainer {
     float *ws_wgrad[TR_CHAINS] = {}, *ws_colsum[TR_CHAINS] = {}, *G[TR_CHAINS] = {}, *T[TR_CHAINS] = {}, *cu[TR_CHAINS] = {},
           *cd[TR_CHAINS] = {}, *dctx_sum[TR_CHAINS] = {};
     bool forward_done = false;
+    bool attn_all_layers = false;   // layout of the concept-attention tap, latched by ch_train_forward for the matching ch_train_backward
 };
 
 namespace {
@@ -143,6 +144,7 @@ int gemm(ch_trainer *t, int chain, int rows, const GemmCall &g, hipStream_t s, i
     p.bias = g.bias; p.out_bf16 = g.out; p.ldo = g.ldo; p.resid = g.resid; p.ldr = D; p.scale_ptr = g.scale; p.addend = g.addend;
     p.ld_addend = D; p.stats_in = g.stats_in; p.fold_c = g.fold_c; p.ln_eps = g.eps; p.stats_out = g.stats_out; p.hb_out = g.hb_out;
     p.ld_hb = g.ld_hb ? g.ld_hb : D; p.aux = g.aux; p.pp_min_k = t->m->pp_min_k;
+    p.nt_resid_opt = t->m->resid_nt; p.nt_out_opt = t->m->nt_out; p.group_n_opt = t->m->group_n;
     return ch_gemm_bf16(p, g.epi, s);
 }
 
@@ -198,9 +200,9 @@ int forward_chain(ch_trainer *t, int ch, const void *images_all, int image_dtype
         if (int e = gemm(t, ch, rows, g, s)) return e;
         const bool pruned = t->prune_last && l == L - 1;
         // last layer: optionally tap the concept tokens' attention rows over the patch tokens (attn_cache[-1][:, :, -Q:, 1:-Q])
-        // (ch_model_set_concept_attn_layers: every layer's rows, [L, B, heads, Q, Np])
+        // (concept_attn_all_layers of the call: every layer's rows, [L, B, heads, Q, Np])
         float *cattn = !out_cattn_all ? nullptr
-                       : m->attn_all_layers ? out_cattn_all + ((size_t)l * t->B + img0) * c.heads * Q * np
+                       : t->attn_all_layers ? out_cattn_all + ((size_t)l * t->B + img0) * c.heads * Q * np
                        : l == L - 1 ? out_cattn_all + (size_t)img0 * c.heads * Q * np : nullptr;
         if (int e = ch_attention(R.d3(v.QKV), B, ntok, c.heads, R.d(v.AO), s, cattn, Q, pruned)) return e;
         if (pruned) {      // from here on every buffer of this layer holds B * (1 + Q) compact rows (CLS, then the concept tokens)
@@ -327,7 +329,7 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, const float *dca
             cur = rows;
         }
         const float *dpext = !dcattn_all ? nullptr
-                             : t->m->attn_all_layers ? dcattn_all + ((size_t)l * t->B + img0) * c.heads * Q * (ntok - Q - 1)
+                             : t->attn_all_layers ? dcattn_all + ((size_t)l * t->B + img0) * c.heads * Q * (ntok - Q - 1)
                              : l == L - 1 ? dcattn_all + (size_t)img0 * c.heads * Q * (ntok - Q - 1) : nullptr;
         if (int e = ch_attention_bwd(R.d3(v.QKV), dctx, B, ntok, c.heads, tQKV, s, dpext, Q)) return e;
         g = GemmCall{D, 3 * D, tQKV, x.qkv_wgT, zero, EPI_BIAS};
@@ -377,9 +379,10 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
     t->params = params;
     t->grads = grads;
     t->ad_numel = adapter_numel(c);
-    if (const char *e = getenv("CH_TRAIN_STREAMS")) t->nchains = std::max(1, std::min(atoi(e), TR_CHAINS));
-    if (const char *e = getenv("CH_TRAIN_CHAIN_MIN_ROWS")) t->chain_min_rows = std::max(1, atoi(e));
-    if (const char *e = getenv("CH_TRAIN_PRUNE_LAST")) t->prune_last = atoi(e) != 0;
+    // options of the model the trainer is created on (ch_model_set_option "train_chains" / "train_chain_min_rows" / "train_prune_last")
+    t->nchains = std::max(1, std::min(m->train_chains, TR_CHAINS));
+    t->chain_min_rows = std::max<int64_t>(1, m->train_chain_min_rows);
+    t->prune_last = m->train_prune_last;
     const int D = c.dim, L = c.layers, M = c.ffn, bpad = m->bpad, Q = c.ncontext;
     // region 0 holds a whole batch (one chain) or the first half (two chains); region 1 the second half
     const int half = (max_batch + 1) / 2;
@@ -472,7 +475,8 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
 extern "C" int64_t ch_trainer_bytes(const ch_trainer *t) { return t ? (int64_t)t->bytes : 0; }
 
 extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image_dtype, int32_t B, const float *concept_tokens,
-                                float *out_hash_features, float *out_cls, float *out_concept_attn, void *stream) {
+                                float *out_hash_features, float *out_cls, float *out_concept_attn, int32_t concept_attn_all_layers,
+                                void *stream) {
     CH_REQUIRE(t != nullptr && images != nullptr && concept_tokens != nullptr && out_hash_features != nullptr, "train_forward: null argument");
     CH_REQUIRE(B >= 1 && B <= t->max_batch, "train_forward: batch outside [1, max_batch]");
     CH_REQUIRE(image_dtype == 0 || image_dtype == 1, "train_forward: image_dtype must be 0 (fp32) or 1 (bf16)");
@@ -480,6 +484,7 @@ extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image
     const ch_model_config &c = t->m->cfg;
     t->B = B;
     t->forward_done = false;
+    t->attn_all_layers = out_concept_attn != nullptr && concept_attn_all_layers != 0;
     CH_CHECK_HIP(hipMemcpyAsync(t->ctx, concept_tokens, sizeof(float) * c.ncontext * c.dim, hipMemcpyDeviceToDevice, s));
     t->nc = (t->nchains > 1 && (int64_t)(B / 2) * t->m->ntok >= t->chain_min_rows) ? 2 : 1;
     if (t->nc == 1) {

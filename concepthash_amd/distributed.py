@@ -190,8 +190,8 @@ class ShardedRetrieval:
 
     # ---- mAP / P@k / R@k -----------------------------------------------------------------------------------------
     def evaluate(self, q_all: torch.Tensor, q_labels: torch.Tensor, R=-1, ks: Sequence[int] = (1, 5, 10),
-                 remove_first: bool = False, seg_rows: Optional[int] = None) -> dict:
-        """Same statistics as ``retrieval.evaluate`` (R an int or a list), gallery sharded by rows: per-shard histograms are
+                 remove_first: bool = False, seg_rows: Optional[int] = None, skip_queries_without_relevant: bool = False) -> dict:
+        """Same statistics as ``retrieval.evaluate`` (R an int or a list; `skip_queries_without_relevant` as there), gallery sharded by rows: per-shard histograms are
         all-gathered, every rank builds the same global bases, ONE local AP pass accumulates every rank limit (each R and each
         k), and the integer sums are all-reduced -- bit-identical to the single-GPU result for any shard count."""
         if self.labels is None:
@@ -260,7 +260,7 @@ class ShardedRetrieval:
         total = totals[:, 1].clone()
         if remove_first:
             total = total - first_rel
-        sm = ops.summarize(S, nrel, total, idx_of, Rs, ks)
+        sm = ops.summarize(S, nrel, total, idx_of, Rs, ks, skip_queries_without_relevant)
         out = dict(precisions=sm["precisions"], recalls=sm["recalls"], hits=sm["hits"], total=total)
         if many:
             out.update(mAP=sm["mAPs"], S=[S[idx_of[i]] for i in range(len(Rs))], nrel=[nrel[idx_of[i]] for i in range(len(Rs))],

@@ -93,7 +93,11 @@ class ConceptHashEncoder:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], heads: Optional[int] = None, upt_heads: int = 8,
                  act: str = "quick_gelu", max_batch: int = 256, device: Optional[torch.device] = None,
-                 ln_eps: float = 1e-5, bn_eps: float = 1e-5, image_size: Optional[int] = None):
+                 ln_eps: float = 1e-5, bn_eps: float = 1e-5, image_size: Optional[int] = None,
+                 options: Optional[Dict[str, int]] = None):
+        """options: ch_model_set_option settings of this handle (`_lib.OPTION_KEYS`: "streams", "ln_fold", "prune_last", "pp_min_k",
+        "resid_nt", "nt_out", ...).  The CH_* environment variables of earlier rounds are DEBUG overrides read here, in the wrapper
+        (`_lib.env_option_overrides`), and lose against an explicit entry of `options`."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("ConceptHashEncoder needs a GPU (MI355X); there is no CPU fallback")
@@ -129,6 +133,8 @@ class ConceptHashEncoder:
             _lib.check(self.lib.ch_model_create(ctypes.byref(c), arr, len(entries), ctypes.byref(handle)),
                        "ch_model_create")
         self._h = handle
+        for k, v in {**_lib.env_option_overrides(), **(options or {})}.items():
+            self.set_option(k, v)
         self.nbit = cfg["nbit"]
         self.words = (self.nbit + 63) // 64
         self.ntok = 1 + (cfg["image_size"] // cfg["patch"]) ** 2 + cfg["ncontext"]
@@ -151,6 +157,16 @@ class ConceptHashEncoder:
     def device_bytes(self) -> int:
         return int(self.lib.ch_model_device_bytes(self._h))
 
+    # -- per-handle options (include/concepthash_hip.h: ch_model_set_option) ------------------------------------------
+    def set_option(self, key: str, value: int) -> None:
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ch_model_set_option(self._h, key.encode(), int(value)), f"ch_model_set_option({key!r})")
+
+    def get_option(self, key: str) -> int:
+        v = ctypes.c_int64()
+        _lib.check(self.lib.ch_model_get_option(self._h, key.encode(), ctypes.byref(v)), f"ch_model_get_option({key!r})")
+        return int(v.value)
+
     @property
     def flops_per_image(self) -> float:
         return float(self.lib.ch_model_flops_per_image(self._h))
@@ -164,7 +180,7 @@ class ConceptHashEncoder:
         ms = (ctypes.c_double * n)()
         cnt = (ctypes.c_int64 * n)()
         fl = (ctypes.c_double * n)()
-        _lib.check(self.lib.ch_model_profile_end(self._h, ms, cnt, fl), "ch_model_profile_end")
+        _lib.check(self.lib.ch_model_profile_end(self._h, n, ms, cnt, fl), "ch_model_profile_end")
         return {name: dict(ms=ms[i], launches=int(cnt[i]), flops=fl[i]) for i, name in enumerate(_lib.CATEGORIES)
                 if name != "end"}
 
@@ -236,10 +252,9 @@ class ConceptHashEncoder:
                                      dtype=torch.float32, device=dev)
                     attn_chunks.append(al)
                     attn_ptr = _lib.ptr(al)
-                _lib.check(self.lib.ch_model_set_concept_attn_layers(self._h, 1 if all_layers else 0), "ch_model_set_concept_attn_layers")
                 _lib.check(self.lib.ch_encode(self._h, _lib.ptr(images[b0:b1]), dt, b1 - b0, sl("codes"), sl("packed"),
                                               sl("logits_cont"), sl("logits_bin"), _lib.ptr(lc), sl("hash_features"),
-                                              sl("image_features"), attn_ptr, sp), "ch_encode")
+                                              sl("image_features"), attn_ptr, 1 if all_layers else 0, sp), "ch_encode")
         if concept_chunks:
             out["logits_concept"] = concept_chunks[0] if len(concept_chunks) == 1 else torch.cat(concept_chunks, dim=1)
         if attn_chunks:

@@ -91,9 +91,11 @@ class GpuPreprocess:
             desc[name] = geo[:, j]
         return desc, int(src.sum()), int(tmp.sum()), int(max(1, geo[:, 5].max())) if B else 1
 
-    def _stage(self, desc: np.ndarray, device) -> torch.Tensor:
+    def _stage(self, desc: np.ndarray, device, stream=None) -> torch.Tensor:
         """descriptors -> device without synchronising: through a ring of pinned host buffers and a non-blocking copy (a copy from
-        pageable memory would wait for everything queued on the stream -- once per batch, in the evaluator loop)."""
+        pageable memory would wait for everything queued on the stream -- once per batch, in the evaluator loop).  The copy and the
+        ring event go on the stream `ch_preprocess` is launched on, so that the kernel can never read the descriptors before they have
+        landed and a ring slot is never rewritten under a copy in flight, whatever stream the caller passes."""
         raw = torch.from_numpy(desc.view(np.uint8).reshape(-1))
         slot = self._ring[self._ring_pos % self._RING]
         self._ring_pos += 1
@@ -102,10 +104,12 @@ class GpuPreprocess:
         if slot["buf"] is None or slot["buf"].numel() < raw.numel():
             slot["buf"] = torch.empty(max(raw.numel(), 48 * 256), dtype=torch.uint8, pin_memory=True)
         slot["buf"][:raw.numel()].copy_(raw)
-        ddev = torch.empty(raw.numel(), dtype=torch.uint8, device=device)
-        ddev.copy_(slot["buf"][:raw.numel()], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
+        s = stream if stream is not None else torch.cuda.current_stream(device)
+        with torch.cuda.stream(s):
+            ddev = torch.empty(raw.numel(), dtype=torch.uint8, device=device)
+            ddev.copy_(slot["buf"][:raw.numel()], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(s)
         slot["event"] = ev
         return ddev
 
@@ -122,7 +126,7 @@ class GpuPreprocess:
             raise ValueError(f"pixels holds {pixels.numel()} bytes, the sizes add up to {nbytes}")
         pixels = pixels.contiguous()
         with torch.cuda.device(pixels.device):
-            ddev = self._stage(desc, pixels.device)
+            ddev = self._stage(desc, pixels.device, stream)
             ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=pixels.device)
             _lib.check(self.lib.ch_preprocess(_lib.ptr(pixels), _lib.ptr(ddev), B, max_rows, self.crop, self._mean, self._std,
                                               _lib.ptr(out), 1 if self.out_dtype == torch.bfloat16 else 0, _lib.ptr(ws),

@@ -344,9 +344,14 @@ def ap_from_fixed(S: torch.Tensor, nrel: torch.Tensor) -> torch.Tensor:
     return torch.where(nrel > 0, Sf / (n.clamp_min(1.0) * TWO32), torch.zeros_like(Sf))
 
 
-def summarize(S, nrel, total, idx_of, Rs: Sequence[int], ks: Sequence[int]) -> dict:
+def summarize(S, nrel, total, idx_of, Rs: Sequence[int], ks: Sequence[int], skip_queries_without_relevant: bool = False) -> dict:
     """Host-side statistics from the per-limit integers of one multi-limit AP pass: limits were Rs + ks (idx_of maps each to
-    its row of S / nrel).  mAP per R; P@k = hits / k and R@k = hits / total with hits = nrel under limit k."""
+    its row of S / nrel).  mAP per R; P@k = hits / k and R@k = hits / total with hits = nrel under limit k.
+    skip_queries_without_relevant: the ONE convention of the AP definition that changes numbers ("Retrieval
+    definition"): a query with no relevant row inside its top R has AP = 0.  False (default): it counts in the
+    mean with that 0.  True (the HashNet / OrthoHash-family convention, `if tsum == 0: continue`): it is left out of the mean --
+    mAP@R = mean of AP over the queries that have a relevant row in their top R (0.0 when no query has one).  Identical whenever
+    every query has a relevant row inside R, e.g. mAP@all on CUB-200 / Cars196 / NABirds."""
     Qn = total.shape[0]
     dev = total.device
     nR = len(Rs)
@@ -354,7 +359,13 @@ def summarize(S, nrel, total, idx_of, Rs: Sequence[int], ks: Sequence[int]) -> d
     hits = torch.zeros(Qn, len(ks), dtype=torch.int32, device=dev)
     if not Qn:
         return dict(mAPs=[0.0] * nR, aps=aps, hits=hits, precisions=[0.0] * len(ks), recalls=[0.0] * len(ks))
-    means = [a.mean() for a in aps]                         # 0-dim float64 tensors; ONE device->host copy for all of them below
+    if skip_queries_without_relevant:
+        means = []
+        for i, a in enumerate(aps):
+            has = nrel[idx_of[i]] > 0
+            means.append(a.sum() / has.sum().clamp_min(1).double())    # a is 0 where nrel == 0
+    else:
+        means = [a.mean() for a in aps]                     # 0-dim float64 tensors; ONE device->host copy for all of them below
     tot = total.clamp_min(1).double()
     for t, k in enumerate(ks):
         h = nrel[idx_of[nR + t]]
@@ -369,7 +380,7 @@ def summarize(S, nrel, total, idx_of, Rs: Sequence[int], ks: Sequence[int]) -> d
 
 def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels: torch.Tensor, R=-1,
              ks: Sequence[int] = (1, 5, 10), remove_first: bool = False, seg_rows: Optional[int] = None,
-             records: Optional[bool] = None, rec_cap: Optional[int] = None) -> dict:
+             records: Optional[bool] = None, rec_cap: Optional[int] = None, skip_queries_without_relevant: bool = False) -> dict:
     """Single-GPU mAP@R + P@k + R@k on packed codes: histogram pass, prefix, ONE AP pass whose rank limits are R (an int or
     a list) and every k -- the number of relevant rows inside limit k is exactly hits@k, for any k.  Returns python
     floats/lists plus the raw integer statistics (S, nrel, hits, total) that the parity tests compare bit-for-bit with the
@@ -377,7 +388,8 @@ def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels:
     records (default on; CH_HAMMING_RECORDS=0 = off): the one-scan form -- the histogram pass also records the relevant rows and
     the AP pass walks those records instead of scanning the gallery again; rec_cap overrides the list capacity (tests).  Left to the
     default, large single-label problems first predict (exactly, from the labels) how many workgroups' lists would overflow and run
-    the two-scan form where most would (`predicted_overflow`)."""
+    the two-scan form where most would (`predicted_overflow`).
+    skip_queries_without_relevant: which queries the mean of AP runs over (`summarize`); the integers S / nrel do not depend on it."""
     q, g = _check_packed(q, g)
     Qn, W = q.shape
     G = g.shape[0]
@@ -418,7 +430,7 @@ def evaluate(q: torch.Tensor, g: torch.Tensor, q_labels: torch.Tensor, g_labels:
     total = totals[:, 1].clone()
     if remove_first:
         total = total - first_rel
-    sm = summarize(S, nrel, total, idx_of, Rs, ks)
+    sm = summarize(S, nrel, total, idx_of, Rs, ks, skip_queries_without_relevant)
     out = dict(precisions=sm["precisions"], recalls=sm["recalls"], hits=sm["hits"], total=total)
     if many:
         out.update(mAP=sm["mAPs"], S=[S[idx_of[i]] for i in range(len(Rs))], nrel=[nrel[idx_of[i]] for i in range(len(Rs))],

@@ -33,11 +33,13 @@ class TrainEngine:
     adapters: list over layers of (adapt_mlp_1, adapt_mlp_2) modules whose parameters are re-pointed into the arena."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], adapters: Sequence[Sequence[torch.nn.Module]], heads: int,
-                 upt_heads: int = 8, act: str = "quick_gelu", max_batch: int = 64, device=None, image_size=None):
+                 upt_heads: int = 8, act: str = "quick_gelu", max_batch: int = 64, device=None, image_size=None, options=None):
+        """options: ch_model_set_option settings of the frozen model the trainer is created on -- "train_chains", "train_chain_min_rows",
+        "train_prune_last" are read by ch_trainer_create, "pp_min_k" etc. by every launch (ConceptHashEncoder)."""
         self.lib = _lib.load()
         # the frozen model: its own workspace is never used by training, so it is sized for one image
         self.encoder = ConceptHashEncoder(state_dict, heads=heads, upt_heads=upt_heads, act=act, max_batch=1, device=device,
-                                          image_size=image_size)
+                                          image_size=image_size, options=options)
         self.device = self.encoder.device
         self.cfg = self.encoder.cfg
         self.max_batch = int(max_batch)
@@ -135,17 +137,23 @@ class TrainEngine:
         shape = ((c["layers"],) if all_layers else ()) + (B, c["heads"], c["ncontext"], npatch)
         attn = torch.empty(shape, dtype=torch.float32, device=self.device) if want_attn else None
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ch_model_set_concept_attn_layers(self.encoder._h, 1 if all_layers else 0), "ch_model_set_concept_attn_layers")
             _lib.check(self.lib.ch_train_forward(self._t, _lib.ptr(images), 0 if images.dtype == torch.float32 else 1, B,
-                                                 _lib.ptr(ct), _lib.ptr(hf), _lib.ptr(cls), _lib.ptr(attn), _lib.stream_ptr()),
-                       "ch_train_forward")
+                                                 _lib.ptr(ct), _lib.ptr(hf), _lib.ptr(cls), _lib.ptr(attn), 1 if all_layers else 0,
+                                                 _lib.stream_ptr()), "ch_train_forward")
         self.generation += 1
         return (hf, cls, attn) if want_attn else (hf, cls)
 
     def grads_live(self) -> bool:
         """True when the adapters' `.grad`s still are the arena views of an earlier backward, i.e. no `zero_grad()` (set_to_none,
         the default) ran since: the next backward must ADD to them, as autograd does for every other parameter."""
-        return any(p.grad is not None and p.grad.data_ptr() == gview.data_ptr() for p, gview in self._views[:1])
+        return any(p.grad is not None and p.grad.data_ptr() == gview.data_ptr() for p, gview in self._views)
+
+    def drop_grads(self) -> None:
+        """`optimizer.zero_grad(set_to_none=True)` for the adapters alone: the next backward overwrites the arena instead of accumulating
+        (what a timing loop that calls `backward` repeatedly wants -- otherwise every call after the first also pays the accumulation's
+        clone + add of the arena and the gradients grow without bound)."""
+        for p, _ in self._views:
+            p.grad = None
 
     def backward(self, d_hash_features: torch.Tensor, d_concept_attn: torch.Tensor = None) -> torch.Tensor:
         """`ch_train_backward` OVERWRITES the gradient arena.  Gradient accumulation (two backward calls without a zero_grad in

@@ -13,6 +13,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work and never
  *     synchronise, allocate or free device memory (graph-capture safe) -- except ch_model_create/destroy.
  *   - integers are bit-exact by contract; floating point tolerances are stated in DESIGN.md / tests.
+ *   - no hidden global state: the library reads NO environment variable; every tuning / test knob is state of one opaque handle
+ *     (ch_model_set_option), the only process-wide switches are the test taps of concepthash_hip_debug.h.
  */
 #ifndef CONCEPTHASH_HIP_H
 #define CONCEPTHASH_HIP_H
@@ -24,7 +26,10 @@
 extern "C" {
 #endif
 
-#define CH_ABI_VERSION 1
+/* 2 (round 4): ch_encode / ch_train_forward take the layout of the concept-attention tap as an argument (ch_model_set_concept_attn_layers
+ * is gone), ch_model_profile_end takes the capacity of the caller's arrays, ch_model_set_option / ch_model_get_option replace every
+ * environment variable the library used to read. */
+#define CH_ABI_VERSION 2
 
 typedef struct ch_model ch_model; /* opaque: weights (bf16/fp32, device) + activation workspace */
 
@@ -74,6 +79,23 @@ void ch_model_destroy(ch_model *m);
 /* bytes of device memory held by the model (weights + workspace) */
 size_t ch_model_device_bytes(const ch_model *m);
 
+/* Tuning / test options of ONE model handle ("no hidden global state except an opaque handle").  Every call
+ * made on the handle afterwards uses the new value; outputs are bit-identical for every setting except "ln_fold" (rounding points
+ * move) and "splitk" (summation order).  Unknown keys and out-of-range values are errors.
+ *   "streams"       1..4   micro-batch launch chains of ch_encode on as many HIP streams (default 2; 1 = what a per-kernel profile wants)
+ *   "ln_fold"       0/1    LayerNorm folded into the consumer GEMMs (default 1)
+ *   "prune_last"    0/1    final layer past its attention on the rows the hashing head reads only (default 1)
+ *   "pp_min_k"      >= 0   smallest K that goes to the 256x256 ping-pong GEMM (0 = dispatcher default: 512 and >= 128 tiles)
+ *   "resid_nt"      -1/0/1 non-temporal read-modify-write of the fp32 residual: off / by tensor size (default) / on
+ *   "nt_out"        -1/0/1 non-temporal stores of large bf16 GEMM outputs: off / by tensor size (default) / on
+ *   "group_n"       >= 0   n-tiles per L2-resident weight group of the GEMM tile order (0 = host heuristic)
+ *   "splitk"        0/1    split-K tail of the 256x256 GEMM (default 0; allocates 64 MiB per chain on first use)
+ *   "serpentine"    0/1    alternate the row direction of consecutive launches (default 0)
+ *   "small_kernel", "pp_sched", "fused_adapter", "gemm_rows"  experiment kernels: non-zero values need the experiments build
+ *   "train_chains" 1..2, "train_chain_min_rows", "train_prune_last" 0/1   read by ch_trainer_create from the model it is created on */
+int ch_model_set_option(ch_model *m, const char *key, int64_t value);
+int ch_model_get_option(ch_model *m, const char *key, int64_t *value);
+
 /* Replaces: LGHWithFixedPrompt.forward (models/arch/coop.py:524-598) as driven by
  * COOPTrainer.compute_features_one_batch (trainers/coop.py:59-71), eval mode.
  *   images        [B,3,H,W] NCHW, fp32 (image_dtype 0) or bf16 (image_dtype 1)
@@ -85,17 +107,16 @@ size_t ch_model_device_bytes(const ch_model *m);
  *   out_image_features [B,P] fp32 pooled CLS -> post-LN -> visual_projection (coop.py:498-501) (optional)
  *   out_concept_attn   [B,heads,Q,Np] fp32 last-layer attention of the Q concept tokens over the Np patch tokens
  *                      = attn_cache[-1][:, :, -Q:, 1:-Q] (coop.py:481-482; consumer models/loss/coop.py:164-176)  (optional)
+ *   concept_attn_all_layers  layout of out_concept_attn, part of THIS call (no sticky state on the handle): 0 = the last layer only,
+ *                      [B,heads,Q,Np]; 1 = EVERY layer, [L,B,heads,Q,Np], layer l = attn_cache[l][:, :, -Q:, 1:-Q] -- what the
+ *                      `avg_attn` form of the attention-diversity loss averages (models/loss/coop.py:164-167,
+ *                      `torch.stack(outputs['attn_cache']).mean(0)`) and the per-layer visualisations read
+ *                      (models/arch/coop.py:481-482), without the (B, heads, N, N) maps ever being written.
  * B must be in [1, max_batch]. */
 int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, float *out_codes,
               uint64_t *out_packed, float *out_logits_cont, float *out_logits_bin, float *out_logits_concept,
-              float *out_hash_features, float *out_image_features, float *out_concept_attn, void *stream);
-
-/* Which layers' concept-token attention rows `out_concept_attn` (ch_encode, ch_train_forward) and `d_concept_attn`
- * (ch_train_backward) carry: 0 (default) = the last layer only, [B,heads,Q,Np]; 1 = EVERY layer, [L,B,heads,Q,Np], layer l =
- * attn_cache[l][:, :, -Q:, 1:-Q] -- what the `avg_attn` form of the attention-diversity loss averages (models/loss/coop.py:164-167,
- * `torch.stack(outputs['attn_cache']).mean(0)`) and the per-layer visualisations read (models/arch/coop.py:481-482), without the
- * (B, heads, N, N) maps ever being written.  Applies to trainers created on the model as well. */
-int ch_model_set_concept_attn_layers(ch_model *m, int32_t all_layers);
+              float *out_hash_features, float *out_image_features, float *out_concept_attn, int32_t concept_attn_all_layers,
+              void *stream);
 
 /* Parity tap (tests only): run the encoder for `layer` layers (0 = embeddings + concept tokens + pre-LN) and copy the
  * fp32 residual stream [B*N, D], N = 1 + patches + Q, to out_hidden.  Mirrors `image_hidden_states[layer]`
@@ -117,7 +138,8 @@ int ch_encode_hidden(ch_model *m, const void *images, int32_t image_dtype, int32
 typedef struct ch_trainer ch_trainer;
 /* total floats of the adapter arena of this model (0 without adapters) */
 int64_t ch_adapter_arena_numel(const ch_model *m);
-/* Shares the frozen weights of `m` (which must outlive the trainer); allocates the per-layer saved activations for max_batch. */
+/* Shares the frozen weights of `m` (which must outlive the trainer); allocates the per-layer saved activations for max_batch.
+ * Reads the model's "train_*" options (ch_model_set_option) once, here. */
 int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, float *grads, ch_trainer **out);
 void ch_trainer_destroy(ch_trainer *t);
 int64_t ch_trainer_bytes(const ch_trainer *t);
@@ -129,10 +151,13 @@ int ch_trainer_refresh(ch_trainer *t, void *stream);
  *   out_cls           [B,D] fp32 last-layer CLS states (optional, NULL)
  *   out_concept_attn  [B,heads,Q,Np] fp32 last-layer attention of the concept tokens over the patch tokens
  *                     = attn_cache[-1][:, :, -Q:, 1:-Q] (coop.py:481-482), what the attention-diversity term of the loss reads
- *                     (models/loss/coop.py:164-189)                                                    (optional, NULL) */
+ *                     (models/loss/coop.py:164-189)                                                    (optional, NULL)
+ *   concept_attn_all_layers  as in ch_encode: 1 = out_concept_attn is [L,B,heads,Q,Np]; the trainer remembers the layout of its last
+ *                     forward, and the matching ch_train_backward takes d_concept_attn in the same one */
 int ch_train_forward(ch_trainer *t, const void *images, int32_t image_dtype, int32_t B, const float *concept_tokens,
-                     float *out_hash_features, float *out_cls, float *out_concept_attn, void *stream);
-/* Backward of the last ch_train_forward: d_hash_features [B,Q,D] fp32 and (optional, NULL) d_concept_attn [B,heads,Q,Np] fp32 in;
+                     float *out_hash_features, float *out_cls, float *out_concept_attn, int32_t concept_attn_all_layers, void *stream);
+/* Backward of the last ch_train_forward: d_hash_features [B,Q,D] fp32 and (optional, NULL) d_concept_attn fp32 in the layout that
+ * forward was called with ([B,heads,Q,Np] or [L,B,heads,Q,Np]; ignored when that forward had no out_concept_attn) in;
  * adapter gradients into the gradient arena, d_concept_tokens [Q,D] fp32 out. */
 int ch_train_backward(ch_trainer *t, const float *d_hash_features, const float *d_concept_attn, float *d_concept_tokens, void *stream);
 /* torch.optim.SGD.step (configs/optim/sgd.yaml; maximize False) over ONE flat fp32 array -- the adapter arena: d = g + weight_decay * p;
@@ -143,7 +168,8 @@ int ch_sgd_step(float *params, const float *grads, float *momentum_buf, int64_t 
 /* Launch profiler for bench.py's roofline: between begin and end every kernel launch of ch_encode is bracketed by
  * HIP events on the caller's stream (capacity max_launches events; launches beyond it are not recorded).
  * ch_model_profile_end waits for the last recorded event and returns, per category, the summed launch durations
- * (ms), the number of launches and their algorithmic FLOPs. */
+ * (ms), the number of launches and their algorithmic FLOPs; `ncat` is the capacity of the caller's three arrays and must be
+ * >= CH_NCAT (a caller built against a header with fewer categories is refused instead of overrun). */
 /* The *_PRUNED categories are the launches of the final layer behind its attention, which run on the B * (1 + Q) rows the hashing
  * head reads instead of all B * N token rows: kept apart so that every category is ONE problem shape. */
 enum {
@@ -153,7 +179,7 @@ enum {
     CH_CAT_GEMM_FC2_PRUNED, CH_CAT_END, CH_NCAT
 };
 int ch_model_profile_begin(ch_model *m, int32_t max_launches);
-int ch_model_profile_end(ch_model *m, double *ms_per_cat, int64_t *launches_per_cat, double *flops_per_cat);
+int ch_model_profile_end(ch_model *m, int32_t ncat, double *ms_per_cat, int64_t *launches_per_cat, double *flops_per_cat);
 
 /* Algorithmic FLOPs of one image through ch_encode (SURVEY.md section 8d formula). */
 double ch_model_flops_per_image(const ch_model *m);

@@ -52,6 +52,10 @@ int ch_debug_adapter(const void *A, float *H, int32_t M, int32_t D, int32_t b, c
 /* qkv [B*ntok, 3*heads*64] bf16 (q | k | v) -> out [B*ntok, heads*64] bf16: softmax(q k^T / 8) v per (image, head). */
 int ch_debug_attention(const void *qkv, int32_t B, int32_t ntok, int32_t heads, void *out, void *stream);
 
+/* 1 = the mAP scan passes read the gallery through scalar loads (the round-1 form) instead of 16-row VMEM blocks + DPP row broadcast:
+ * same results bit for bit, kept as a cross-check of the row loops (tests/test_hamming_gpu.py).  Process-wide, tests only. */
+void ch_debug_set_hamming_scalar_loads(int32_t on);
+
 /* Kernel taps of the training step: see train_kernels.hip / attention_bwd.hip. */
 int ch_debug_attention_bwd(const void *qkv, const void *dO, int32_t B, int32_t ntok, int32_t heads, void *dqkv, const float *dpext,
                            int32_t ncon, void *stream);

@@ -80,8 +80,10 @@ def pack_multihot(labels: np.ndarray) -> np.ndarray:
 
 
 def mean_ap(q: np.ndarray, g: np.ndarray, q_labels: np.ndarray, g_labels: np.ndarray, R: int = -1,
-            ks=(1, 5, 10), remove_first: bool = False, want_hist: bool = False) -> dict:
-    """labels: 1-D int class ids (single label) or 2-D {0,1} multi-hot."""
+            ks=(1, 5, 10), remove_first: bool = False, want_hist: bool = False, skip_queries_without_relevant: bool = False) -> dict:
+    """labels: 1-D int class ids (single label) or 2-D {0,1} multi-hot.
+    skip_queries_without_relevant: False = SURVEY.md section 8c (a query with no relevant row in its top R has AP 0 and counts in the
+    mean); True = the HashNet / OrthoHash-family convention (`if tsum == 0: continue`: such queries are left out of the mean)."""
     q = np.ascontiguousarray(q, dtype=np.uint64)
     g = np.ascontiguousarray(g, dtype=np.uint64)
     Qn, W = q.shape
@@ -118,9 +120,15 @@ def mean_ap(q: np.ndarray, g: np.ndarray, q_labels: np.ndarray, g_labels: np.nda
     precisions = (hits[:, :nk] / ks_f[None, :]).mean(axis=0) if nk else np.zeros(0)
     recalls = np.where(total[:, None] > 0, hits[:, :nk] / np.maximum(total, 1)[:, None], 0.0).mean(axis=0) \
         if nk else np.zeros(0)
+    if skip_queries_without_relevant:
+        keep = nrel > 0
+        m_fixed = float(ap_fixed[keep].mean()) if keep.any() else 0.0
+        m_f64 = float(ap[keep].mean()) if keep.any() else 0.0
+    else:
+        m_fixed = float(ap_fixed.mean()) if Qn else 0.0
+        m_f64 = float(ap.mean()) if Qn else 0.0
     return dict(S=S, nrel=nrel, ap_f64=ap, ap_fixed=ap_fixed, hits=hits[:, :nk], total=total, hist=hist,
-                mAP=float(ap_fixed.mean()) if Qn else 0.0, mAP_f64=float(ap.mean()) if Qn else 0.0,
-                precisions=precisions, recalls=recalls)
+                mAP=m_fixed, mAP_f64=m_f64, precisions=precisions, recalls=recalls)
 
 
 # ---- reference-style float path (sign -> matmul -> argsort), the CPU-baseline "port" leg -----------------

@@ -172,8 +172,9 @@ def test_the_benchmark_batch_is_bit_identical_across_policies_chains_and_repeats
         again = enc.encode(x, want=want)
         for k in want:
             assert torch.equal(again[k], ref[k]), k
-    monkeypatch.setenv("CH_RESID_NT", "0")
-    monkeypatch.setenv("CH_NT_OUT", "0")
+    enc.set_option("resid_nt", -1)                           # per-handle options, no environment: both policies forced off
+    enc.set_option("nt_out", -1)
+    assert enc.get_option("resid_nt") == -1 and enc.get_option("streams") == 2
     c2 = count()
     off = enc.encode(x, want=want)
     torch.cuda.synchronize()
@@ -181,10 +182,7 @@ def test_the_benchmark_batch_is_bit_identical_across_policies_chains_and_repeats
     for k in want:
         assert torch.equal(off[k], ref[k]), k
     enc.close()
-    monkeypatch.delenv("CH_RESID_NT")
-    monkeypatch.delenv("CH_NT_OUT")
-    monkeypatch.setenv("CH_STREAMS", "1")
-    one = _encoder(sd, cfg["heads"], max_batch=256)
+    one = _encoder(sd, cfg["heads"], max_batch=256, options={"streams": 1})
     single = one.encode(x, want=want)
     torch.cuda.synchronize()
     for k in want:
@@ -226,14 +224,11 @@ def test_fused_adapter_kernel_matches_unfused_chain(dev, monkeypatch):
     sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
     x = eo.synthetic_images(3, cfg["image"])
     if not _lib.load().ch_debug_experiments_built():
-        monkeypatch.setenv("CH_FUSED_ADAPTER", "1")
         with pytest.raises(RuntimeError, match="not part of this build"):     # the product library refuses loudly
-            _encoder(sd, cfg["heads"], max_batch=4)
+            _encoder(sd, cfg["heads"], max_batch=4, options={"fused_adapter": 1})
         pytest.skip("adapter_fused.hip is an experiment kernel (CH_BUILD_EXPERIMENTS=1 builds it)")
     base = _encoder(sd, cfg["heads"], max_batch=4).encode(x.to(dev))["codes"].cpu()
-    monkeypatch.setenv("CH_FUSED_ADAPTER", "1")
-    fused = _encoder(sd, cfg["heads"], max_batch=4).encode(x.to(dev))["codes"].cpu()
-    monkeypatch.delenv("CH_FUSED_ADAPTER")
+    fused = _encoder(sd, cfg["heads"], max_batch=4, options={"fused_adapter": 1}).encode(x.to(dev))["codes"].cpu()
     ref = eo.encode(sd, x, heads=cfg["heads"], with_pooled=False)["codes"]
     assert not torch.equal(fused, base)                       # really a different code path
     assert _rel_err(fused, ref) < 4e-2 and _rel_err(fused, base) < 2e-2

@@ -439,51 +439,32 @@ def test_randomised_shapes_against_oracle(dev):
         assert np.array_equal(got["total"].cpu().numpy().astype(np.uint32), ref["total"]), case
 
 
-_SCALAR_FORM_SCRIPT = r"""
-import hashlib, json, sys
-import numpy as np, torch
-sys.path.insert(0, {root!r})
-from concepthash_amd import retrieval as rt
-from oracle import hamming_oracle as ho
-out = {{}}
-for nbit, Qn, G, ncls, seg in ((64, 700, 9001, 25, None), (128, 513, 7777, 12, 1000), (192, 300, 5000, 9, 257), (256, 129, 4100, 5, None)):
-    q, ql = ho.synthetic_codes(Qn, nbit, seed=31, nclass=ncls, flip=0.15)
-    g, gl = ho.synthetic_codes(G, nbit, seed=32, nclass=ncls, flip=0.15)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a.view(np.int64) if a.dtype == np.uint64 else a)).cuda()
-    got = rt.evaluate(t(q), t(g), t(ql), t(gl), R=-1, ks=(1, 5, 10), remove_first=bool(nbit == 128), seg_rows=seg)
-    out[str(nbit)] = [hashlib.sha256(got[k].cpu().numpy().tobytes()).hexdigest() for k in ("S", "nrel", "hits", "total")]
-print("RESULT " + json.dumps(out))
-"""
-
-
 def test_scalar_load_form_of_the_map_passes_is_bit_identical(dev):
-    """`CH_HAMMING_VMEM=0` selects the scalar-load form of both mAP passes (the default takes the gallery through VMEM in 16-row
-    blocks + DPP row broadcast, csrc/hamming.hip).  The switch is read once per process, so the scalar form runs in a child
-    process; S / nrel / hits / total of four problems (64 .. 256 bit, explicit and default segment sizes) must be the same bytes."""
+    """`ch_debug_set_hamming_scalar_loads(1)` (a test tap, include/concepthash_hip_debug.h) selects the scalar-load form of both mAP
+    passes (the default takes the gallery through VMEM in 16-row blocks + DPP row broadcast, csrc/hamming.hip).  S / nrel / hits /
+    total of four problems (64 .. 256 bit, explicit and default segment sizes) must be the same bytes under both forms, and one of
+    them is checked against the oracle."""
     import hashlib
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = _SCALAR_FORM_SCRIPT.format(root=root)
-
-    def run(env_value):
-        env = dict(os.environ)
-        if env_value is None:
-            env.pop("CH_HAMMING_VMEM", None)
-        else:
-            env["CH_HAMMING_VMEM"] = env_value
-        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        line = [x for x in r.stdout.splitlines() if x.startswith("RESULT ")][-1]
-        return json.loads(line[len("RESULT "):])
-
-    scalar = run("0")
-    default = run(None)
-    assert scalar == default
-    # and the default form against the oracle on one of them, in this process
-    from concepthash_amd import retrieval as rt
+    from concepthash_amd import _lib, retrieval as rt
     from oracle import hamming_oracle as ho
+    lib = _lib.load()
+
+    def run():
+        out = {}
+        for nbit, Qn, G, ncls, seg in ((64, 700, 9001, 25, None), (128, 513, 7777, 12, 1000), (192, 300, 5000, 9, 257), (256, 129, 4100, 5, None)):
+            q, ql = ho.synthetic_codes(Qn, nbit, seed=31, nclass=ncls, flip=0.15)
+            g, gl = ho.synthetic_codes(G, nbit, seed=32, nclass=ncls, flip=0.15)
+            got = rt.evaluate(_t(q, dev), _t(g, dev), _t(ql, dev), _t(gl, dev), R=-1, ks=(1, 5, 10), remove_first=bool(nbit == 128), seg_rows=seg)
+            out[str(nbit)] = [hashlib.sha256(got[k].cpu().numpy().tobytes()).hexdigest() for k in ("S", "nrel", "hits", "total")]
+        return out
+
+    lib.ch_debug_set_hamming_scalar_loads(1)
+    try:
+        scalar = run()
+    finally:
+        lib.ch_debug_set_hamming_scalar_loads(0)
+    default = run()
+    assert scalar == default
     q, ql = ho.synthetic_codes(513, 128, seed=31, nclass=12, flip=0.15)
     g, gl = ho.synthetic_codes(7777, 128, seed=32, nclass=12, flip=0.15)
     ref = ho.mean_ap(q, g, ql, gl, R=-1, ks=(1, 5, 10), remove_first=True)

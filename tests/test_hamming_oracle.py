@@ -87,6 +87,51 @@ def test_map_against_numpy(R, remove_first):
             assert r["hist"][i, b, 1] == ((d[i] == b) & (rel[i] == 1)).sum()
 
 
+@pytest.mark.parametrize("R", [3, 10, -1])
+def test_both_ap_conventions_on_queries_without_a_relevant_row_in_the_top_R(R):
+    """The one convention that changes numbers at R < G ("Retrieval definition"): a query with NO relevant row in
+    its top R.  Default: AP 0, counted in the mean.  `skip_queries_without_relevant=True` (the HashNet /
+    OrthoHash-family evaluators: `if tsum == 0: continue`): left out of the mean.  Both against an independent numpy restatement, on a
+    set built so that some queries have none (a class that is absent from the gallery, and rare classes ranked late), and the same
+    two means out of `retrieval.summarize` (the host code the HIP path shares) from the oracle's integers."""
+    import torch
+    from concepthash_amd import retrieval as rt
+    q, ql = ho.synthetic_codes(60, 64, seed=15, nclass=12, flip=0.3)
+    g, gl = ho.synthetic_codes(400, 64, seed=16, nclass=12, flip=0.3)
+    ql[:5] = 11                       # queries of a class ...
+    gl[gl == 11] = 0                  # ... that the gallery does not hold: no relevant row at any R
+    d = ho.dist(q, g)
+    rel = (ql[:, None] == gl[None, :]).astype(np.int64)
+    G = g.shape[0]
+    RR = G if R <= 0 else R
+    aps, has = [], []
+    for i in range(60):
+        order = np.argsort(d[i], kind="stable")
+        rr = rel[i][order]
+        aps.append(_ap_reference_style(np.arange(G), rr, RR))
+        has.append(rr[:RR].sum() > 0)
+    aps, has = np.array(aps), np.array(has)
+    assert 5 <= (~has).sum() < 60     # the set exercises the convention (more queries without a hit at small R)
+    r_all = ho.mean_ap(q, g, ql, gl, R=R)
+    r_skip = ho.mean_ap(q, g, ql, gl, R=R, skip_queries_without_relevant=True)
+    assert np.array_equal(r_all["S"], r_skip["S"]) and np.array_equal(r_all["nrel"], r_skip["nrel"])   # integers do not depend on it
+    assert abs(r_all["mAP_f64"] - aps.mean()) < 1e-12 and abs(r_all["mAP"] - aps.mean()) < 1e-9
+    assert abs(r_skip["mAP_f64"] - aps[has].mean()) < 1e-12 and abs(r_skip["mAP"] - aps[has].mean()) < 1e-9
+    assert r_skip["mAP"] > r_all["mAP"]
+    # the product's host-side summary from the same integers
+    S = torch.from_numpy(r_all["S"].view(np.int64))[None]
+    nrel = torch.from_numpy(r_all["nrel"].astype(np.int32))[None]
+    total = torch.from_numpy(r_all["total"].astype(np.int32))
+    for skip, want in ((False, r_all["mAP"]), (True, r_skip["mAP"])):
+        sm = rt.summarize(S, nrel, total, [0], [R], [], skip_queries_without_relevant=skip)
+        assert abs(sm["mAPs"][0] - want) < 1e-12
+    # no query with a hit at all: 0.0 under both, no division by zero
+    e = ho.mean_ap(q[:5], g, ql[:5], gl, R=R, skip_queries_without_relevant=True)
+    assert e["mAP"] == 0.0
+    z = rt.summarize(S[:, :5], nrel[:, :5], total[:5], [0], [R], [], skip_queries_without_relevant=True)
+    assert z["mAPs"][0] == 0.0
+
+
 def test_multihot_equals_single_label():
     q, ql = ho.synthetic_codes(20, 128, seed=7, nclass=70)
     g, gl = ho.synthetic_codes(200, 128, seed=8, nclass=70)

@@ -43,13 +43,50 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.ch_abi_version() == 1
+    from concepthash_amd import _lib
+    header = open(os.path.join(ROOT, "include", "concepthash_hip.h")).read()
+    assert lib.ch_abi_version() == 2 == _lib.ABI_VERSION == int(re.search(r"#define CH_ABI_VERSION (\d+)", header).group(1))
     st = lib.ch_pack_sign(None, -1, 0, 0.0, None, None)
     assert st != 0 and b"pack_sign" in lib.ch_last_error()
     st = lib.ch_hamming_topk(None, 4, None, 4, 9, 10, 0, None, None, None, 0, None)
     assert st != 0 and b"W" in lib.ch_last_error()
     st = lib.ch_hamming_topk(None, 4, None, 4, 1, 1000, 0, None, None, None, 0, None)
     assert st != 0 and b"k" in lib.ch_last_error()
+
+
+def test_the_library_reads_no_environment_variable():
+    """SURVEY.md section 8(b): "no hidden global state except an opaque handle".  Every knob is ch_model_set_option state of one handle;
+    the CH_* variables of earlier rounds survive as debug overrides read by the PYTHON wrapper only.  No product kernel source calls
+    getenv, every option key the wrapper knows is documented in the header, and every environment override maps onto such a key."""
+    from concepthash_amd import _lib, build
+    for src in build.SOURCES + build.HEADERS:
+        text = open(os.path.join(build.CSRC, src)).read()
+        assert "getenv" not in text, f"{src} reads the environment"
+    header = open(os.path.join(ROOT, "include", "concepthash_hip.h")).read()
+    for key in _lib.OPTION_KEYS:
+        assert f'"{key}"' in header, f"option {key} is not documented in the header"
+    assert {k for k, _ in _lib._ENV_OVERRIDES.values()} <= set(_lib.OPTION_KEYS)
+    model_src = open(os.path.join(build.CSRC, "model.hip")).read()
+    assert set(re.findall(r'\{"([a-z_]+)", [012], CH_OPT_FIELD', model_src)) == set(_lib.OPTION_KEYS)
+
+
+def test_option_and_capacity_arguments_are_validated_on_the_host(lib):
+    """ch_model_set_option / get_option / profile_end refuse null handles (no GPU needed to see the argument checks)."""
+    v = ctypes.c_int64()
+    assert lib.ch_model_set_option(None, b"streams", 1) != 0 and b"null model" in lib.ch_last_error()
+    assert lib.ch_model_get_option(None, b"streams", ctypes.byref(v)) != 0
+    assert lib.ch_model_profile_end(None, 20, None, None, None) != 0
+
+
+def test_env_overrides_are_read_in_the_wrapper(monkeypatch):
+    from concepthash_amd import _lib
+    for k in _lib._ENV_OVERRIDES:
+        monkeypatch.delenv(k, raising=False)
+    assert _lib.env_option_overrides() == {}
+    monkeypatch.setenv("CH_STREAMS", "1")
+    monkeypatch.setenv("CH_RESID_NT", "0")
+    monkeypatch.setenv("CH_NT_OUT", "1")
+    assert _lib.env_option_overrides() == {"streams": 1, "resid_nt": -1, "nt_out": 1}
 
 
 def test_model_config_validation_runs_on_host(lib):
@@ -151,6 +188,7 @@ def test_no_built_kernel_selects_the_high_half_of_src1_in_a_packed_fp32_instruct
     seen = 0
     for o in objs:
         if not mod.has_device_code(o):
+            assert not mod.expects_device_code(o), f"{o}: kernels in the source but no extractable device code"
             continue
         total, bad = mod.check_pk_opsel(o)
         seen += total

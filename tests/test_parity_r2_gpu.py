@@ -120,8 +120,8 @@ def test_cache_policy_instances_are_bit_identical(dev, monkeypatch, pp_min_k):
     h_base = enc.hidden_states(x, 2).clone()
     torch.cuda.synchronize()
     assert count() == c0                                     # forced off: default instances only
-    monkeypatch.setenv("CH_RESID_NT", "1")
-    monkeypatch.setenv("CH_NT_OUT", "1")
+    enc.set_option("resid_nt", 1)
+    enc.set_option("nt_out", 1)
     out = enc.encode(x, want=want)
     h = enc.hidden_states(x, 2)
     torch.cuda.synchronize()

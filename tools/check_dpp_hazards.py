@@ -62,10 +62,12 @@ def disassemble(obj):
         local = os.path.join(tmp, "k.o")
         shutil.copy(obj, local)
         subprocess.run([OBJDUMP, "-d", "--offloading", local], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        dev = [f for f in os.listdir(tmp) if "amdgcn" in f]
+        dev = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)
         if not dev:
             raise RuntimeError("no device code object found in " + obj)
-        return subprocess.run([OBJDUMP, "-d", os.path.join(tmp, dev[0])], stdout=subprocess.PIPE, check=True).stdout.decode()
+        # EVERY extracted amdgcn code object (one per offload arch / translation unit), not only the first
+        return "\n".join(subprocess.run([OBJDUMP, "-d", os.path.join(tmp, d)], stdout=subprocess.PIPE, check=True).stdout.decode()
+                         for d in dev)
 
 
 def functions(text):
@@ -258,10 +260,25 @@ def check_pk_opsel(obj):
 
 
 def product_objects():
+    """Objects the library on disk was linked from: the product sources, plus the experiment kernels when the last build was an
+    experiments build (csrc/build/experiments.flag, written by concepthash_amd.build) -- they are dispatchable there."""
     build = os.path.join(ROOT, "concepthash_amd", "csrc", "build")
     sys.path.insert(0, ROOT)
-    from concepthash_amd.build import SOURCES
-    return [os.path.join(build, os.path.basename(s).replace(".hip", ".o")) for s in SOURCES]
+    from concepthash_amd.build import EXPERIMENT_SOURCES, SOURCES
+    stamp = os.path.join(build, "experiments.flag")
+    experiments = os.path.exists(stamp) and open(stamp).read().strip() == "1"
+    return [os.path.join(build, os.path.basename(s).replace(".hip", ".o")) for s in SOURCES + (EXPERIMENT_SOURCES if experiments else [])]
+
+
+def expects_device_code(obj):
+    """True when the object's source defines kernels (`__global__`): then a failed extraction is an error, not 'host-only object'."""
+    sys.path.insert(0, ROOT)
+    from concepthash_amd.build import CSRC, EXPERIMENT_SOURCES, SOURCES
+    base = os.path.basename(obj).replace(".o", ".hip")
+    for s in SOURCES + EXPERIMENT_SOURCES:
+        if os.path.basename(s) == base:
+            return "__global__" in open(os.path.join(CSRC, s)).read()
+    return True
 
 
 def has_device_code(obj):
@@ -283,6 +300,9 @@ if __name__ == "__main__":
         n_bad = 0
         for o in product_objects():
             if not has_device_code(o):
+                if expects_device_code(o):
+                    print(f"{os.path.basename(o)}: NO device code could be extracted although its source defines kernels")
+                    n_bad += 1
                 continue
             t, b = check_pk_opsel(o)
             for x in b[:10]:

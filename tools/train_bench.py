@@ -42,6 +42,7 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         tf = tb = 0.0
         for it in range(a.warmup + a.steps):
+            eng.drop_grads()      # backward overwrites the arena: no accumulation clone + add inside the timed call
             ev[0].record()
             eng.forward(x, ctx)
             ev[1].record()

@@ -44,7 +44,7 @@ def _sharded():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def _evaluate(db_codes, db_labels, test_codes, test_labels, R, ks, remove_first):
+def _evaluate(db_codes, db_labels, test_codes, test_labels, R, ks, remove_first, skip=False):
     dev = _device()
     from concepthash_amd.distributed import RowShard
     if isinstance(db_codes, RowShard) or isinstance(test_codes, RowShard):
@@ -66,7 +66,7 @@ def _evaluate(db_codes, db_labels, test_codes, test_labels, R, ks, remove_first)
             ql, _ = _all_gather_ragged(tl.contiguous(), sr.group)
         else:
             ql = _labels(test_labels, dev)
-        return sr.evaluate(q, ql, R=R, ks=ks, remove_first=remove_first)
+        return sr.evaluate(q, ql, R=R, ks=ks, remove_first=remove_first, skip_queries_without_relevant=skip)
     q = rt.pack_sign(torch.as_tensor(test_codes).to(dev, torch.float32))
     if _sharded():
         # replicated inputs under an initialised process group (a caller that gathered its codes): every rank takes its block
@@ -76,23 +76,29 @@ def _evaluate(db_codes, db_labels, test_codes, test_labels, R, ks, remove_first)
         lo, hi = b[dist.get_rank()], b[dist.get_rank() + 1]
         g = rt.pack_sign(torch.as_tensor(db_codes[lo:hi]).to(dev, torch.float32))
         sr = ShardedRetrieval(g, _labels(db_labels[lo:hi], dev))
-        return sr.evaluate(q, _labels(test_labels, dev), R=R, ks=ks, remove_first=remove_first)
+        return sr.evaluate(q, _labels(test_labels, dev), R=R, ks=ks, remove_first=remove_first, skip_queries_without_relevant=skip)
     g = rt.pack_sign(torch.as_tensor(db_codes).to(dev, torch.float32))
-    return rt.evaluate(q, g, _labels(test_labels, dev), _labels(db_labels, dev), R=R, ks=ks, remove_first=remove_first)
+    return rt.evaluate(q, g, _labels(test_labels, dev), _labels(db_labels, dev), R=R, ks=ks, remove_first=remove_first,
+                       skip_queries_without_relevant=skip)
 
 
 def calculate_mAP(db_codes, db_labels, test_codes, test_labels, R, threshold=0., dist_metric="hamming", PRs=None,
-                  remove_first_retrieved=False, landmark_gt=None, db_id=None, test_id=None, multiclass=False):
+                  remove_first_retrieved=False, landmark_gt=None, db_id=None, test_id=None, multiclass=False,
+                  skip_queries_without_relevant=False):
     """-> (mAP, recalls, precisions); `mAP` is a list when `R` is a list (experiments/test_hashing.py:124-128).
     R <= 0 means the whole database.  One histogram pass + one AP pass whatever the length of R and PRs: every R and every k
-    is a rank limit of the same gallery scan."""
+    is a rank limit of the same gallery scan.
+    skip_queries_without_relevant (not a reference argument; the reference's un-vendored `utils.hashing` cannot be read, so the one
+    convention that changes numbers at R < database size is a switch): False (default) = a query with no relevant row inside its top
+    R contributes AP = 0 to the mean; True = such queries are left out of the mean, as the HashNet /
+    OrthoHash family of evaluators does.  mAP@all on CUB-200 / Cars196 / NABirds is the same under both."""
     _check(dist_metric, threshold, landmark_gt)
     ks = [int(k) for k in (PRs or [])]
     many = isinstance(R, (list, tuple)) or (hasattr(R, "__iter__") and not isinstance(R, (int, float)))
     Rs = [int(r) for r in R] if many else int(R)
     if many and not Rs:
         return [], [], []
-    res = _evaluate(db_codes, db_labels, test_codes, test_labels, Rs, ks, remove_first_retrieved)
+    res = _evaluate(db_codes, db_labels, test_codes, test_labels, Rs, ks, remove_first_retrieved, bool(skip_queries_without_relevant))
     return res["mAP"], res["recalls"], res["precisions"]
 
 
