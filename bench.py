@@ -24,6 +24,7 @@ rank 0, N == 1 only -- the CPU baselines on the host cores, on bounded samples o
 from __future__ import annotations
 
 import argparse
+import io
 import json
 import os
 import socket
@@ -61,13 +62,15 @@ def parse_args():
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step block (SURVEY.md section 8 row f4)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the single-stream profiled pass")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the evaluator-inclusive block (COOPTrainer.inference_one_epoch)")
+    ap.add_argument("--no-loader", action="store_true", help="skip the loader-inclusive block (JPEG files -> DataLoader -> decode -> encode)")
+    ap.add_argument("--loader-images", type=int, default=2048, help="JPEG files the loader-inclusive block generates and reads")
     ap.add_argument("--encode-only", action="store_true",
                     help="nothing but the timed encode + retrieve steps (and the roofline pass unless --no-roofline-pass): no "
                          "pcie / decode / evaluator / training / Hamming-scan / CPU-baseline blocks -- what the rocprofv3 passes of "
                          "tools/profile_round.sh trace, so that every kernel row of a summary is the encoder's")
     a = ap.parse_args()
     if a.encode_only:
-        a.no_cpu_baseline = a.no_hamming_scan = a.no_train_step = a.no_evaluator = True
+        a.no_cpu_baseline = a.no_hamming_scan = a.no_train_step = a.no_evaluator = a.no_loader = True
     return a
 
 
@@ -268,6 +271,10 @@ def main():
     # ---- decode-inclusive variant (outside the timed region): decoded uint8 bytes -> GPU pre-processing -> encode ------------
     if rank == 0 and not args.encode_only:
         result["decode_inclusive"] = decode_block(torch, enc, B, dev)
+
+    # ---- loader-inclusive variants (outside the timed region): JPEG FILES on disk -> DataLoader -> decode -> pre-process -> encode ----
+    if rank == 0 and not args.no_loader:
+        result["loader_inclusive"] = loader_block(torch, np, enc, B, dev, args.loader_images, value=result["value"] / world)
 
     # ---- evaluator-inclusive variant (outside the timed region): the reference's evaluation loop around the same model ------------
     if rank == 0 and not args.no_evaluator:
@@ -478,6 +485,103 @@ def decode_block(torch, enc, B, dev):
             "preprocess_gbs": round((B * h * w * 3 + B * 3 * 224 * 224 * 2) / s_pre / 1e9, 1),
             "note": f"{B} decoded {w}x{h} uint8 RGB images resident in HBM -> ch_preprocess (bit-equal to the PIL chain) -> "
                     f"ch_encode; host-side descriptor planning included; never used for `value`"}
+
+
+def loader_block(torch, np, enc, B, dev, nimg, value):
+    """SURVEY.md section 8 f1, the real front end: CUB-sized JPEG files (500 x 375, 4:2:0, quality 85) generated here with PIL, read back
+    through `engine.dataloader` worker processes, three ways:
+      cpu_loader   the reference's loader (engine.py:41-54, configs/dataset/cub200.yaml:31-47): workers PIL-decode AND run the
+                   Resize / CenterCrop / ToTensor / normalize chain; the fp32 batch is copied to the GPU and encoded;
+      gpu_preprocess  workers PIL-decode only; ch_preprocess + ch_encode on the GPU;
+      gpu_decode   workers only READ the files; host threads Huffman-decode (ch_jpeg_entropy_decode), the GPU does inverse DCT,
+                   upsampling, colour conversion (ch_jpeg_reconstruct), ch_preprocess, ch_encode.
+    Each mode: one warm-up pass over a quarter of the files (worker start-up, page cache), then a timed pass over all of them."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    import engine
+    from concepthash_amd.jpeg import GpuJpegDecoder, prefetch_decoded
+    from concepthash_amd.preprocess import GpuPreprocess
+    from utils import transforms as T
+    from utils.datasets import HashingDataset, OneHot
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    root = tempfile.mkdtemp(prefix="ch_loader_")
+    try:
+        os.makedirs(os.path.join(root, "img"))
+        h, w = 375, 500
+
+        def make(i):
+            rng = np.random.default_rng(1000 + i)
+            low = rng.integers(0, 256, (12 + i % 13, 16 + i % 11, 3), dtype=np.uint8)          # smooth structure at a random scale ...
+            img = np.asarray(Image.fromarray(low).resize((w, h), Image.BICUBIC), dtype=np.int16)
+            img = np.clip(img + rng.normal(0, 7, img.shape), 0, 255).astype(np.uint8)            # ... plus sensor-like noise
+            p = os.path.join(root, "img", f"{i}.jpg")
+            Image.fromarray(img).save(p, "JPEG", quality=85)
+            return os.path.getsize(p)
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=min(16, cores)) as ex:
+            sizes = list(ex.map(make, range(nimg)))
+        gen_s = time.perf_counter() - t0
+        with open(os.path.join(root, "test.txt"), "w") as f:
+            f.write("".join(f"img/{i}.jpg {i % NCLASS}\n" for i in range(nimg)))
+        chain = [T.Resize(256, T.interpolation("bicubic")), T.CenterCrop(224), T.ToTensor(), T.normalize_transform(3)]
+        pre = GpuPreprocess(256, 224, out_dtype=torch.bfloat16, device=dev)
+        dec = GpuJpegDecoder(device=dev)
+        out = {"files": nimg, "image_size": [h, w], "mean_file_kb": round(float(np.mean(sizes)) / 1024, 1), "host_cores_visible": cores,
+               "host_cores_used": min(16, cores), "generate_s": round(gen_s, 1)}
+        log(f"[bench] loader: {nimg} JPEG files ({out['mean_file_kb']} KiB mean) in {gen_s:.1f} s; {cores} host cores")
+
+        def run(mode, n):
+            ds = HashingDataset(root, "test.txt", transform=chain, target_transform=OneHot(NCLASS), gpu_preprocess=mode == "gpu_preprocess",
+                                gpu_decode=mode == "gpu_decode")
+            ds.items = ds.items[:n]
+            dl = engine.dataloader(ds, B, shuffle=False, drop_last=False)
+            t0 = time.perf_counter()
+            done = 0
+            it = prefetch_decoded(dl, dec) if mode == "gpu_decode" else dl      # host half of the decode one or two batches ahead
+            for image, labels, index in it:
+                if mode == "gpu_decode":
+                    image = pre(*image.finish())
+                elif mode == "gpu_preprocess":
+                    image = image.to(dev, non_blocking=True)
+                    image = pre(image.pixels, image.sizes)
+                else:
+                    image = image.to(dev, non_blocking=True)
+                enc.encode(image, want=("codes", "packed"))
+                done += labels.shape[0]
+            torch.cuda.synchronize()
+            sec = time.perf_counter() - t0
+            workers = dl.num_workers
+            del dl
+            return done / sec, workers
+
+        for mode in ("cpu_loader", "gpu_preprocess", "gpu_decode"):
+            run(mode, max(B, nimg // 4))
+            ips, workers = run(mode, nimg)
+            out[mode] = {"images_per_s": round(ips, 1), "vs_value": round(ips / value, 4), "loader_workers": workers}
+            if mode == "gpu_decode":
+                out[mode].update(decode_threads=dec.threads, pil_fallback=dec.stats["pil_fallback"])
+            log(f"[bench] loader {mode}: {ips:.0f} images/s")
+        # the decoder split alone, files already in memory: host entropy decode -> H2D -> reconstruct (no loader, no encode)
+        files = [np.fromfile(os.path.join(root, "img", f"{i}.jpg"), dtype=np.uint8) for i in range(B)]
+        dec.decode(files)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            dec.decode(files)
+        torch.cuda.synchronize()
+        out["gpu_decode"]["decoder_alone_images_per_s"] = round(4 * B / (time.perf_counter() - t0), 1)
+        t0 = time.perf_counter()
+        for f in files[:64]:
+            np.asarray(Image.open(io.BytesIO(f.tobytes())).convert("RGB"))
+        out["pil_decode_images_per_s_per_core"] = round(64 / (time.perf_counter() - t0), 1)
+        out["note"] = ("JPEG files on local disk (page cache warm) -> engine.dataloader workers -> ... -> ch_encode(codes, packed); wall clock "
+                       "of a full pass; cpu_loader is the reference's loader arrangement; never used for `value`")
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def evaluator_block(torch, syn, sd, cfg, B, dev, value):

@@ -27,6 +27,12 @@ class ImageDesc(Structure):
                [(n, c_int32) for n in ("h", "w", "nh", "nw", "top", "left", "row0", "nrows")]
 
 
+class JpegDesc(Structure):
+    _fields_ = [("coef_offset", c_int64), ("pix_offset", c_int64), ("plane_offset", c_int64)] + \
+               [(n, c_int32) for n in ("width", "height", "ncomp", "hs", "vs", "mcu_w", "mcu_h", "status", "nblocks", "reserved")] + \
+               [("quant", (ctypes.c_uint16 * 64) * 3)]
+
+
 class Tensor(Structure):
     _fields_ = [("name", c_char_p), ("data", POINTER(c_float)), ("numel", c_int64)]
 
@@ -61,6 +67,11 @@ SIGNATURES = {
     "ch_preprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p,
                               c_int32, c_void_p, c_void_p]),
     "ch_preprocess_max_taps": (c_int32, []),
+    "ch_jpeg_plan": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "ch_jpeg_entropy_decode": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32]),
+    "ch_jpeg_plan_packed": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "ch_jpeg_entropy_decode_packed": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32]),
+    "ch_jpeg_reconstruct": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "ch_pack_sign": (c_int, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "ch_hamming_dist": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "ch_hamming_topk_workspace": (c_size_t, [c_int64, c_int64, c_int32, c_int32]),

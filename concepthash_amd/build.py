@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libconcepthash_hip.so")
 SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip",
-           "preprocess.hip", "train_kernels.hip", "attention_bwd.hip", "train.hip"]
+           "preprocess.hip", "train_kernels.hip", "attention_bwd.hip", "train.hip", "jpeg.hip"]
 # kernels that lost to the dispatched ones (DESIGN.md sections 3.8-3.9): kept in csrc/experiments/ with their parity tests, compiled
 # only into an experiments build (CH_BUILD_EXPERIMENTS=1), never into the product library
 EXPERIMENT_SOURCES = [os.path.join("experiments", f) for f in ("gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "gemm_r4.hip",

@@ -1,0 +1,705 @@
+// JPEG decode split for the evaluation loader (reference: engine.py:41-54 DataLoader workers running
+// PIL `Image.open(...).convert("RGB")` = libjpeg-turbo, then configs/dataset/cub200.yaml:31-47's transform chain).
+//
+// A 20k images/s encoder outruns any CPU-side full decode (PIL: ~1.5-2 ms per 500x375 image per core), so the decoder is split where
+// the hardware splits it:
+//   * HOST (this file, plain C++, `ch_jpeg_plan` / `ch_jpeg_entropy_decode`): marker parsing and the Huffman entropy decode -- a serial
+//     bit-stream walk, ~25 % of libjpeg's decode time -- on a pool of host threads, straight into a pinned buffer of int16 coefficient
+//     blocks (natural order, DC prediction undone);
+//   * GPU (`ch_jpeg_reconstruct`): dequantisation + 8x8 inverse DCT + chroma upsampling + YCbCr -> RGB, i.e. everything that is
+//     data-parallel, written as decoded RGB bytes in the layout `ch_preprocess` consumes.
+// The GPU half restates libjpeg-turbo's DEFAULT decompression arithmetic (what Pillow runs): `jpeg_idct_islow` (jidctint.c: 13-bit
+// fixed-point LL&M, two passes, descale 11 / 18, range limit through the post-IDCT table), `h2v1_fancy_upsample` / `h2v2_fancy_upsample`
+// (jdsample.c: triangle filter, biases 1/2 and 8/7, edge columns special-cased, context rows clamped at the image's first / last sample
+// row as jdmainct.c's funny pointers do) and `ycc_rgb_convert` (jdcolor.c: 16-bit fixed-point tables).  Integer arithmetic throughout:
+// the RGB bytes are BIT-EQUAL to Pillow's on every supported file (tests/test_jpeg.py, against PIL itself).
+// Supported: 8-bit baseline / extended-sequential Huffman (SOF0 / SOF1), one interleaved scan, 1 component (grey) or 3 components
+// (YCbCr) with luma sampling 1x1 (4:4:4), 2x1 (4:2:2) or 2x2 (4:2:0) and chroma 1x1, restart intervals.  Anything else (progressive,
+// arithmetic, CMYK / Adobe RGB, 12 bit, multi-scan, exotic sampling, tiny images) gets a non-zero `status` in its descriptor: the host
+// side of the loader decodes exactly those files with PIL -- the reference's own path -- and counts them.
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/concepthash_hip.h"
+#include "ch_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host: marker parsing
+// ---------------------------------------------------------------------------------------------------------------------------------
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+constexpr int LOOK = 9;  // look-ahead bits of the Huffman tables
+
+struct Huff {
+    bool present = false;
+    uint8_t counts[17] = {};
+    uint8_t vals[256] = {};
+    // derived
+    uint16_t look[1 << LOOK];     // (length << 8) | symbol for codes of <= LOOK bits, 0 otherwise
+    int32_t maxcode[18];          // largest code of each length (left-justified compare), -1 if none
+    int32_t valoff[17];           // vals index of the first code of each length minus that code
+    int16_t fast_ac[1 << LOOK];   // AC tables: (value << 8) | (run << 4) | total bits, when code + magnitude fit in LOOK bits; 0 otherwise
+};
+
+bool build_huff(Huff &h, bool is_ac) {
+    int code = 0, k = 0;
+    uint16_t codes[256];
+    uint8_t sizes[256];
+    for (int len = 1; len <= 16; ++len) {
+        for (int i = 0; i < h.counts[len]; ++i) {
+            if (k >= 256) return false;
+            codes[k] = (uint16_t)code++;
+            sizes[k++] = (uint8_t)len;
+        }
+        if (code > (1 << len)) return false;   // over-subscribed
+        code <<= 1;
+    }
+    std::memset(h.look, 0, sizeof(h.look));
+    int p = 0;
+    code = 0;
+    for (int len = 1; len <= 16; ++len) {
+        if (h.counts[len]) {
+            h.valoff[len] = p - codes[p];
+            p += h.counts[len];
+            h.maxcode[len] = codes[p - 1];
+        } else {
+            h.maxcode[len] = -1;
+            h.valoff[len] = 0;
+        }
+    }
+    h.maxcode[17] = 0x7fffffff;
+    for (int i = 0; i < k; ++i) {
+        if (sizes[i] <= LOOK) {
+            const int first = codes[i] << (LOOK - sizes[i]);
+            for (int j = 0; j < (1 << (LOOK - sizes[i])); ++j) h.look[first + j] = (uint16_t)((sizes[i] << 8) | h.vals[i]);
+        }
+    }
+    std::memset(h.fast_ac, 0, sizeof(h.fast_ac));
+    if (is_ac) {
+        for (int i = 0; i < (1 << LOOK); ++i) {
+            const uint16_t e = h.look[i];
+            if (!e) continue;
+            const int len = e >> 8, rs = e & 255, run = rs >> 4, mag = rs & 15;
+            if (mag && len + mag <= LOOK) {
+                int v = ((i << len) & ((1 << LOOK) - 1)) >> (LOOK - mag);
+                if (v < (1 << (mag - 1))) v += (int)((~0u) << mag) + 1;   // EXTEND
+                if (v >= -128 && v <= 127) h.fast_ac[i] = (int16_t)((v * 256) + (run * 16) + (len + mag));
+            }
+        }
+    }
+    h.present = true;
+    return true;
+}
+
+struct Parsed {
+    int status = 0;
+    int width = 0, height = 0, ncomp = 0, hs = 1, vs = 1, restart = 0;
+    int tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    uint16_t quant[4][64];
+    bool have_q[4] = {false, false, false, false};
+    Huff dc[4], ac[4];
+    int64_t scan_begin = 0;   // first byte of the entropy-coded segment
+};
+
+// status codes (also documented in include/concepthash_hip.h)
+enum {
+    JS_OK = 0, JS_NOT_JPEG = 1, JS_TRUNCATED = 2, JS_PROGRESSIVE_OR_OTHER_SOF = 3, JS_PRECISION = 4, JS_COMPONENTS = 5,
+    JS_SAMPLING = 6, JS_MULTISCAN = 7, JS_COLORSPACE = 8, JS_TABLES = 9, JS_TINY = 10, JS_CORRUPT = 11
+};
+
+inline int rd16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
+
+// header-only parse when `full` is false (no Huffman table construction)
+void parse(const uint8_t *d, int64_t n, Parsed &P, bool full) {
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) { P.status = JS_NOT_JPEG; return; }
+    int64_t pos = 2;
+    bool jfif = false, adobe = false, sof = false;
+    int adobe_transform = -1;
+    int comp_id[3] = {0, 0, 0}, comp_h[3] = {1, 1, 1}, comp_v[3] = {1, 1, 1};
+    while (true) {
+        if (pos + 4 > n) { P.status = JS_TRUNCATED; return; }
+        if (d[pos] != 0xFF) { P.status = JS_CORRUPT; return; }
+        while (pos < n && d[pos] == 0xFF) ++pos;   // fill bytes
+        if (pos >= n) { P.status = JS_TRUNCATED; return; }
+        const int m = d[pos++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;   // standalone markers
+        if (m == 0xD9) { P.status = JS_TRUNCATED; return; }                   // EOI before SOS
+        if (pos + 2 > n) { P.status = JS_TRUNCATED; return; }
+        const int len = rd16(d + pos);
+        if (len < 2 || pos + len > n) { P.status = JS_TRUNCATED; return; }
+        const uint8_t *s = d + pos + 2;
+        const int sl = len - 2;
+        switch (m) {
+            case 0xE0: if (sl >= 5 && !std::memcmp(s, "JFIF\0", 5)) jfif = true; break;
+            case 0xEE: if (sl >= 12 && !std::memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; } break;
+            case 0xDB: {
+                int o = 0;
+                while (o < sl) {
+                    const int pq = s[o] >> 4, t = s[o] & 15;
+                    ++o;
+                    if (t > 3 || o + (pq ? 128 : 64) > sl) { P.status = JS_TABLES; return; }
+                    for (int i = 0; i < 64; ++i) {
+                        const int v = pq ? rd16(s + o + 2 * i) : s[o + i];
+                        P.quant[t][kZigzag[i]] = (uint16_t)v;
+                    }
+                    P.have_q[t] = true;
+                    o += pq ? 128 : 64;
+                }
+                break;
+            }
+            case 0xC0: case 0xC1: {
+                if (sof) { P.status = JS_CORRUPT; return; }
+                sof = true;
+                if (sl < 6) { P.status = JS_TRUNCATED; return; }
+                if (s[0] != 8) { P.status = JS_PRECISION; return; }
+                P.height = rd16(s + 1);
+                P.width = rd16(s + 3);
+                P.ncomp = s[5];
+                if (P.ncomp != 1 && P.ncomp != 3) { P.status = JS_COMPONENTS; return; }
+                if (sl < 6 + 3 * P.ncomp || P.height == 0 || P.width == 0) { P.status = JS_CORRUPT; return; }
+                for (int c = 0; c < P.ncomp; ++c) {
+                    comp_id[c] = s[6 + 3 * c];
+                    comp_h[c] = s[7 + 3 * c] >> 4;
+                    comp_v[c] = s[7 + 3 * c] & 15;
+                    P.tq[c] = s[8 + 3 * c];
+                    if (P.tq[c] > 3) { P.status = JS_TABLES; return; }
+                }
+                break;
+            }
+            case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+                if (sl >= 6) {   // every SOFn has the same header: the caller's own decoder is told the size of the slot it fills
+                    P.height = rd16(s + 1);
+                    P.width = rd16(s + 3);
+                }
+                P.status = JS_PROGRESSIVE_OR_OTHER_SOF;
+                return;
+            case 0xC4: {
+                int o = 0;
+                while (o < sl) {
+                    if (o + 17 > sl) { P.status = JS_TABLES; return; }
+                    const int cls = s[o] >> 4, id = s[o] & 15;
+                    if (cls > 1 || id > 3) { P.status = JS_TABLES; return; }
+                    Huff &h = cls ? P.ac[id] : P.dc[id];
+                    int total = 0;
+                    h.counts[0] = 0;
+                    for (int i = 1; i <= 16; ++i) { h.counts[i] = s[o + i]; total += s[o + i]; }
+                    o += 17;
+                    if (total > 256 || o + total > sl) { P.status = JS_TABLES; return; }
+                    std::memcpy(h.vals, s + o, total);
+                    o += total;
+                    if (full) { if (!build_huff(h, cls == 1)) { P.status = JS_TABLES; return; } }
+                    else h.present = true;
+                }
+                break;
+            }
+            case 0xDD: if (sl >= 2) P.restart = rd16(s); break;
+            case 0xDA: {
+                if (!sof) { P.status = JS_CORRUPT; return; }
+                if (sl < 1 || s[0] != P.ncomp || sl < 1 + 2 * P.ncomp + 3) { P.status = JS_MULTISCAN; return; }
+                for (int c = 0; c < P.ncomp; ++c) {
+                    if (s[1 + 2 * c] != comp_id[c]) { P.status = JS_MULTISCAN; return; }
+                    P.td[c] = s[2 + 2 * c] >> 4;
+                    P.ta[c] = s[2 + 2 * c] & 15;
+                    if (P.td[c] > 3 || P.ta[c] > 3 || !P.dc[P.td[c]].present || !P.ac[P.ta[c]].present || !P.have_q[P.tq[c]]) {
+                        P.status = JS_TABLES;
+                        return;
+                    }
+                }
+                const uint8_t *t = s + 1 + 2 * P.ncomp;
+                if (t[0] != 0 || t[1] != 63 || t[2] != 0) { P.status = JS_PROGRESSIVE_OR_OTHER_SOF; return; }
+                // colour space, as libjpeg's default_decompress_parms decides it
+                if (P.ncomp == 3) {
+                    bool ycc;
+                    if (jfif) ycc = true;
+                    else if (adobe) ycc = adobe_transform == 1;
+                    else ycc = comp_id[0] == 1 && comp_id[1] == 2 && comp_id[2] == 3;
+                    if (!ycc) { P.status = JS_COLORSPACE; return; }
+                    if (comp_h[1] != 1 || comp_v[1] != 1 || comp_h[2] != 1 || comp_v[2] != 1) { P.status = JS_SAMPLING; return; }
+                    if (!((comp_h[0] == 1 && comp_v[0] == 1) || (comp_h[0] == 2 && comp_v[0] == 1) || (comp_h[0] == 2 && comp_v[0] == 2))) {
+                        P.status = JS_SAMPLING;
+                        return;
+                    }
+                    P.hs = comp_h[0];
+                    P.vs = comp_v[0];
+                } else {
+                    P.hs = P.vs = 1;   // a single-component scan is non-interleaved: one block per MCU whatever the factors say
+                }
+                if (P.width < 16 || P.height < 16) { P.status = JS_TINY; return; }   // the fancy upsamplers' narrow-image special cases
+                P.scan_begin = pos + len;
+                return;
+            }
+            default: break;
+        }
+        pos += len;
+    }
+}
+
+void fill_desc(const Parsed &P, ch_jpeg_desc &d) {
+    std::memset(&d, 0, sizeof(d));
+    d.status = P.status;
+    d.width = P.width;
+    d.height = P.height;
+    if (P.status) return;
+    d.ncomp = P.ncomp;
+    d.hs = P.hs;
+    d.vs = P.vs;
+    d.mcu_w = (P.width + 8 * P.hs - 1) / (8 * P.hs);
+    d.mcu_h = (P.height + 8 * P.vs - 1) / (8 * P.vs);
+    for (int c = 0; c < P.ncomp; ++c)
+        for (int i = 0; i < 64; ++i) d.quant[c][i] = P.quant[P.tq[c]][i];
+    const int64_t y = (int64_t)d.mcu_w * d.hs * d.mcu_h * d.vs;
+    d.nblocks = (int32_t)(d.ncomp == 3 ? y + 2 * (int64_t)d.mcu_w * d.mcu_h : y);
+}
+
+inline int64_t blocks_of(const ch_jpeg_desc &d) { return d.nblocks; }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host: Huffman entropy decode of one image into int16 coefficient blocks (natural order)
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct BitReader {
+    const uint8_t *p, *end;
+    uint64_t acc = 0;   // valid bits are the TOP `bits` bits
+    int bits = 0;
+    bool marker = false;   // a marker (FF xx, xx != 0) was reached: only zero bits are fed from here on
+
+    // callers need at most 31 valid bits at a time (a 16-bit code + a 15-bit magnitude): top up only when fewer than 32 are left
+    inline void ensure32() {
+        if (bits < 32) refill();
+    }
+    void refill() {
+        while (bits <= 56) {
+            if (!marker && p + 8 <= end) {
+                uint64_t v;
+                std::memcpy(&v, p, 8);
+                // any 0xFF byte among the next 8?  (byte-wise test for a zero byte of ~v)
+                const uint64_t nv = ~v;
+                if (!((nv - 0x0101010101010101ull) & ~nv & 0x8080808080808080ull)) {
+                    const int take = (64 - bits) >> 3;   // whole bytes that fit: 1..8
+                    v = __builtin_bswap64(v);
+                    if (take == 8) {
+                        acc = v;
+                        bits = 64;
+                    } else {
+                        acc |= (v >> (64 - 8 * take)) << (64 - bits - 8 * take);
+                        bits += 8 * take;
+                    }
+                    p += take;
+                    continue;
+                }
+            }
+            unsigned b = 0;
+            if (!marker && p < end) {
+                b = *p;
+                if (b == 0xFF) {
+                    if (p + 1 < end && p[1] == 0) p += 2;
+                    else { marker = true; b = 0; }
+                } else {
+                    ++p;
+                }
+            } else {
+                marker = true;
+            }
+            acc |= (uint64_t)b << (56 - bits);
+            bits += 8;
+        }
+    }
+    inline unsigned peek(int n) const { return (unsigned)(acc >> (64 - n)); }
+    inline void skip(int n) { acc <<= n; bits -= n; }
+};
+
+inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v + (int)((~0u) << s) + 1 : v; }
+
+// -> symbol, or -1 on a bad code.  Needs >= 16 valid bits.
+inline int decode_sym(BitReader &br, const Huff &h) {
+    const unsigned look = br.peek(LOOK);
+    const uint16_t e = h.look[look];
+    if (e) {
+        br.skip(e >> 8);
+        return e & 255;
+    }
+    const unsigned top = br.peek(16);
+    for (int len = LOOK + 1; len <= 16; ++len) {
+        const int code = (int)(top >> (16 - len));
+        if (code <= h.maxcode[len]) {
+            br.skip(len);
+            return h.vals[(code + h.valoff[len]) & 255];
+        }
+    }
+    return -1;
+}
+
+bool decode_block(BitReader &br, const Huff &dc, const Huff &ac, int &pred, int16_t *blk) {
+    std::memset(blk, 0, 128);
+    br.ensure32();
+    int s = decode_sym(br, dc);
+    if (s < 0 || s > 11) return false;
+    if (s) {
+        const int v = (int)br.peek(s);
+        br.skip(s);
+        pred += extend(v, s);
+    }
+    blk[0] = (int16_t)pred;
+    int k = 1;
+    while (k < 64) {
+        br.ensure32();
+        const int16_t f = ac.fast_ac[br.peek(LOOK)];
+        if (f) {
+            k += (f >> 4) & 15;
+            if (k > 63) return false;
+            br.skip(f & 15);
+            blk[kZigzag[k++]] = (int16_t)(f >> 8);
+            continue;
+        }
+        const int rs = decode_sym(br, ac);
+        if (rs < 0) return false;
+        const int r = rs >> 4, sz = rs & 15;
+        if (!sz) {
+            if (r != 15) break;   // EOB
+            k += 16;
+            continue;
+        }
+        k += r;
+        if (k > 63) return false;
+        const int v = (int)br.peek(sz);
+        br.skip(sz);
+        blk[kZigzag[k++]] = (int16_t)extend(v, sz);
+    }
+    return true;
+}
+
+// coef: this image's blocks -- component 0 [rows][cols][64], then components 1, 2
+int entropy_decode_one(const uint8_t *d, int64_t n, const ch_jpeg_desc &desc, int16_t *coef) {
+    Parsed P;
+    parse(d, n, P, true);
+    if (P.status) return P.status;
+    BitReader br;
+    br.p = d + P.scan_begin;
+    br.end = d + n;
+    int pred[3] = {0, 0, 0};
+    const int ybw = desc.mcu_w * desc.hs;   // luma blocks per row
+    int16_t *cb = coef + (int64_t)64 * ybw * desc.mcu_h * desc.vs;
+    int16_t *cr = cb + (int64_t)64 * desc.mcu_w * desc.mcu_h;
+    const Huff &dc0 = P.dc[P.td[0]], &ac0 = P.ac[P.ta[0]];
+    int to_restart = P.restart, next_rst = 0;
+    for (int my = 0; my < desc.mcu_h; ++my) {
+        for (int mx = 0; mx < desc.mcu_w; ++mx) {
+            if (P.restart) {
+                if (to_restart == 0) {
+                    // byte-align, expect RSTn
+                    br.acc = 0;
+                    br.bits = 0;
+                    br.marker = false;
+                    const uint8_t *q = br.p;
+                    while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) {
+                        if (q[0] == 0xFF && q[1] != 0 && q[1] != 0xFF) return JS_CORRUPT;
+                        ++q;
+                    }
+                    if (q + 1 >= br.end || q[1] != 0xD0 + next_rst) return JS_CORRUPT;
+                    br.p = q + 2;
+                    next_rst = (next_rst + 1) & 7;
+                    pred[0] = pred[1] = pred[2] = 0;
+                    to_restart = P.restart;
+                }
+                --to_restart;
+            }
+            for (int v = 0; v < desc.vs; ++v)
+                for (int h = 0; h < desc.hs; ++h) {
+                    int16_t *blk = coef + (int64_t)64 * ((int64_t)(my * desc.vs + v) * ybw + mx * desc.hs + h);
+                    if (!decode_block(br, dc0, ac0, pred[0], blk)) return JS_CORRUPT;
+                }
+            if (desc.ncomp == 3) {
+                const int64_t ci = (int64_t)64 * ((int64_t)my * desc.mcu_w + mx);
+                if (!decode_block(br, P.dc[P.td[1]], P.ac[P.ta[1]], pred[1], cb + ci)) return JS_CORRUPT;
+                if (!decode_block(br, P.dc[P.td[2]], P.ac[P.ta[2]], pred[2], cr + ci)) return JS_CORRUPT;
+            }
+        }
+    }
+    return JS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// GPU: dequantise + jpeg_idct_islow, one thread per 8x8 block -> component planes (uint8)
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int CONST_BITS = 13, PASS1_BITS = 2;
+constexpr int F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 4433, F_0_765366865 = 6270, F_0_899976223 = 7373,
+              F_1_175875602 = 9633, F_1_501321110 = 12299, F_1_847759065 = 15137, F_1_961570560 = 16069, F_2_053119869 = 16819,
+              F_2_562915447 = 20995, F_3_072711026 = 25172;
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// the post-IDCT range-limit table of jdmaster.c (prepare_range_limit_table), index = value & RANGE_MASK (1023), level shift included
+__device__ __forceinline__ int idct_limit(int x) {
+    const int v = x & 1023;
+    return v < 128 ? v + 128 : v < 512 ? 255 : v < 896 ? 0 : v - 896;
+}
+
+// one 1-D pass of jidctint.c on eight (dequantised) values; SHIFT = CONST_BITS - PASS1_BITS in pass 1, CONST_BITS + PASS1_BITS + 3 in pass 2
+template <int SHIFT>
+__device__ __forceinline__ void idct_1d(const int (&in)[8], int (&out)[8]) {
+    int z2 = in[2], z3 = in[6];
+    int z1 = (z2 + z3) * F_0_541196100;
+    int tmp2 = z1 + z3 * (-F_1_847759065);
+    int tmp3 = z1 + z2 * F_0_765366865;
+    z2 = in[0];
+    z3 = in[4];
+    int tmp0 = (z2 + z3) << CONST_BITS;
+    int tmp1 = (z2 - z3) << CONST_BITS;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[7];
+    tmp1 = in[5];
+    tmp2 = in[3];
+    tmp3 = in[1];
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * F_1_175875602;
+    tmp0 *= F_0_298631336;
+    tmp1 *= F_2_053119869;
+    tmp2 *= F_3_072711026;
+    tmp3 *= F_1_501321110;
+    z1 *= -F_0_899976223;
+    z2 *= -F_2_562915447;
+    z3 *= -F_1_961570560;
+    z4 *= -F_0_390180644;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    out[0] = descale(tmp10 + tmp3, SHIFT);
+    out[7] = descale(tmp10 - tmp3, SHIFT);
+    out[1] = descale(tmp11 + tmp2, SHIFT);
+    out[6] = descale(tmp11 - tmp2, SHIFT);
+    out[2] = descale(tmp12 + tmp1, SHIFT);
+    out[5] = descale(tmp12 - tmp1, SHIFT);
+    out[3] = descale(tmp13 + tmp0, SHIFT);
+    out[4] = descale(tmp13 - tmp0, SHIFT);
+}
+
+__global__ __launch_bounds__(128) void jpeg_idct_kernel(const int16_t *__restrict__ coef, const ch_jpeg_desc *__restrict__ descs,
+                                                        uint8_t *__restrict__ planes) {
+    const ch_jpeg_desc &d = descs[blockIdx.y];
+    if (d.status) return;
+    const int ybw = d.mcu_w * d.hs, ybh = d.mcu_h * d.vs;
+    const int nby = ybw * ybh, nbc = d.mcu_w * d.mcu_h;
+    const int total = d.ncomp == 3 ? nby + 2 * nbc : nby;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= total) return;
+    int comp = 0, local = b, bw = ybw;
+    int64_t plane_off = d.plane_offset;
+    if (b >= nby) {
+        comp = 1 + (b - nby) / nbc;
+        local = (b - nby) - (comp - 1) * nbc;
+        bw = d.mcu_w;
+        plane_off += (int64_t)nby * 64 + (int64_t)(comp - 1) * nbc * 64;
+    }
+    const int by = local / bw, bx = local - by * bw;
+    // 64 coefficients and 64 table entries as eight 16-byte loads each (both 16-byte aligned: blocks are 128 bytes, quant sits at
+    // offset 64 of the descriptor)
+    union Row {
+        uint4 v;
+        int16_t s[8];
+        uint16_t u[8];
+    } cr[8], qr[8];
+    const uint4 *c4 = (const uint4 *)(coef + d.coef_offset + (int64_t)b * 64), *q4 = (const uint4 *)d.quant[comp];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        cr[r].v = c4[r];
+        qr[r].v = q4[r];
+    }
+    int ws[8][8];   // [row][col] after pass 1
+#pragma unroll
+    for (int col = 0; col < 8; ++col) {
+        int in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = (int)cr[r].s[col] * (int)qr[r].u[col];
+        idct_1d<CONST_BITS - PASS1_BITS>(in, out);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[r][col] = out[r];
+    }
+    uint8_t *dst = planes + plane_off + ((int64_t)by * 8 * bw + bx) * 8;
+    const int pitch = bw * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int out[8];
+        idct_1d<CONST_BITS + PASS1_BITS + 3>(ws[r], out);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lo |= (uint32_t)idct_limit(out[i]) << (8 * i);
+            hi |= (uint32_t)idct_limit(out[4 + i]) << (8 * i);
+        }
+        *(uint2 *)(dst + (int64_t)r * pitch) = make_uint2(lo, hi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// GPU: fancy upsampling (jdsample.c) + YCbCr -> RGB (jdcolor.c), one thread per output pixel
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+
+// chroma sample at full-resolution position (x, y) of a plane of dw x dh REAL samples (pitch >= dw)
+__device__ __forceinline__ int chroma_at(const uint8_t *pl, int pitch, int dw, int dh, int hs, int vs, int x, int y) {
+    if (hs == 1) return pl[(int64_t)y * pitch + x];   // 4:4:4
+    const int i = x >> 1, odd = x & 1;
+    if (vs == 1) {   // h2v1_fancy_upsample
+        const uint8_t *row = pl + (int64_t)y * pitch;
+        const int v = row[i];
+        if (odd) return i == dw - 1 ? v : (3 * v + row[i + 1] + 2) >> 2;
+        return i == 0 ? v : (3 * v + row[i - 1] + 1) >> 2;
+    }
+    // h2v2_fancy_upsample: the nearer input row weighs 3, the farther 1; the row above the first / below the last REAL sample row
+    // is that row itself (jdmainct.c: make_funny_pointers / set_bottom_pointers)
+    const int r = y >> 1;
+    int far = (y & 1) ? r + 1 : r - 1;
+    far = far < 0 ? 0 : far > dh - 1 ? dh - 1 : far;
+    const uint8_t *n0 = pl + (int64_t)r * pitch, *n1 = pl + (int64_t)far * pitch;
+    const int cs = 3 * n0[i] + n1[i];
+    if (odd) {
+        if (i == dw - 1) return (cs * 4 + 7) >> 4;
+        return (cs * 3 + (3 * n0[i + 1] + n1[i + 1]) + 7) >> 4;
+    }
+    if (i == 0) return (cs * 4 + 8) >> 4;
+    return (cs * 3 + (3 * n0[i - 1] + n1[i - 1]) + 8) >> 4;
+}
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(const ch_jpeg_desc *__restrict__ descs, const uint8_t *__restrict__ planes,
+                                                         uint8_t *__restrict__ pixels) {
+    const ch_jpeg_desc &d = descs[blockIdx.z];
+    if (d.status) return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= d.width || y >= d.height) return;
+    const int ypitch = d.mcu_w * d.hs * 8, yrows = d.mcu_h * d.vs * 8;
+    const uint8_t *py = planes + d.plane_offset;
+    const int Y = py[(int64_t)y * ypitch + x];
+    uint8_t *out = pixels + d.pix_offset + ((int64_t)y * d.width + x) * 3;
+    if (d.ncomp == 1) {
+        out[0] = out[1] = out[2] = (uint8_t)Y;
+        return;
+    }
+    const int cpitch = d.mcu_w * 8;
+    const uint8_t *pcb = py + (int64_t)ypitch * yrows, *pcr = pcb + (int64_t)cpitch * d.mcu_h * 8;
+    const int dw = (d.width + d.hs - 1) / d.hs, dh = (d.height + d.vs - 1) / d.vs;
+    const int cb = chroma_at(pcb, cpitch, dw, dh, d.hs, d.vs, x, y) - 128;
+    const int cr = chroma_at(pcr, cpitch, dw, dh, d.hs, d.vs, x, y) - 128;
+    // jdcolor.c build_ycc_rgb_table: SCALEBITS 16, FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
+    const int r = Y + ((91881 * cr + 32768) >> 16);
+    const int b = Y + ((116130 * cb + 32768) >> 16);
+    const int g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+    out[0] = (uint8_t)clamp255(r);
+    out[1] = (uint8_t)clamp255(g);
+    out[2] = (uint8_t)clamp255(b);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" int ch_jpeg_plan(const uint8_t *const *files, const int64_t *lens, int32_t n, ch_jpeg_desc *desc, int64_t *total_coef,
+                            int64_t *total_pix, int64_t *total_plane) {
+    CH_REQUIRE(n >= 0 && (n == 0 || (files && lens && desc)), "jpeg_plan: null argument");
+    int64_t co = 0, po = 0, pl = 0;
+    for (int i = 0; i < n; ++i) {
+        Parsed P;
+        if (!files[i] || lens[i] < 4) P.status = JS_NOT_JPEG;
+        else parse(files[i], lens[i], P, false);
+        fill_desc(P, desc[i]);
+        desc[i].coef_offset = co;
+        desc[i].pix_offset = po;
+        desc[i].plane_offset = pl;
+        if (!P.status) {
+            const int64_t nb = blocks_of(desc[i]);
+            co += nb * 64;
+            pl += (nb * 64 + 15) / 16 * 16;
+        }
+        po += (int64_t)desc[i].width * desc[i].height * 3;   // fallback images (status != 0 but a readable size) keep their slot
+    }
+    if (total_coef) *total_coef = co;
+    if (total_pix) *total_pix = po;
+    if (total_plane) *total_plane = pl;
+    return 0;
+}
+
+extern "C" int ch_jpeg_entropy_decode(const uint8_t *const *files, const int64_t *lens, int32_t n, ch_jpeg_desc *desc, int16_t *coef_host,
+                                      int32_t nthreads) {
+    CH_REQUIRE(n >= 0 && (n == 0 || (files && lens && desc && coef_host)), "jpeg_entropy_decode: null argument");
+    if (n == 0) return 0;
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            if (desc[i].status) continue;
+            const int st = entropy_decode_one(files[i], lens[i], desc[i], coef_host + desc[i].coef_offset);
+            if (st) desc[i].status = st;   // a corrupt stream: the caller falls back to its host decoder for this file
+        }
+    };
+    const int nt = std::max(1, std::min<int>(nthreads, n));
+    if (nt == 1) {
+        work();
+        return 0;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(nt - 1);
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    return 0;
+}
+
+// the same two host calls for a batch whose files sit back to back in ONE buffer (what a `gpu_decode` loader worker produces):
+// file i = data[offsets[i], offsets[i + 1]); no per-file pointers for the caller to build
+extern "C" int ch_jpeg_plan_packed(const uint8_t *data, const int64_t *offsets, int32_t n, ch_jpeg_desc *desc, int64_t *total_coef,
+                                   int64_t *total_pix, int64_t *total_plane) {
+    CH_REQUIRE(n >= 0 && (n == 0 || (data && offsets && desc)), "jpeg_plan_packed: null argument");
+    std::vector<const uint8_t *> files(n);
+    std::vector<int64_t> lens(n);
+    for (int i = 0; i < n; ++i) {
+        CH_REQUIRE(offsets[i + 1] >= offsets[i], "jpeg_plan_packed: offsets must be non-decreasing");
+        files[i] = data + offsets[i];
+        lens[i] = offsets[i + 1] - offsets[i];
+    }
+    return ch_jpeg_plan(files.data(), lens.data(), n, desc, total_coef, total_pix, total_plane);
+}
+extern "C" int ch_jpeg_entropy_decode_packed(const uint8_t *data, const int64_t *offsets, int32_t n, ch_jpeg_desc *desc, int16_t *coef_host,
+                                             int32_t nthreads) {
+    CH_REQUIRE(n >= 0 && (n == 0 || (data && offsets && desc && coef_host)), "jpeg_entropy_decode_packed: null argument");
+    std::vector<const uint8_t *> files(n);
+    std::vector<int64_t> lens(n);
+    for (int i = 0; i < n; ++i) {
+        files[i] = data + offsets[i];
+        lens[i] = offsets[i + 1] - offsets[i];
+    }
+    return ch_jpeg_entropy_decode(files.data(), lens.data(), n, desc, coef_host, nthreads);
+}
+
+extern "C" int ch_jpeg_reconstruct(const int16_t *coef_dev, const ch_jpeg_desc *desc_dev, const ch_jpeg_desc *desc_host, int32_t n,
+                                   uint8_t *planes_ws, uint8_t *pixels, void *stream) {
+    CH_REQUIRE(n >= 0, "jpeg_reconstruct: negative image count");
+    if (n == 0) return 0;
+    CH_REQUIRE(coef_dev && desc_dev && desc_host && planes_ws && pixels, "jpeg_reconstruct: null argument");
+    CH_REQUIRE(n <= 65535, "jpeg_reconstruct: at most 65535 images per call");
+    int64_t max_blocks = 0;
+    int max_w = 0, max_h = 0;
+    for (int i = 0; i < n; ++i) {
+        if (desc_host[i].status) continue;
+        max_blocks = std::max<int64_t>(max_blocks, blocks_of(desc_host[i]));
+        max_w = std::max(max_w, desc_host[i].width);
+        max_h = std::max(max_h, desc_host[i].height);
+    }
+    if (max_blocks == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((max_blocks + 127) / 128), n), dim3(128), 0, s, coef_dev, desc_dev, planes_ws);
+    CH_LAUNCH_CHECK();
+    CH_REQUIRE(max_h <= 65535, "jpeg_reconstruct: image taller than 65535 rows");
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_w + 255) / 256, max_h, n), dim3(256), 0, s, desc_dev, planes_ws, pixels);
+    CH_LAUNCH_CHECK();
+    return 0;
+}

@@ -11,6 +11,29 @@ from torch.utils.data import DataLoader
 default_workers = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
 
 
+_forkserver_ready = False
+
+
+def _worker_context(workers):
+    """How loader workers are started.  On MI355X / ROCm a process that has initialised the GPU must not FORK workers: while forked
+    children are alive the parent's GPU work runs ~100x slower (measured with tools/loader_probe.py: the same batch of copies + kernels
+    takes 2.0 s instead of 8 ms; every copy-on-write fault of the parent is an MMU-notifier round trip through the GPU driver) -- the
+    reference's default `DataLoader(num_workers=...)` (engine.py:48-53) forks.  So whenever a GPU is present the workers come from a
+    FORKSERVER (a clean helper process that has imported torch and the dataset module once, so a worker starts in milliseconds, not
+    the seconds a `spawn` re-import takes).  CPU-only runs keep the platform default."""
+    global _forkserver_ready
+    if workers <= 0 or not torch.cuda.is_available():
+        return None
+    import multiprocessing as mp
+    if not _forkserver_ready:
+        try:
+            mp.set_forkserver_preload(["torch", "numpy", "utils.datasets", "utils.transforms"])
+        except Exception:
+            pass
+        _forkserver_ready = True
+    return mp.get_context("forkserver")
+
+
 def dataloader(d, bs=256, shuffle=False, workers=-1, drop_last=False, sampler=None):
     if len(d) == 0:
         return []
@@ -18,8 +41,16 @@ def dataloader(d, bs=256, shuffle=False, workers=-1, drop_last=False, sampler=No
         workers = default_workers
     if getattr(d, "in_memory", False):      # tensor-backed datasets need no worker processes
         workers = 0
+    if getattr(d, "gpu_decode", False):
+        # `gpu_decode` datasets fetch a whole BATCH per call (one read loop into one buffer, no per-item tensors, no collate): the
+        # loader hands the dataset index lists.  Workers only read files; the host cores belong to the trainer's entropy-decode threads.
+        from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
+        workers = min(workers, 6)
+        base = sampler if sampler is not None else (RandomSampler(d) if shuffle else SequentialSampler(d))
+        return DataLoader(d, batch_size=None, sampler=BatchSampler(base, bs, drop_last), num_workers=workers, pin_memory=False,
+                          multiprocessing_context=_worker_context(workers), persistent_workers=False)
     return DataLoader(d, bs, shuffle, drop_last=drop_last, num_workers=workers, sampler=sampler,
-                      pin_memory=workers > 0, collate_fn=getattr(d, "collate_fn", None))
+                      pin_memory=workers > 0, collate_fn=getattr(d, "collate_fn", None), multiprocessing_context=_worker_context(workers))
 
 
 class _SequentialSubset(torch.utils.data.Sampler):

@@ -212,6 +212,53 @@ int ch_preprocess(const uint8_t *pixels, const ch_image_desc *desc_device, int32
 int32_t ch_preprocess_max_taps(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * JPEG decode split  (replaces the decode half of the loader workers: `Image.open(path).convert("RGB")` in the dataset classes
+ * that engine.dataloader drives, engine.py:41-54 -- PIL = libjpeg-turbo with its default settings: islow IDCT, fancy upsampling)
+ *
+ * Host threads do what is serial (marker parsing + Huffman entropy decode -> int16 coefficient blocks in pinned memory), the GPU does
+ * what is data-parallel (dequantise + 8x8 inverse DCT + chroma upsampling + YCbCr -> RGB), writing decoded RGB bytes in the layout
+ * ch_preprocess reads.  Integer arithmetic restated from libjpeg-turbo (jidctint.c, jdsample.c, jdcolor.c): the bytes are bit-equal
+ * to Pillow's.  Files outside the supported subset get status != 0 and are decoded by the caller's host decoder (PIL, the
+ * reference's own path); see csrc/jpeg.hip for the subset.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct ch_jpeg_desc {
+    int64_t coef_offset;  /* int16 elements from the batch coefficient buffer to this image's first block */
+    int64_t pix_offset;   /* bytes from `pixels` to this image's [height, width, 3] RGB output */
+    int64_t plane_offset; /* bytes from the plane workspace to this image's component planes */
+    int32_t width, height;
+    int32_t ncomp;        /* 1 (grey, replicated to RGB as PIL's convert("RGB") does) or 3 (YCbCr) */
+    int32_t hs, vs;       /* luma sampling factors: 1x1 (4:4:4), 2x1 (4:2:2), 2x2 (4:2:0); chroma is 1x1 */
+    int32_t mcu_w, mcu_h; /* MCUs per row / column */
+    int32_t status;       /* 0 = decoded by this path; 1 not a JPEG, 2 truncated, 3 progressive / lossless / arithmetic or spectral
+                             selection, 4 not 8 bit, 5 component count, 6 sampling factors, 7 multi-scan, 8 colour space, 9 tables,
+                             10 smaller than 16x16, 11 corrupt entropy data (set by ch_jpeg_entropy_decode) */
+    int32_t nblocks;      /* 8x8 blocks of all components = coefficient elements / 64 */
+    int32_t reserved;
+    uint16_t quant[3][64]; /* quantisation tables per component, natural (row-major) order */
+} ch_jpeg_desc;
+
+/* HOST: parse the headers of n files (files[i], lens[i]: host pointers / byte counts).  Fills desc[i] (sizes, sampling, tables,
+ * status) and default back-to-back offsets; totals: int16 coefficient elements, output bytes, plane-workspace bytes.  The caller may
+ * rewrite the three offsets (e.g. after sizing the slots of the files it decodes itself). */
+int ch_jpeg_plan(const uint8_t *const *files, const int64_t *lens, int32_t n, ch_jpeg_desc *desc, int64_t *total_coef, int64_t *total_pix,
+                 int64_t *total_plane);
+/* HOST: Huffman-decode the entropy-coded segments of the files with status 0 on `nthreads` threads into coef_host (host memory,
+ * ideally pinned; every block fully written, DC prediction undone, natural order).  A corrupt stream sets that descriptor's status. */
+int ch_jpeg_entropy_decode(const uint8_t *const *files, const int64_t *lens, int32_t n, ch_jpeg_desc *desc, int16_t *coef_host,
+                           int32_t nthreads);
+/* HOST: the same two calls for a batch whose files sit back to back in ONE buffer (what a `gpu_decode` loader worker hands over):
+ * file i = data[offsets[i], offsets[i + 1]), offsets has n + 1 entries. */
+int ch_jpeg_plan_packed(const uint8_t *data, const int64_t *offsets, int32_t n, ch_jpeg_desc *desc, int64_t *total_coef, int64_t *total_pix,
+                        int64_t *total_plane);
+int ch_jpeg_entropy_decode_packed(const uint8_t *data, const int64_t *offsets, int32_t n, ch_jpeg_desc *desc, int16_t *coef_host,
+                                  int32_t nthreads);
+/* GPU: coefficient blocks -> RGB bytes.  coef_dev: the coefficient buffer on the device; desc_dev / desc_host: the same n descriptors
+ * on the device and on the host (the host copy sizes the launch); planes_ws: device workspace of total_plane bytes; pixels: device
+ * output (total_pix bytes); images with status != 0 are skipped (their slots are the caller's to fill). */
+int ch_jpeg_reconstruct(const int16_t *coef_dev, const ch_jpeg_desc *desc_dev, const ch_jpeg_desc *desc_host, int32_t n,
+                        uint8_t *planes_ws, uint8_t *pixels, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Retrieve  (replaces the un-vendored utils.hashing.{calculate_mAP, calculate_pr_curve, get_hamm_dist}; call sites
  *            experiments/test_hashing.py:106-119,153-162, trainers/orthohash.py:362; definition: SURVEY.md 8c)
  * ------------------------------------------------------------------------------------------------------------- */

@@ -1,0 +1,219 @@
+"""JPEG decode split (reference: the loader workers' `PIL.Image.open(path).convert("RGB")`, engine.py:41-54).
+
+CPU: the HOST half of the product (`ch_jpeg_plan` / `ch_jpeg_entropy_decode`: marker parsing + Huffman decode, plain C++ -- it runs
+without a GPU) feeds oracle/jpeg_oracle.py (numpy restatement of libjpeg-turbo's islow IDCT, fancy upsampling and YCbCr -> RGB); the
+result must equal PIL's bytes -- this pins both the entropy decoder and the restatement against Pillow itself.
+GPU: `GpuJpegDecoder` (host entropy decode + `ch_jpeg_reconstruct`) equals PIL bit for bit on the same files, mixed batches with
+unsupported files (progressive -> PIL on the host, counted) included, and `dataset.gpu_decode: true` gives the codes of the
+reference-style CPU loader through `COOPTrainer.inference_one_epoch`."""
+import ctypes
+import io
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+
+def _image(h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.zeros((h, w, 3), np.float32)
+    for c in range(3):
+        for _ in range(5):
+            fx, fy = rng.uniform(0.005, 0.15, 2)
+            img[:, :, c] += rng.uniform(10, 60) * np.sin(fx * xx + fy * yy + rng.uniform(0, 6.28))
+    img += 128 + rng.normal(0, 10, img.shape)
+    img[h // 4:h // 2, w // 3:w // 2] = rng.uniform(0, 255, 3)      # a flat, possibly saturated patch with hard edges
+    img[:8, :8] = 255
+    img[-5:, -7:] = 0
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _jpeg(img, mode="RGB", **kw):
+    im = Image.fromarray(img)
+    if mode == "L":
+        im = im.convert("L")
+    bio = io.BytesIO()
+    im.save(bio, "JPEG", **kw)
+    return bio.getvalue()
+
+
+def _pil(data):
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+# (h, w), subsampling (0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0), quality, mode, extra save options
+CASES = [((375, 500), 2, 75, "RGB", {}), ((500, 375), 2, 90, "RGB", {}), ((333, 500), 1, 85, "RGB", {}), ((241, 255), 0, 95, "RGB", {}),
+         ((17, 16), 2, 75, "RGB", {}), ((16, 33), 1, 50, "RGB", {}), ((64, 64), 0, 30, "RGB", {}), ((480, 640), 2, 20, "RGB", {}),
+         ((375, 500), 2, 75, "L", {}), ((129, 67), 0, 90, "L", {}), ((375, 500), 2, 75, "RGB", dict(optimize=True)),
+         ((375, 500), 2, 75, "RGB", dict(restart_marker_blocks=5)), ((300, 401), 1, 85, "RGB", dict(restart_marker_rows=1)),
+         ((99, 1001), 2, 60, "RGB", {}), ((1001, 99), 2, 60, "RGB", {}), ((257, 259), 2, 100, "RGB", {})]
+
+
+def _files():
+    out = []
+    for i, ((h, w), sub, q, mode, kw) in enumerate(CASES):
+        kw = dict(kw, quality=q)
+        if mode == "RGB":
+            kw["subsampling"] = sub
+        out.append(_jpeg(_image(h, w, i), mode, **kw))
+    return out
+
+
+def _host_decode(files, threads=2):
+    from concepthash_amd import _lib
+    from concepthash_amd.jpeg import DESC_DTYPE, GpuJpegDecoder
+    lib = _lib.load()
+    n = len(files)
+    bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+    ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (ctypes.c_int64 * n)(*[len(f) for f in files])
+    desc = np.zeros(n, dtype=DESC_DTYPE)
+    tc, tp, tl = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    assert lib.ch_jpeg_plan(ptrs, lens, n, desc.ctypes.data, ctypes.byref(tc), ctypes.byref(tp), ctypes.byref(tl)) == 0
+    assert (tc.value, tp.value, tl.value) == GpuJpegDecoder.layout(desc.copy())     # the library's default layout == the wrapper's
+    coef = np.full(max(tc.value, 1), 12345, np.int16)                                 # poisoned: every block must be fully written
+    assert lib.ch_jpeg_entropy_decode(ptrs, lens, n, desc.ctypes.data, coef.ctypes.data, threads) == 0
+    return desc, coef
+
+
+def test_host_entropy_decoder_and_oracle_reconstruction_equal_pillow():
+    from oracle import jpeg_oracle as jo
+    files = _files()
+    desc, coef = _host_decode(files)
+    for i, f in enumerate(files):
+        d = desc[i]
+        assert d["status"] == 0, (CASES[i], int(d["status"]))
+        ref = _pil(f)
+        assert (d["height"], d["width"]) == ref.shape[:2]
+        got = jo.reconstruct(coef[d["coef_offset"]:d["coef_offset"] + int(d["nblocks"]) * 64], d)
+        assert np.array_equal(got, ref), (CASES[i], int((got != ref).sum()))
+    # one thread and many threads write the same coefficients
+    d1, c1 = _host_decode(files, threads=1)
+    d8, c8 = _host_decode(files, threads=8)
+    assert np.array_equal(c1, c8) and np.array_equal(d1, d8)
+
+
+def test_files_outside_the_subset_are_flagged_not_guessed():
+    img = _image(120, 160, 3)
+    prog = _jpeg(img, quality=80, progressive=True)
+    cmyk = io.BytesIO()
+    Image.fromarray(img).convert("CMYK").save(cmyk, "JPEG")
+    tiny = _jpeg(_image(12, 40, 1), quality=80)
+    png = io.BytesIO()
+    Image.fromarray(img).save(png, "PNG")
+    good = _jpeg(img, quality=80)
+    trunc = good[: len(good) // 2]
+    desc, _ = _host_decode([prog, cmyk.getvalue(), tiny, png.getvalue(), good, good[:100], trunc])
+    assert list(desc["status"][:5]) == [3, 5, 10, 1, 0]
+    assert desc["status"][5] != 0                                 # cut inside the headers
+    assert desc["status"][6] in (0, 11)                           # cut inside the entropy data: zero-filled tail or flagged corrupt
+    assert (desc["height"][0], desc["width"][0]) == (120, 160)    # the size of a file the caller decodes itself is still reported
+
+
+@pytest.mark.gpu
+def test_gpu_jpeg_decoder_equals_pillow_bit_for_bit():
+    from concepthash_amd.jpeg import GpuJpegDecoder, decode_to_list
+    dev = torch.device("cuda:0")
+    files = _files()
+    files.insert(3, _jpeg(_image(200, 300, 77), quality=85, progressive=True))     # outside the subset: PIL on the host, same bytes
+    dec = GpuJpegDecoder(device=dev, threads=4)
+    for rep in range(3):                                                             # the pinned ring is reused
+        outs = decode_to_list(dec, files)
+        torch.cuda.synchronize()
+        for f, o in zip(files, outs):
+            ref = _pil(f)
+            assert tuple(o.shape) == ref.shape
+            assert np.array_equal(o.cpu().numpy(), ref)
+    assert dec.stats["pil_fallback"] == 3 and dec.stats["gpu"] == 3 * (len(files) - 1)
+    assert dec.stats["fallback_reasons"] == {"progressive / lossless / arithmetic": 3}
+    with pytest.raises(ValueError, match="strict"):
+        GpuJpegDecoder(device=dev, strict=True).decode(files)
+    pixels, sizes = dec.decode([])
+    assert pixels.numel() == 0 and sizes == []
+    # a larger batch of one size (the loader's common case), several host threads
+    batch = [_jpeg(_image(375, 500, 100 + i), quality=90) for i in range(24)]
+    outs = decode_to_list(GpuJpegDecoder(device=dev), batch)
+    for f, o in zip(batch, outs):
+        assert np.array_equal(o.cpu().numpy(), _pil(f))
+
+
+@pytest.mark.gpu
+def test_trainer_with_gpu_decode_gives_the_codes_of_the_cpu_loader(tmp_path):
+    """`dataset.gpu_decode: true` end to end: list-file dataset of JPEG files of different sizes / samplings -> DataLoader workers only
+    READ -> RawJpegBatch -> COOPTrainer: host entropy decode + ch_jpeg_reconstruct + ch_preprocess + ch_encode.  Codes are bit-equal to
+    the run whose CPU workers decode with PIL and apply the torchvision-style transform chain (the reference's loader, engine.py:41-54,
+    configs/dataset/cub200.yaml:31-47)."""
+    from concepthash_amd import config as cfglib
+    from concepthash_amd import synthetic as syn
+    from trainers.coop import COOPTrainer
+    from utils import transforms as T
+    from utils.datasets import HashingDataset, OneHot
+    root = tmp_path / "d"
+    (root / "img").mkdir(parents=True)
+    lines = []
+    cases = [((375, 500), 2, 75), ((500, 375), 2, 90), ((333, 500), 1, 85), ((300, 300), 0, 95), ((64, 48), 2, 80), ((400, 731), 2, 70),
+             ((257, 300), 2, 90)]
+    for i, ((h, w), sub, q) in enumerate(cases):
+        (root / "img" / f"{i}.jpg").write_bytes(_jpeg(_image(h, w, i), quality=q, subsampling=sub, progressive=(i == 4)))
+        lines.append(f"img/{i}.jpg {i % 3}")
+    (root / "test.txt").write_text("\n".join(lines) + "\n")
+    cfg = dict(syn.CONFIGS["vit_s16"])
+    cfg["L"] = 2
+    sd = syn.synthetic_state_dict(cfg, nbit=32, nclass=3)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            from concepthash_amd.encoder import ConceptHashEncoder
+            self.enc = ConceptHashEncoder(sd, heads=cfg["heads"], max_batch=4, device=torch.device("cuda:0"))
+
+        def forward(self, x):
+            return None, self.enc.encode(x, want=("codes", "logits_cont", "logits_bin"))
+
+    class Crit(torch.nn.Module):
+        losses = {}
+
+        def forward(self, out, y):
+            return out["codes"].sum() * 0
+
+    chain = [T.Resize(256, T.interpolation("bicubic")), T.CenterCrop(224), T.ToTensor(), T.normalize_transform(3)]
+    codes = {}
+    for mode in (False, True):
+        conf = cfglib.DictConfig(device="cuda", batch_size=4, model=cfglib.DictConfig(),
+                                 dataset=cfglib.DictConfig(multiclass=False, resize=256, crop=224, norm=3, gpu_preprocess=mode, gpu_decode=mode))
+        tr = COOPTrainer(conf)
+        tr.dataset = {"train": [], "db": [], "test": HashingDataset(str(root), "test.txt", transform=chain, target_transform=OneHot(3),
+                                                                     gpu_decode=mode)}
+        tr.load_dataloader()
+        tr.model, tr.criterion = Model(), Crit()
+        meters, out = tr.inference_one_epoch("test", True)
+        codes[mode] = out["codes"]
+        assert out["codes"].shape == (7, 32) and out["labels"].shape == (7, 3)
+        if mode:
+            assert tr._gpu_jpeg.stats["pil_fallback"] == 1 and tr._gpu_jpeg.stats["gpu"] == 6
+    # the CPU loader hands fp32 tensors to the model, the GPU path bf16: compare through the same rounding
+    assert torch.equal(codes[True], codes[False])
+
+
+def test_packed_batch_calls_equal_the_per_file_calls():
+    """`ch_jpeg_plan_packed` / `ch_jpeg_entropy_decode_packed` (files back to back in one buffer, as a `gpu_decode` loader worker hands
+    them over) give the descriptors and coefficients of the per-file calls."""
+    from concepthash_amd import _lib
+    from concepthash_amd.jpeg import DESC_DTYPE
+    lib = _lib.load()
+    files = _files()[:6]
+    d1, c1 = _host_decode(files)
+    data = np.concatenate([np.frombuffer(f, dtype=np.uint8) for f in files])
+    off = np.zeros(len(files) + 1, np.int64)
+    off[1:] = np.cumsum([len(f) for f in files])
+    d2 = np.zeros(len(files), dtype=DESC_DTYPE)
+    tc, tp, tl = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    assert lib.ch_jpeg_plan_packed(data.ctypes.data, off.ctypes.data, len(files), d2.ctypes.data, ctypes.byref(tc), ctypes.byref(tp), ctypes.byref(tl)) == 0
+    c2 = np.full(tc.value, 777, np.int16)
+    assert lib.ch_jpeg_entropy_decode_packed(data.ctypes.data, off.ctypes.data, len(files), d2.ctypes.data, c2.ctypes.data, 3) == 0
+    assert np.array_equal(d1, d2) and np.array_equal(c1, c2)
+    bad = off.copy()
+    bad[2] = bad[1] - 1
+    assert lib.ch_jpeg_plan_packed(data.ctypes.data, bad.ctypes.data, len(files), d2.ctypes.data, None, None, None) != 0

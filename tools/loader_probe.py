@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Where the time of the `gpu_decode` loader path goes (bench.py `loader_inclusive`): per batch, the wait for the DataLoader, the host
+entropy decode + copies + reconstruct launch, the pre-process launch and the encode launch, with 0 / 2 / 4 worker processes.
+`python tools/loader_probe.py [nimg]` on a GPU box."""
+import io, os, sys, tempfile, time, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from PIL import Image
+from torch.utils.data import DataLoader
+from concepthash_amd import synthetic as syn
+from concepthash_amd.encoder import ConceptHashEncoder
+from concepthash_amd.jpeg import GpuJpegDecoder
+from concepthash_amd.preprocess import GpuPreprocess
+from utils.datasets import HashingDataset, OneHot
+
+
+def main():
+    nimg = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    dev = torch.device("cuda:0")
+    cfg = syn.CONFIGS["vit_b16"]
+    enc = ConceptHashEncoder(syn.synthetic_state_dict(cfg, nbit=64, nclass=200, seed=42), heads=cfg["heads"], max_batch=256, device=dev)
+    root = tempfile.mkdtemp(prefix="ch_probe_")
+    os.makedirs(root + "/img")
+    rng = np.random.default_rng(0)
+    for i in range(nimg):
+        low = rng.integers(0, 256, (12 + i % 13, 16 + i % 11, 3), dtype=np.uint8)
+        img = np.asarray(Image.fromarray(low).resize((500, 375), Image.BICUBIC), dtype=np.int16)
+        Image.fromarray(np.clip(img + rng.normal(0, 7, img.shape), 0, 255).astype(np.uint8)).save(f"{root}/img/{i}.jpg", "JPEG", quality=85)
+    open(root + "/test.txt", "w").write("".join(f"img/{i}.jpg {i % 200}\n" for i in range(nimg)))
+    pre = GpuPreprocess(256, 224, out_dtype=torch.bfloat16, device=dev)
+    dec = GpuJpegDecoder(device=dev)
+    ds = HashingDataset(root, "test.txt", target_transform=OneHot(200), gpu_decode=True)
+    import engine
+    for label in ("engine.dataloader (forkserver workers, batch reads)",):
+        for rep in range(3):
+            for k in ("plan_s", "ring_wait_s", "entropy_s", "enqueue_s"):
+                dec.stats[k] = 0.0
+            dl = engine.dataloader(ds, 256, shuffle=False, drop_last=False)
+            workers, pin, ctx = dl.num_workers, False, "forkserver"
+            tw = td = tp = te = 0.0
+            t_all = time.perf_counter()
+            from concepthash_amd.jpeg import prefetch_decoded
+            it = iter(prefetch_decoded(dl, dec) if "--no-prefetch" not in sys.argv else dl)
+            n = 0
+            while True:
+                t0 = time.perf_counter()
+                try:
+                    image, labels, index = next(it)
+                except StopIteration:
+                    break
+                t1 = time.perf_counter()
+                px, sizes = image.finish() if hasattr(image, "staged") else dec.decode(image.files)
+                t2 = time.perf_counter()
+                x = pre(px, sizes)
+                t3 = time.perf_counter()
+                enc.encode(x, want=("codes", "packed"))
+                t4 = time.perf_counter()
+                tw += t1 - t0; td += t2 - t1; tp += t3 - t2; te += t4 - t3
+                n += labels.shape[0]
+            torch.cuda.synchronize()
+            tot = time.perf_counter() - t_all
+            nb = -(-n // 256)
+            print(f"workers {workers} pin {pin} ctx {ctx} pass {rep}: {n / tot:8.0f} images/s | per batch ms: wait {tw / nb * 1e3:7.1f} decode {td / nb * 1e3:7.1f} "
+                  f"(plan {dec.stats['plan_s'] / nb * 1e3:.1f} ring-wait {dec.stats['ring_wait_s'] / nb * 1e3:.1f} entropy {dec.stats['entropy_s'] / nb * 1e3:.1f} "
+                  f"enqueue {dec.stats['enqueue_s'] / nb * 1e3:.1f}) preprocess {tp / nb * 1e3:6.1f} encode-launch {te / nb * 1e3:6.1f}", flush=True)
+            del it, dl
+    shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":      # spawn / forkserver workers re-import this module
+    main()

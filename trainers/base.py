@@ -78,6 +78,10 @@ class BaseTrainer:
     def inference_one_batch(self, *args, **kwargs):
         raise NotImplementedError
 
+    def iterate_loader(self, loader):
+        """Hook: how a split's loader is iterated (COOPTrainer wraps `gpu_decode` loaders with a host-stage prefetch thread)."""
+        return loader
+
     def inference_one_epoch(self, datakey="test", return_codes=False, **kwargs):
         assert self.is_ready_for_inference()
         self.model.eval()
@@ -87,7 +91,7 @@ class BaseTrainer:
         self.inference_datakey = datakey
         loader = self.dataloader[datakey]
         n = len(loader) if hasattr(loader, "__len__") else 0
-        for i, data in enumerate(loader):
+        for i, data in enumerate(self.iterate_loader(loader)):
             output = self.inference_one_batch(data, dmeters, bidx=i, **kwargs)
             if return_codes:
                 for key, val in output.items():

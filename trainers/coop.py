@@ -71,9 +71,32 @@ class COOPTrainer(BaseTrainer):
             self._gpu_pre = GpuPreprocess(int(ds.get("resize", 256)), int(ds.get("crop", 224)), mean, std, device=self.device)
         return self._gpu_pre(raw.pixels, raw.sizes)
 
+    def _jpeg_decoder(self):
+        if getattr(self, "_gpu_jpeg", None) is None:
+            from concepthash_amd.jpeg import GpuJpegDecoder
+            self._gpu_jpeg = GpuJpegDecoder(device=self.device, threads=self.config.dataset.get("decode_threads", None) or None)
+        return self._gpu_jpeg
+
+    def _gpu_decode(self, raw):
+        """`dataset.gpu_decode: true`: the batch's JPEG FILES -> decoded RGB bytes on the GPU (host threads entropy-decode, the GPU does
+        inverse DCT / upsampling / colour conversion; bit-equal to the PIL decode of the reference's workers, engine.py:41-54).  `raw` is
+        a RawJpegBatch (undecoded files) or, from `iterate_loader`, a StagedJpegBatch whose host half already ran on the prefetch thread."""
+        from utils.datasets import RawImageBatch
+        pixels, sizes = raw.finish() if hasattr(raw, "staged") else self._jpeg_decoder().decode(raw)
+        return RawImageBatch(pixels, sizes)
+
+    def iterate_loader(self, loader):
+        """A `gpu_decode` loader is iterated with the host half of the JPEG decode one or two batches ahead, on a background thread."""
+        if getattr(getattr(loader, "dataset", None), "gpu_decode", False):
+            from concepthash_amd.jpeg import prefetch_decoded
+            return prefetch_decoded(loader, self._jpeg_decoder())
+        return loader
+
     def compute_features_one_batch(self, data):
         image, labels, index = data
         image = image.to(self.device, non_blocking=True)
+        if hasattr(image, "files") or hasattr(image, "staged"):   # gpu_decode dataset: undecoded files / host-staged coefficients
+            image = self._gpu_decode(image)
         if hasattr(image, "pixels"):                      # RawImageBatch from a gpu_preprocess dataset
             image = self._gpu_preprocess(image)
         labels = labels.to(self.device, non_blocking=True)

@@ -59,18 +59,63 @@ def raw_collate(batch):
     return RawImageBatch(pixels, [tuple(im.shape[:2]) for im in imgs]), targets, torch.as_tensor(idxs)
 
 
+class RawJpegBatch:
+    """UNDECODED image files of one batch for the GPU decode path (`gpu_decode: true`): `data` = the files' bytes back to back in ONE
+    uint8 host tensor (one shared-memory segment per batch between worker and trainer, not one per image), `lengths` = bytes per file.
+    Stays on the host -- the entropy decode runs on host threads -- until the trainer hands `files` to
+    `concepthash_amd.jpeg.GpuJpegDecoder`, which returns the RawImageBatch the GPU pre-processing takes."""
+
+    def __init__(self, data: torch.Tensor, lengths):
+        self.data = data
+        self.lengths = [int(n) for n in lengths]
+
+    @property
+    def files(self):
+        out, o = [], 0
+        for n in self.lengths:
+            out.append(self.data[o:o + n])
+            o += n
+        return out
+
+    def size(self, dim=0):
+        if dim != 0:
+            raise IndexError("RawJpegBatch only has a batch dimension")
+        return len(self.lengths)
+
+    def to(self, device, non_blocking=False):
+        return self
+
+    def pin_memory(self):
+        return self
+
+
+def jpeg_collate(batch):
+    """collate_fn of a `gpu_decode` dataset: the items are file bytes; nothing is decoded or resized on the CPU."""
+    files, targets, idxs = zip(*batch)
+    targets = torch.stack([t if torch.is_tensor(t) else torch.as_tensor(t) for t in targets])
+    return RawJpegBatch(torch.cat(files), [f.numel() for f in files]), targets, torch.as_tensor(idxs)
+
+
 class HashingDataset(Dataset):
     """Returns (image, target, index), as the trainers unpack it (trainers/coop.py:62).
+
+    `gpu_decode=True` (dataset config key of the same name; implies GPU pre-processing): the worker only READS the file; the item is its
+    bytes, the loader collates with `jpeg_collate`, and the trainer decodes the batch with `concepthash_amd.jpeg.GpuJpegDecoder` (host
+    threads: Huffman entropy decode; GPU: inverse DCT, upsampling, colour conversion -- bytes bit-equal to PIL's) before the GPU
+    pre-processing.
 
     `gpu_preprocess=True` (dataset config key of the same name): `transform` is NOT applied on the CPU worker; the item is the
     decoded uint8 [H, W, 3] image and the loader collates batches with `raw_collate`; the trainer then runs Resize -> CenterCrop ->
     ToTensor -> normalize on the GPU (`concepthash_amd.preprocess.GpuPreprocess`, bit-equal to the CPU chain)."""
 
     def __init__(self, root, filename="train.txt", transform=None, target_transform=None, num_classes=None, num_shots=0,
-                 separate_multiclass=False, gpu_preprocess=False, **kwargs):
+                 separate_multiclass=False, gpu_preprocess=False, gpu_decode=False, **kwargs):
         from utils.transforms import Compose
-        self.gpu_preprocess = bool(gpu_preprocess)
-        if self.gpu_preprocess:
+        self.gpu_decode = bool(gpu_decode)
+        self.gpu_preprocess = bool(gpu_preprocess) or self.gpu_decode
+        if self.gpu_decode:
+            self.collate_fn = jpeg_collate
+        elif self.gpu_preprocess:
             self.collate_fn = raw_collate
         self.root = root
         self.items = read_list(os.path.join(root, filename))
@@ -83,6 +128,7 @@ class HashingDataset(Dataset):
             self.items = keep
         self.transform = Compose(transform) if isinstance(transform, (list, tuple)) else transform
         self.target_transform = target_transform
+        self._paths = {}          # index -> resolved path (a worker resolves each file once)
 
     def __len__(self):
         return len(self.items)
@@ -93,16 +139,43 @@ class HashingDataset(Dataset):
                 return cand
         raise FileNotFoundError(f"image '{rel}' not found (list root {self.root}); use dataset=synthetic_* without images")
 
+    def _read_batch(self, indices):
+        """`gpu_decode`: the files of a whole batch read back to back into ONE uint8 buffer (no decode, no per-item tensors, no collate)."""
+        paths = []
+        for i in indices:
+            p = self._paths.get(i)
+            if p is None:
+                p = self._paths[i] = self._resolve(self.items[i][0])
+            paths.append(p)
+        lengths = [os.path.getsize(p) for p in paths]
+        data = torch.empty(sum(lengths), dtype=torch.uint8)
+        view = memoryview(data.numpy())
+        o = 0
+        for p, n in zip(paths, lengths):
+            with open(p, "rb", buffering=0) as f:
+                got = f.readinto(view[o:o + n])
+            if got != n:
+                raise IOError(f"short read of {p}: {got} of {n} bytes")
+            o += n
+        targets = [self.target_transform(self.items[i][1]) if self.target_transform is not None else self.items[i][1] for i in indices]
+        targets = torch.stack([t if torch.is_tensor(t) else torch.as_tensor(t) for t in targets])
+        return RawJpegBatch(data, lengths), targets, torch.as_tensor(list(indices))
+
     def __getitem__(self, index):
         from PIL import Image
+        if self.gpu_decode and isinstance(index, (list, tuple)):       # engine.dataloader hands a gpu_decode dataset index LISTS
+            return self._read_batch(index)
         rel, lab = self.items[index]
+        target = self.target_transform(lab) if self.target_transform is not None else lab
+        if self.gpu_decode:
+            import numpy as np
+            return torch.from_numpy(np.fromfile(self._resolve(rel), dtype=np.uint8)), target, index      # read only: no decode on the CPU
         img = Image.open(self._resolve(rel)).convert("RGB")
         if self.gpu_preprocess:
             import numpy as np
             img = torch.from_numpy(np.array(img, dtype=np.uint8))          # decode only; resize / crop / normalise on the GPU
         elif self.transform is not None:
             img = self.transform(img)
-        target = self.target_transform(lab) if self.target_transform is not None else lab
         return img, target, index
 
 
