@@ -297,31 +297,57 @@ class StagedJpegBatch:
 
 
 def prefetch_decoded(loader, decoder: GpuJpegDecoder, depth: int = 2):
-    """Iterate a `gpu_decode` loader with the HOST half of the decode (file batch -> pinned coefficient blocks) running on a background
-    thread up to `depth` batches ahead: yields (StagedJpegBatch, targets, indices).  The Huffman decode releases the GIL, so the
-    trainer's thread enqueues copies and kernels for batch i while the host threads decode batch i + 1 -- the step time becomes
-    max(host, GPU) instead of their sum.  depth <= GpuJpegDecoder._RING - 2."""
+    """Iterate a `gpu_decode` loader as a three-stage pipeline: a FETCH thread takes batches from the loader's workers (unpickling, mapping
+    the shared-memory segment), a HOST-STAGE thread turns them into pinned coefficient blocks (header parse + Huffman decode: GIL-free C
+    with its own thread pool), up to `depth` batches ahead, and the caller's thread enqueues copies and kernels: yields
+    (StagedJpegBatch, targets, indices).  The step time becomes max(fetch, host decode, GPU) instead of their sum.
+    depth <= GpuJpegDecoder._RING - 2."""
     import queue
     import threading
     depth = max(1, min(int(depth), decoder._RING - 2))
-    q = queue.Queue(maxsize=depth)
+    q_raw, q_staged = queue.Queue(maxsize=2), queue.Queue(maxsize=depth)
     stop = threading.Event()
 
-    def produce():
-        try:
-            for raw, targets, index in loader:
-                if stop.is_set():
-                    return
-                q.put((decoder.host_stage(raw), targets, index))
-            q.put(None)
-        except BaseException as e:      # re-raised in the consumer
-            q.put(e)
+    def put(q, item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
 
-    th = threading.Thread(target=produce, name="jpeg-host-stage", daemon=True)
-    th.start()
+    def fetch():
+        try:
+            for item in loader:
+                if not put(q_raw, item):
+                    return
+            put(q_raw, None)
+        except BaseException as e:      # re-raised in the consumer
+            put(q_raw, e)
+
+    def stage():
+        try:
+            while not stop.is_set():
+                try:
+                    item = q_raw.get(timeout=0.1)
+                except queue.Empty:
+                    continue
+                if item is None or isinstance(item, BaseException):
+                    put(q_staged, item)
+                    return
+                raw, targets, index = item
+                if not put(q_staged, (decoder.host_stage(raw), targets, index)):
+                    return
+        except BaseException as e:
+            put(q_staged, e)
+
+    threads = [threading.Thread(target=fetch, name="jpeg-fetch", daemon=True), threading.Thread(target=stage, name="jpeg-host-stage", daemon=True)]
+    for th in threads:
+        th.start()
     try:
         while True:
-            item = q.get()
+            item = q_staged.get()
             if item is None:
                 break
             if isinstance(item, BaseException):
@@ -329,11 +355,10 @@ def prefetch_decoded(loader, decoder: GpuJpegDecoder, depth: int = 2):
             yield item
     finally:
         stop.set()
-        while th.is_alive():            # unblock a producer waiting on a full queue
-            try:
-                q.get_nowait()
-            except queue.Empty:
-                th.join(timeout=0.05)
+        for th in threads:
+            th.join(timeout=5.0)
+        for slot in decoder._ring:      # staged batches that were never device-staged (early exit): their slots are free again
+            slot["busy"] = False
 
 
 def decode_to_list(decoder: GpuJpegDecoder, files: Sequence) -> List[torch.Tensor]:

@@ -33,12 +33,14 @@ def main():
     dec = GpuJpegDecoder(device=dev)
     ds = HashingDataset(root, "test.txt", target_transform=OneHot(200), gpu_decode=True)
     import engine
-    for label in ("engine.dataloader (forkserver workers, batch reads)",):
-        for rep in range(3):
+    combos = [(16, 6), (8, 6), (12, 2), (16, 2), (8, 2), (24, 3)] if "--matrix" in sys.argv else [(16, 6)]
+    for threads, nworkers in combos:
+        dec.threads = threads
+        for rep in range(2):
             for k in ("plan_s", "ring_wait_s", "entropy_s", "enqueue_s"):
                 dec.stats[k] = 0.0
-            dl = engine.dataloader(ds, 256, shuffle=False, drop_last=False)
-            workers, pin, ctx = dl.num_workers, False, "forkserver"
+            dl = engine.dataloader(ds, 256, shuffle=False, drop_last=False, workers=nworkers)
+            workers, pin, ctx = dl.num_workers, False, f"forkserver threads {threads}"
             tw = td = tp = te = 0.0
             t_all = time.perf_counter()
             from concepthash_amd.jpeg import prefetch_decoded
