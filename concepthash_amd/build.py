@@ -15,7 +15,7 @@ SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "attention.hip", "rowops
 # kernels that lost to the dispatched ones (DESIGN.md sections 3.8-3.9): kept in csrc/experiments/ with their parity tests, compiled
 # only into an experiments build (CH_BUILD_EXPERIMENTS=1), never into the product library
 EXPERIMENT_SOURCES = [os.path.join("experiments", f) for f in ("gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "gemm_r4.hip",
-                                                                "adapter_fused.hip", "gemm_rows.hip")]
+                                                                "adapter_fused.hip", "gemm_rows.hip", "gemm_wide.hip")]
 HEADERS = ["ch_common.h", "kernels.h", "gemm_epilogue.h", "model_internal.h", os.path.join("..", "..", "include", "concepthash_hip.h"),
            os.path.join("..", "..", "include", "concepthash_hip_debug.h")]
 # attention post-processes every MFMA result on the VALU: keep accumulators in VGPRs (no v_accvgpr_read round trips)

@@ -210,7 +210,7 @@ int ch_gemm_group_n(int M, int N, int K, int bm, int bn, int forced) {
 }
 
 // ---- dispatcher: the 256x256 ping-pong kernel when the shape allows it, this file's 128x128 kernel otherwise ---------
-static std::atomic<int64_t> g_dispatch_count[4];   // 128x128 | 256x256 | non-temporal residual instance | non-temporal output instance
+static std::atomic<int64_t> g_dispatch_count[5];   // 128x128 | 256x256 | non-temporal residual instance | non-temporal output instance | 256x384
 void ch_gemm_count_nt_launch(int kind) { g_dispatch_count[2 + (kind != 0)].fetch_add(1, std::memory_order_relaxed); }
 static int g_gemm_variant = 0;  // 0 auto, 1 force v1 (128x128 two-phase), 2 force pp (256x256 ping-pong), 3 force dp
 void ch_gemm_set_variant(int v) { g_gemm_variant = v; }
@@ -256,6 +256,7 @@ int ch_gemm_bf16(const GemmParams &p0, int epi, hipStream_t s) {
         return ch_gemm_bf16_pp(q, epi, s);
     }
     if (g_gemm_variant == 3) return ch_gemm_bf16_dp(p, epi, s);
+    if (g_gemm_variant == 10) return ch_gemm_bf16_wide(p, epi, s);
     // Short-K GEMMs (the adapter up-projection, K = 384) are epilogue/HBM bound: two 128x128 workgroups per CU overlap one's
     // read-modify-write epilogue with the other's K loop and win there (measured: 152 -> 97 us per launch in the pipeline);
     // the 256x256 ping-pong kernel wins from K = 512 up.
@@ -265,8 +266,13 @@ int ch_gemm_bf16(const GemmParams &p0, int epi, hipStream_t s) {
     // N = 768 (153 tiles) the two tie.  Not applied when CH_GEMM_PP_MIN_K pins the choice (parity tests on small fixtures).
     const int64_t tiles_pp = ceil_div64(p.M, 256) * (p.N / 256);
     const bool pp = ch_gemm_pp_supported(p) && p.K >= min_k && (p.pp_min_k > 0 || tiles_pp >= 128);
-    g_dispatch_count[pp ? 1 : 0].fetch_add(1, std::memory_order_relaxed);
+    // N = 384 (the adapter bottleneck of ViT-B/16) does not fit the 256x256 kernel; as 128x128 tiles it is LDS-port bound (64x64 wave
+    // tiles).  experiments/gemm_wide.hip (256x384 tiles, 64x192 wave tiles, X read once, one round of the chip) is 9-14 % faster as an
+    // isolated launch and neutral end to end (profiles/r04_gemm_wide_ab.txt): opt-in, model option "wide_kernel" = 1, experiments build.
+    const bool wide = !pp && p.wide_opt > 0 && ch_gemm_wide_supported(p, epi);
+    g_dispatch_count[pp ? 1 : wide ? 4 : 0].fetch_add(1, std::memory_order_relaxed);
     if (pp) return ch_gemm_bf16_pp(p, epi, s);
+    if (wide) return ch_gemm_bf16_wide(p, epi, s);
     // N = 384 (the adapter bottleneck) as whole-row workgroups (experiments/gemm_rows.hip): one round of the chip instead of 2.36
     // rounds of 128x128 tiles, bit-identical -- and no faster (61 vs 59 us).  Opt-in: model option "gemm_rows", experiments build.
     if (p.rows_opt && p.small_kernel == 0 && p.M >= 128 * 128 && ch_gemm_rows_supported(p, epi)) return ch_gemm_bf16_rows(p, epi, s);
@@ -274,7 +280,8 @@ int ch_gemm_bf16(const GemmParams &p0, int epi, hipStream_t s) {
     return ring ? ch_gemm_bf16_r4(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
 }
 // test tap: how many GEMMs the dispatcher has sent to the 128x128 (which = 0) / 256x256 ping-pong (which = 1) kernel, and how many
-// launches ran the instance with the non-temporal residual read-modify-write (2) / the non-temporal bf16 output store (3)
+// launches ran the instance with the non-temporal residual read-modify-write (2) / the non-temporal bf16 output store (3); 4 = GEMMs sent
+// to the 256x384 kernel
 extern "C" int64_t ch_debug_gemm_dispatch_count(int32_t which) {
-    return g_dispatch_count[which < 0 || which > 3 ? 0 : which].load(std::memory_order_relaxed);
+    return g_dispatch_count[which < 0 || which > 4 ? 0 : which].load(std::memory_order_relaxed);
 }

@@ -73,6 +73,7 @@ struct GemmParams {
     int group_n_opt;         // > 0: n-tiles per weight group instead of the ch_gemm_group_n heuristic
     int splitk_opt;          // 1 = split-K tail of the 256x256 kernel (needs splitk_ws / splitk_cnt)
     int rows_opt;            // 1 = whole-row kernel for N = 384 where supported (experiments build)
+    int wide_opt;            // 256x384 kernel for N % 384 == 0 (experiments build): 0 = off (default: measured neutral end to end), 1 = wherever supported
 };
 constexpr size_t CH_SPLITK_WS_BYTES = (size_t)256 * 256 * 256 * 4;  // 64 MiB: at most 256 tail units of one 256x256 fp32 slab
 constexpr size_t CH_SPLITK_CNT_BYTES = 256 * sizeof(unsigned);
@@ -95,6 +96,9 @@ int ch_gemm_bf16_r4(const GemmParams &p, int epi, hipStream_t s);   // gemm_r4.h
 bool ch_gemm_r4_supported(const GemmParams &p);
 int ch_gemm_bf16_rows(const GemmParams &p, int epi, hipStream_t s); // gemm_rows.hip: 128 whole rows x N = 384 per workgroup (adapter down-projection)
 bool ch_gemm_rows_supported(const GemmParams &p, int epi);
+int ch_gemm_bf16_wide(const GemmParams &p, int epi, hipStream_t s); // gemm_wide.hip: 256x384x32, three-stage ring, two-phase ping-pong (N = 384: adapter bottleneck)
+bool ch_gemm_wide_supported(const GemmParams &p, int epi);
+int ch_gemm_bf16_wide_dbg(const GemmParams &p, int dbg, hipStream_t s);  // timing-only builds (garbage results)
 #else
 static inline int ch_experiments_not_built() {
     ch_set_error("experiment kernels are not part of this build (rebuild with CH_BUILD_EXPERIMENTS=1)");
@@ -107,6 +111,9 @@ static inline int ch_gemm_bf16_r4(const GemmParams &, int, hipStream_t) { return
 static inline bool ch_gemm_r4_supported(const GemmParams &) { return false; }
 static inline int ch_gemm_bf16_rows(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
 static inline bool ch_gemm_rows_supported(const GemmParams &, int) { return false; }
+static inline int ch_gemm_bf16_wide(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
+static inline bool ch_gemm_wide_supported(const GemmParams &, int) { return false; }
+static inline int ch_gemm_bf16_wide_dbg(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
 #endif
 int ch_gemm_bf16_pp_dbg(const GemmParams &p, int dbg, hipStream_t s);  // timing-only builds (garbage results)
 void ch_gemm_count_nt_launch(int kind);  // test tap counters: 0 = non-temporal residual instance, 1 = non-temporal output instance

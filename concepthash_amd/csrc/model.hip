@@ -430,7 +430,7 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
         GemmParams p{};
         p.tag = cat == CH_CAT_GEMM_FC2 ? 1 : 0;   // fc2 runs out_proj's kernel instance: second symbol name for per-kernel profiles
         p.splitk_ws = mm->splitk_ws[pi]; p.splitk_cnt = mm->splitk_cnt[pi]; p.pp_min_k = mm->pp_min_k; p.pp_sched = mm->pp_sched; p.small_kernel = mm->small_kernel; p.rev = next_dir();
-        p.nt_resid_opt = mm->resid_nt; p.nt_out_opt = mm->nt_out; p.group_n_opt = mm->group_n; p.splitk_opt = mm->splitk; p.rows_opt = mm->gemm_rows;
+        p.nt_resid_opt = mm->resid_nt; p.nt_out_opt = mm->nt_out; p.group_n_opt = mm->group_n; p.splitk_opt = mm->splitk; p.rows_opt = mm->gemm_rows; p.wide_opt = mm->wide_kernel;
         p.footprint_rows = (int64_t)cur_rows * Btot / B;   // all concurrent chains of this call: what the cache-policy choice is sized on
         p.stats_in = f.stats_in; p.fold_c = f.fold_c; p.ln_eps = f.eps; p.stats_out = f.stats_out; p.hb_out = f.hb_out; p.ld_hb = D;
         p.addend = addend; p.ld_addend = D;
@@ -648,6 +648,7 @@ const OptionRef g_options[] = {
     {"group_n", 0, CH_OPT_FIELD(group_n), 0, 64},
     {"splitk", 0, CH_OPT_FIELD(splitk), 0, 1},
     {"gemm_rows", 0, CH_OPT_FIELD(gemm_rows), 0, 1},
+    {"wide_kernel", 0, CH_OPT_FIELD(wide_kernel), 0, 1},
     {"train_chains", 0, CH_OPT_FIELD(train_chains), 1, 2},
     {"train_chain_min_rows", 2, CH_OPT_FIELD(train_chain_min_rows), 1, (int64_t)1 << 40},
     {"train_prune_last", 1, CH_OPT_FIELD(train_prune_last), 0, 1},
@@ -675,7 +676,7 @@ extern "C" int ch_model_set_option(ch_model *m, const char *key, int64_t value) 
     }
 #ifndef CH_EXPERIMENTS
     const std::string k = key;
-    if (value != 0 && (k == "fused_adapter" || k == "pp_sched" || k == "gemm_rows" || (k == "small_kernel" && value == 2))) {
+    if (value != 0 && (k == "fused_adapter" || k == "pp_sched" || k == "gemm_rows" || k == "wide_kernel" || (k == "small_kernel" && value == 2))) {
         ch_set_error("set_option: '" + k + "' selects an experiment kernel that is not part of this build (CH_BUILD_EXPERIMENTS=1)");
         return 2;
     }
@@ -883,11 +884,13 @@ extern "C" int ch_debug_gemm(int32_t variant, const void *X, int64_t X_rows_allo
         return ch_gemm_bf16_pp(p, epi, s);
     }
     if (variant == 3) return ch_gemm_bf16_dp(p, epi, s);
+    if (variant == 10) return ch_gemm_bf16_wide(p, epi, s);
     if (variant == 9) return ch_gemm_bf16_rows(p, epi, s);
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
     if (variant == 7) return ch_gemm_bf16_r4(p, epi, s);
     if (variant >= 21 && variant <= 29) return ch_gemm_bf16_pp_dbg(p, variant - 20, s);  // timing-only / stamped builds
+    if (variant >= 41 && variant <= 47) return ch_gemm_bf16_wide_dbg(p, variant - 40, s);  // timing-only builds of the 256x384 kernel
     return ch_gemm_bf16(p, epi, s);
 }
 extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_alloc, const void *W, const float *bias,
@@ -906,9 +909,9 @@ extern "C" int ch_debug_gemm_ln(int32_t variant, const void *X, int64_t X_rows_a
     if (variant == 5) return ch_gemm_bf16_ppp(p, epi, s);
     if (variant == 6) return ch_gemm_bf16_pq(p, epi, s);
     if (variant == 7) return ch_gemm_bf16_r4(p, epi, s);
-    if (variant == 1 || variant == 2 || variant == 4 || variant == 8 || variant == 9) ch_gemm_set_variant(variant);
+    if (variant == 1 || variant == 2 || variant == 4 || variant == 8 || variant == 9 || variant == 10) ch_gemm_set_variant(variant);
     const int rc = ch_gemm_bf16(p, epi, s);
-    if (variant == 1 || variant == 2 || variant == 4 || variant == 8 || variant == 9) ch_gemm_set_variant(0);
+    if (variant == 1 || variant == 2 || variant == 4 || variant == 8 || variant == 9 || variant == 10) ch_gemm_set_variant(0);
     return rc;
 }
 extern "C" void ch_debug_set_gemm_variant(int32_t v) { ch_gemm_set_variant(v); }

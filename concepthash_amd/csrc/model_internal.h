@@ -83,6 +83,7 @@ struct ch_model {
     int group_n = 0;                // n-tiles per L2-resident weight group of the GEMM tile order (0 = host heuristic)
     int splitk = 0;                 // split-K tail of the 256x256 GEMM (opt-in, measured slower: DESIGN.md section 3.8)
     int gemm_rows = 0;              // whole-row kernel for N = 384 (experiments build)
+    int wide_kernel = 0;            // 256x384 GEMM for N % 384 == 0 (adapter bottleneck; experiments build): 1 = wherever supported
     // read by ch_trainer_create from the model it is created on
     int train_chains = 1;
     int64_t train_chain_min_rows = 12000;

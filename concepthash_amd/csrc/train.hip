@@ -144,7 +144,7 @@ int gemm(ch_trainer *t, int chain, int rows, const GemmCall &g, hipStream_t s, i
     p.bias = g.bias; p.out_bf16 = g.out; p.ldo = g.ldo; p.resid = g.resid; p.ldr = D; p.scale_ptr = g.scale; p.addend = g.addend;
     p.ld_addend = D; p.stats_in = g.stats_in; p.fold_c = g.fold_c; p.ln_eps = g.eps; p.stats_out = g.stats_out; p.hb_out = g.hb_out;
     p.ld_hb = g.ld_hb ? g.ld_hb : D; p.aux = g.aux; p.pp_min_k = t->m->pp_min_k;
-    p.nt_resid_opt = t->m->resid_nt; p.nt_out_opt = t->m->nt_out; p.group_n_opt = t->m->group_n;
+    p.nt_resid_opt = t->m->resid_nt; p.nt_out_opt = t->m->nt_out; p.group_n_opt = t->m->group_n; p.wide_opt = t->m->wide_kernel;
     return ch_gemm_bf16(p, g.epi, s);
 }
 

@@ -291,6 +291,43 @@ def test_whole_row_kernel_is_bit_identical_and_race_free(M, K):
             assert torch.isnan(out[M:].float()).all()          # rows past M are never written
 
 
+@pytest.mark.parametrize("M,N,K", [(51456, 384, 768), (25728, 384, 768), (1000, 384, 768), (130, 384, 1024), (515, 768, 384), (77, 384, 64),
+                                   (300, 384, 192), (2049, 1152, 320)])
+def test_wide_kernel_is_bit_identical_and_race_free(M, N, K):
+    """gemm_wide_kernel (experiments/gemm_wide.hip, variant 10 of the taps, experiments build; 9-14 % faster than the 128x128 kernel as
+    an isolated launch at 51k rows, neutral end to end, not dispatched -- profiles/r04_gemm_wide_ab.txt): 256 x 384 x
+    32 tiles, 64 x 192 wave tiles, three-stage LDS-DMA ring behind counted `vmcnt(5)`, two-phase ping-pong with waves 4-7 one barrier
+    behind.  Same MFMA and the same ascending-k order per output element as the 128x128 kernel: bit-identical to it for every epilogue
+    the taps reach -- bias, exact GELU, LayerNorm-folded + GELU -- so any difference is a staging race; repeated with caches warm and
+    evicted, ragged row counts, K = 64 (two K-tiles: prologue only), K = 192 / 320 (the ring wraps), N = 768 / 1,152 (two / three
+    column tiles)."""
+    _need_experiments()
+    X, W, bias, _ = _inputs(M, N, K, seed=13)
+    junk = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    Mp = X.shape[0]
+    stats = torch.zeros(Mp, max(1, K // 64), 2, device="cuda")
+    if K % 64 == 0:
+        stats[:M] = _slice_stats(X, M).float()
+    fold_c = torch.randn(N, device="cuda")
+    epis = [EPI_BIAS, EPI_GELU] + ([10] if K % 128 == 0 and K <= 1280 else [])
+    for epi in epis:
+        outs = []
+        for variant, it in ((1, 0), (10, 0), (10, 1), (10, 2), (10, 3)):
+            out = torch.full((Mp, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+            if it % 2:
+                junk.fill_(float(it))
+            if epi >= 8:
+                _gemm_ln(variant, X, W, bias, M, epi, out=out, stats_in=stats, fold_c=fold_c, eps=1e-5)
+            else:
+                _gemm(variant, X, W, bias, M, epi, out=out)
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert not torch.isnan(outs[1][:M].float()).any()
+        for out in outs[1:]:
+            assert torch.equal(out[:M].view(torch.int16), outs[0][:M].view(torch.int16)), (epi, M, N, K)
+            assert torch.isnan(out[M:].float()).all()          # rows past M are never written
+
+
 @pytest.mark.parametrize("variant", [1, 2, 4, 7])
 @pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (700, 3072, 768), (515, 384, 768), (300, 256, 128), (257, 512, 1280)])
 def test_layernorm_folded_consumers(variant, M, N, K):
