@@ -549,6 +549,14 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
     return 0;
 }
 
+void drop_graphs(ch_model *m) {
+    for (auto &kv : m->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    m->graphs.clear();
+}
+
 int validate(const ch_model_config *c) {
     CH_REQUIRE(c != nullptr, "null config");
     CH_REQUIRE(c->dim > 0 && c->dim % 128 == 0 && c->dim <= 1280, "dim must be a multiple of 128 and <= 1280");
@@ -608,6 +616,8 @@ extern "C" int ch_model_create(const ch_model_config *cfg, const ch_tensor *tens
 
 extern "C" void ch_model_destroy(ch_model *m) {
     if (!m) return;
+    drop_graphs(m);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     for (auto &P : m->prof) {
         for (hipEvent_t e : P.ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : P.kstart) (void)hipEventDestroy(e);
@@ -618,7 +628,8 @@ extern "C" void ch_model_destroy(ch_model *m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     for (hipEvent_t e : m->ev_join)
         if (e) (void)hipEventDestroy(e);
-    for (void *p : m->allocs) (void)hipFree(p);
+    for (void *p : m->allocs)
+        if (p) (void)hipFree(p);
     delete m;
 }
 
@@ -649,6 +660,7 @@ const OptionRef g_options[] = {
     {"splitk", 0, CH_OPT_FIELD(splitk), 0, 1},
     {"gemm_rows", 0, CH_OPT_FIELD(gemm_rows), 0, 1},
     {"wide_kernel", 0, CH_OPT_FIELD(wide_kernel), 0, 1},
+    {"graph_max_batch", 0, CH_OPT_FIELD(graph_max_batch), 0, 1 << 16},
     {"train_chains", 0, CH_OPT_FIELD(train_chains), 1, 2},
     {"train_chain_min_rows", 2, CH_OPT_FIELD(train_chain_min_rows), 1, (int64_t)1 << 40},
     {"train_prune_last", 1, CH_OPT_FIELD(train_prune_last), 0, 1},
@@ -696,11 +708,15 @@ extern "C" int ch_model_set_option(ch_model *m, const char *key, int64_t value) 
     if (o->kind == 0) *(int *)f = (int)value;
     else if (o->kind == 1) *(bool *)f = value != 0;
     else *(int64_t *)f = value;
+    if (std::string(key) == "graph_max_batch") m->graph_max_batch = std::min(m->graph_max_batch, m->cfg.max_batch);
+    drop_graphs(m);   // a captured chain has the old setting baked in
     return 0;
 }
 
 extern "C" int ch_model_get_option(ch_model *m, const char *key, int64_t *value) {
     CH_REQUIRE(m != nullptr && value != nullptr, "get_option: null model / value");
+    if (key && std::string(key) == "graph_replays") { *value = m->graph_replays; return 0; }      // read-only counters (tests, bench)
+    if (key && std::string(key) == "graph_captures") { *value = m->graph_captures; return 0; }
     const OptionRef *o = find_option(key);
     if (!o) {
         ch_set_error(std::string("invalid argument: get_option: unknown key '") + (key ? key : "(null)") + "'");
@@ -726,17 +742,13 @@ extern "C" double ch_model_flops_per_image(const ch_model *m) {
     return total;
 }
 
-extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, float *out_codes,
-                         uint64_t *out_packed, float *out_logits_cont, float *out_logits_bin, float *out_logits_concept,
-                         float *out_hash_features, float *out_image_features, float *out_concept_attn,
-                         int32_t concept_attn_all_layers, void *stream) {
-    CH_REQUIRE(m != nullptr && images != nullptr && out_codes != nullptr, "null model / images / out_codes");
-    CH_REQUIRE(image_dtype == 0 || image_dtype == 1, "image_dtype must be 0 (fp32) or 1 (bf16)");
-    CH_REQUIRE(B >= 1 && B <= m->cfg.max_batch, "batch outside [1, max_batch]");
-    CH_REQUIRE(!out_logits_concept || m->concept_cent_l2, "model has no concept classifier (concept_ce.centroids)");
-    CH_REQUIRE(!out_image_features || m->vis_proj, "model has no post_layernorm / visual_projection");
-    hipStream_t s = (hipStream_t)stream;
-    if (int e = run_encoder(m, images, image_dtype, B, m->cfg.layers, s, out_concept_attn, concept_attn_all_layers != 0, true)) return e;
+namespace {
+
+// the launch chain of one ch_encode call on stream s (kernels + the fork / join events of the micro-batch chains: capturable)
+int encode_impl(ch_model *m, const void *images, int image_dtype, int B, float *out_codes, uint64_t *out_packed, float *out_logits_cont,
+                float *out_logits_bin, float *out_logits_concept, float *out_hash_features, float *out_image_features,
+                float *out_concept_attn, bool all_layers, hipStream_t s) {
+    if (int e = run_encoder(m, images, image_dtype, B, m->cfg.layers, s, out_concept_attn, all_layers, true)) return e;
     const ch_model_config &c = m->cfg;
     const bool pruned = m->prune_last && m->ln_fold && c.adapter_dim > 0 && !m->use_fused_adapter;  // as run_chain decides
     HeadParams p{};
@@ -753,6 +765,95 @@ extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, i
     if (int e = ch_head(p, s)) return e;
     mark(m, 0, CH_CAT_END, 0.0, s);
     return 0;
+}
+
+int ensure_bytes(ch_model *m, void **buf, size_t *have, size_t need) {
+    if (*have >= need) return 0;
+    drop_graphs(m);                      // cached graphs hold the old pointer
+    if (*buf) {
+        CH_CHECK_HIP(hipDeviceSynchronize());
+        for (void *&p : m->allocs)
+            if (p == *buf) p = nullptr;
+        CH_CHECK_HIP(hipFree(*buf));
+        m->bytes -= *have;
+    }
+    CH_CHECK_HIP(hipMalloc(buf, need));
+    m->allocs.push_back(*buf);
+    m->bytes += need;
+    *have = need;
+    return 0;
+}
+
+// B <= graph_max_batch: images -> staging, one graph replay, requested outputs <- staging
+int encode_graph(ch_model *m, const void *images, int image_dtype, int B, void *const outs[8], bool all_layers, hipStream_t s) {
+    const ch_model_config &c = m->cfg;
+    const size_t img_bytes = (size_t)B * 3 * c.image_size * c.image_size * (image_dtype == 0 ? 4 : 2);
+    const size_t np = (size_t)m->np;
+    const size_t out_bytes[8] = {sizeof(float) * B * c.nbit, sizeof(uint64_t) * B * ((c.nbit + 63) / 64), sizeof(float) * B * c.nclass,
+                                 sizeof(float) * B * c.nclass, sizeof(float) * c.ncontext * B * c.nclass, sizeof(float) * B * c.ncontext * c.dim,
+                                 sizeof(float) * B * c.proj_dim,
+                                 sizeof(float) * (all_layers ? c.layers : 1) * B * c.heads * c.ncontext * np};
+    int mask = 0;
+    for (int i = 0; i < 8; ++i)
+        if (outs[i]) mask |= 1 << i;
+    const size_t cap = (size_t)m->graph_max_batch;
+    if (int e = ensure_bytes(m, &m->g_in, &m->g_in_bytes, cap * 3 * c.image_size * c.image_size * 4)) return e;
+    for (int i = 0; i < 8; ++i)
+        if (outs[i])
+            if (int e = ensure_bytes(m, &m->g_out[i], &m->g_out_bytes[i], out_bytes[i] / B * cap)) return e;
+    CH_CHECK_HIP(hipMemcpyAsync(m->g_in, images, img_bytes, hipMemcpyDeviceToDevice, s));
+    auto staged = [&](int i) { return outs[i] ? m->g_out[i] : nullptr; };
+    auto chain = [&](hipStream_t st) {
+        return encode_impl(m, m->g_in, image_dtype, B, (float *)staged(0), (uint64_t *)staged(1), (float *)staged(2), (float *)staged(3),
+                           (float *)staged(4), (float *)staged(5), (float *)staged(6), (float *)staged(7), all_layers, st);
+    };
+    const auto key = std::make_tuple(B, image_dtype, mask, all_layers ? 1 : 0);
+    auto it = m->graphs.find(key);
+    if (it == m->graphs.end()) {
+        // first call of this shape: run it eagerly (this call's result; also performs every once-per-device function attribute
+        // setting outside the capture), then capture the same chain on the library's own stream and keep the instantiated graph
+        if (int e = chain(s)) return e;
+        if (!m->cap_stream) CH_CHECK_HIP(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+        ch_model::GraphEntry ge;
+        CH_CHECK_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int e = chain(m->cap_stream);
+        const hipError_t he = hipStreamEndCapture(m->cap_stream, &ge.graph);
+        if (e) {
+            if (ge.graph) (void)hipGraphDestroy(ge.graph);
+            return e;
+        }
+        CH_CHECK_HIP(he);
+        CH_CHECK_HIP(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+        m->graphs[key] = ge;
+        m->graph_captures++;
+    } else {
+        CH_CHECK_HIP(hipGraphLaunch(it->second.exec, s));
+        m->graph_replays++;
+    }
+    for (int i = 0; i < 8; ++i)
+        if (outs[i]) CH_CHECK_HIP(hipMemcpyAsync(outs[i], m->g_out[i], out_bytes[i], hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int ch_encode(ch_model *m, const void *images, int32_t image_dtype, int32_t B, float *out_codes,
+                         uint64_t *out_packed, float *out_logits_cont, float *out_logits_bin, float *out_logits_concept,
+                         float *out_hash_features, float *out_image_features, float *out_concept_attn,
+                         int32_t concept_attn_all_layers, void *stream) {
+    CH_REQUIRE(m != nullptr && images != nullptr && out_codes != nullptr, "null model / images / out_codes");
+    CH_REQUIRE(image_dtype == 0 || image_dtype == 1, "image_dtype must be 0 (fp32) or 1 (bf16)");
+    CH_REQUIRE(B >= 1 && B <= m->cfg.max_batch, "batch outside [1, max_batch]");
+    CH_REQUIRE(!out_logits_concept || m->concept_cent_l2, "model has no concept classifier (concept_ce.centroids)");
+    CH_REQUIRE(!out_image_features || m->vis_proj, "model has no post_layernorm / visual_projection");
+    hipStream_t s = (hipStream_t)stream;
+    if (m->graph_max_batch > 0 && B <= m->graph_max_batch && !m->prof_on) {
+        void *const outs[8] = {out_codes, out_packed, out_logits_cont, out_logits_bin, out_logits_concept, out_hash_features,
+                               out_image_features, out_concept_attn};
+        return encode_graph(m, images, image_dtype, B, outs, concept_attn_all_layers != 0, s);
+    }
+    return encode_impl(m, images, image_dtype, B, out_codes, out_packed, out_logits_cont, out_logits_bin, out_logits_concept,
+                       out_hash_features, out_image_features, out_concept_attn, concept_attn_all_layers != 0, s);
 }
 
 extern "C" int ch_encode_hidden(ch_model *m, const void *images, int32_t image_dtype, int32_t B, int32_t layer,

@@ -1,7 +1,9 @@
 // Internal layout of ch_model (weights, workspace, launch profiler): shared by model.hip (the encode chain) and train.hip
 // (the training step, which reuses the frozen backbone weights of an existing model).  Not part of the C-ABI.
 #pragma once
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/concepthash_hip.h"
@@ -84,6 +86,23 @@ struct ch_model {
     int splitk = 0;                 // split-K tail of the 256x256 GEMM (opt-in, measured slower: DESIGN.md section 3.8)
     int gemm_rows = 0;              // whole-row kernel for N = 384 (experiments build)
     int wide_kernel = 0;            // 256x384 GEMM for N % 384 == 0 (adapter bottleneck; experiments build): 1 = wherever supported
+    // ---- hipGraph replay of small batches (option "graph_max_batch", 0 = off): at batch 8 .. 64 the ~230 launches of a two-chain
+    // ch_encode cost more host time than GPU time, so a call with B <= graph_max_batch stages its images into `g_in`, replays the chain
+    // as ONE captured graph (keyed by batch, image dtype, requested outputs, attention-tap layout) and copies the requested outputs out
+    // of the staging buffers.  Any ch_model_set_option drops the cached graphs.  Off in the C-ABI default (a caller may be capturing
+    // ch_encode into a graph of its own); the Python wrapper switches it on.
+    int graph_max_batch = 0;
+    hipStream_t cap_stream = nullptr;
+    struct GraphEntry {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+    };
+    std::map<std::tuple<int, int, int, int>, GraphEntry> graphs;   // (B, image dtype, output mask, all-layers tap)
+    void *g_in = nullptr;
+    size_t g_in_bytes = 0;
+    void *g_out[8] = {};          // codes, packed, logits_cont, logits_bin, logits_concept, hash_features, image_features, concept_attn
+    size_t g_out_bytes[8] = {};
+    int64_t graph_replays = 0, graph_captures = 0;
     // read by ch_trainer_create from the model it is created on
     int train_chains = 1;
     int64_t train_chain_min_rows = 12000;

@@ -89,6 +89,12 @@ size_t ch_model_device_bytes(const ch_model *m);
  *   "resid_nt"      -1/0/1 non-temporal read-modify-write of the fp32 residual: off / by tensor size (default) / on
  *   "nt_out"        -1/0/1 non-temporal stores of large bf16 GEMM outputs: off / by tensor size (default) / on
  *   "group_n"       >= 0   n-tiles per L2-resident weight group of the GEMM tile order (0 = host heuristic)
+ *   "graph_max_batch" >= 0 ch_encode calls with B <= this value replay the launch chain as ONE captured hipGraph (images staged into a library
+ *                          buffer, requested outputs copied out of staging buffers; first call per (B, dtype, output set) runs eagerly and
+ *                          captures).  0 (default) = off: ch_encode then only enqueues kernels and is itself capturable by the caller.
+ *                          Bit-identical outputs; measured NEUTRAL on MI355X (batch 8: 2.07 vs 2.09 ms -- small batches are bound by the
+ *                          latency of one GEMM tile per launch on the GPU, not by host launch time), hence opt-in.
+ *                          (read-only keys of ch_model_get_option: "graph_replays", "graph_captures")
  *   "splitk"        0/1    split-K tail of the 256x256 GEMM (default 0; allocates 64 MiB per chain on first use)
  *   "serpentine"    0/1    alternate the row direction of consecutive launches (default 0)
  *   "small_kernel", "pp_sched", "fused_adapter", "gemm_rows", "wide_kernel"  experiment kernels: non-zero values need the experiments build

@@ -354,3 +354,44 @@ def test_small_and_odd_batches_through_the_default_chain(dev, batch):
     ref = eo.encode(sd, x[:batch], heads=cfg["heads"], with_pooled=True)
     assert _rel_err(small["codes"].cpu(), ref["codes"]) < 4e-2
     assert _rel_err(small["image_features"].cpu(), ref["image_features"]) < 4e-2
+
+
+def test_graph_replay_of_small_batches_is_bit_identical(dev):
+    """Option "graph_max_batch" (opt-in: measured neutral, profiles/r04_graph_replay_ab.txt): a ch_encode call with B <= that value stages its
+    images, replays the whole two-chain launch sequence as ONE captured hipGraph and copies the requested outputs out of staging buffers.
+    First call of a (batch, dtype, output set) runs eagerly and captures; later calls replay.  Every output must equal the eager path's
+    bit for bit -- fp32 and bf16 images, several output sets (incl. every layer's attention rows), batch sizes 1 .. 9, repeated replays
+    with other inputs in between -- and an option change must drop the cached graphs."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_s16"])
+    cfg["L"] = 3
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    x = eo.synthetic_images(9, cfg["image"]).to(dev)
+    eager = _encoder(sd, cfg["heads"], max_batch=16, options={"graph_max_batch": 0})
+    graph = _encoder(sd, cfg["heads"], max_batch=16, options={"graph_max_batch": 64})
+    assert graph.get_option("graph_max_batch") == 16 and eager.get_option("graph_max_batch") == 0    # clamped to max_batch
+    wants = [("codes", "packed"), ("codes", "packed", "logits_cont", "logits_bin", "logits_concept", "hash_features", "image_features"),
+             ("codes", "concept_attn"), ("codes", "concept_attn_layers")]
+    for B in (1, 2, 5, 9):
+        for xs in (x[:B], x[:B].to(torch.bfloat16)):
+            for want in wants:
+                ref = eager.encode(xs, want=want)
+                for rep in range(3):                      # capture, replay, replay (another input staged in between)
+                    if rep == 2:
+                        graph.encode(torch.flip(xs, dims=[0]), want=want)
+                    got = graph.encode(xs, want=want)
+                    for k in ref:
+                        assert torch.equal(got[k], ref[k]), (B, str(xs.dtype), want, k, rep)
+    caps, reps = graph.get_option("graph_captures"), graph.get_option("graph_replays")
+    assert caps == 4 * 2 * len(wants) and reps >= 2 * caps, (caps, reps)
+    assert eager.get_option("graph_captures") == 0
+    graph.set_option("streams", 1)                        # a captured chain has the old setting baked in: dropped and re-captured
+    got = graph.encode(x[:5], want=wants[0])
+    assert graph.get_option("graph_captures") == caps + 1
+    assert torch.equal(got["codes"], eager.encode(x[:5], want=wants[0])["codes"])
+    big = graph.encode(x, want=wants[0])                  # 9 <= 16: graph; a batch above the limit runs eagerly
+    graph.set_option("graph_max_batch", 4)
+    again = graph.encode(x, want=wants[0])
+    assert torch.equal(big["codes"], again["codes"]) and graph.get_option("graph_captures") == caps + 2
+    eager.close()
+    graph.close()
