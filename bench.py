@@ -254,7 +254,7 @@ def main():
 
     # ---- the batch sizes the reference evaluates / trains with (configs/val.yaml:10 batch_size 64; model yaml batch 32), outside the
     # timed region: the same step (encode + pack + top-10 vs the gallery shard) at per-GPU batch 8 / 32 / 64 / 256, default options
-    if rank == 0 and not args.encode_only:
+    if rank == 0 and world == 1 and not args.encode_only:      # (its step would enter collectives the other ranks are not in)
         result["value_by_batch"] = by_batch_block(torch, enc, make_step, images, B)
 
     # ---- Hamming blocks (outside the timed region).  FIRST of the extra blocks: every rank takes part in its collectives, and the
