@@ -55,8 +55,9 @@ def _dont_fork(buf: torch.Tensor) -> None:
 
 
 def default_threads() -> int:
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return max(1, min(16, n))
+    """Entropy-decode threads: what the container's CPU quota allows (hostcpu.cpu_budget), at most 16."""
+    from .hostcpu import cpu_budget
+    return max(1, min(16, cpu_budget()))
 
 
 def _as_bytes_array(f) -> np.ndarray:
@@ -78,11 +79,13 @@ class GpuJpegDecoder:
             raise RuntimeError("GpuJpegDecoder needs a GPU (MI355X); there is no CPU fallback")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.threads = int(threads) if threads else default_threads()
+        self.pretouch = False          # diagnostic (tools/loader_probe.py --pretouch): time the first touch of a worker's batch separately
         self.strict = bool(strict)     # True: a file outside the supported subset raises instead of going through PIL
-        self._ring = [dict(coef=None, desc=None, fb=None, event=None) for _ in range(self._RING)]
+        self._ring = [dict(coef=None, desc=None, fb=None, event=None, coef_dev=None, desc_dev=None, copied=None) for _ in range(self._RING)]
         self._pos = 0
+        self._copy_stream = None       # host -> device copies of a staged batch run here, beside the caller's kernels (SDMA engine)
         self.stats = {"images": 0, "gpu": 0, "pil_fallback": 0, "fallback_reasons": {}, "plan_s": 0.0, "ring_wait_s": 0.0, "entropy_s": 0.0,
-                      "enqueue_s": 0.0}
+                      "enqueue_s": 0.0, "touch_s": 0.0}
 
     # -- host half ------------------------------------------------------------------------------------------------
     def plan(self, files: Sequence) -> Tuple[np.ndarray, list, ctypes.Array, ctypes.Array]:
@@ -129,6 +132,29 @@ class GpuJpegDecoder:
             _dont_fork(buf)
         return buf
 
+    def _device(self, slot, key, nbytes):
+        buf = slot[key]
+        if buf is None or buf.numel() < nbytes:
+            buf = slot[key] = torch.empty(max(int(nbytes * 1.25), 1 << 16), dtype=torch.uint8, device=self.device)
+        return buf
+
+    def _upload(self, slot, desc_nbytes, total_coef):
+        """Last step of the host half: the slot's descriptors and coefficient blocks go to the slot's DEVICE buffers on the decoder's own
+        copy stream, as soon as they exist -- not when the consumer gets round to the batch.  The copy (151 MB for 256 images of
+        500 x 375, ~2.7 ms over PCIe) then runs on the DMA engine under the previous batch's encode instead of in front of this one's
+        kernels on the caller's stream.  `device_stage` makes its stream wait for `slot["copied"]`."""
+        with torch.cuda.device(self.device):
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(self.device)
+            cs = self._copy_stream
+            with torch.cuda.stream(cs):
+                self._device(slot, "desc_dev", desc_nbytes)[:desc_nbytes].copy_(slot["desc"][:desc_nbytes], non_blocking=True)
+                if total_coef:
+                    self._device(slot, "coef_dev", total_coef * 2)[:total_coef * 2].copy_(slot["coef"][:total_coef * 2], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(cs)
+        slot["copied"] = ev
+
     # -- decode -----------------------------------------------------------------------------------------------------
     def _host_stage_packed(self, data: torch.Tensor, lengths) -> Optional["StagedJpegBatch"]:
         """The common case in two GIL-free calls: a batch whose files sit back to back in one buffer (RawJpegBatch) and all belong to the
@@ -150,6 +176,10 @@ class GpuJpegDecoder:
             slot = self._slot()
             coef_host = self._pinned(slot, "coef", max(totals[0], 1) * 2)
             desc_host = self._pinned(slot, "desc", desc.nbytes)
+        if self.pretouch:                              # diagnostic: fault the worker's shared-memory pages in before the threads start
+            t_touch = time.perf_counter()
+            int(data.numpy()[::4096].sum())
+            self.stats["touch_s"] += time.perf_counter() - t_touch
         t2 = time.perf_counter()
         _lib.check(self.lib.ch_jpeg_entropy_decode_packed(base, offsets.ctypes.data, n, desc.ctypes.data, coef_host.data_ptr(), self.threads),
                    "ch_jpeg_entropy_decode_packed")
@@ -160,19 +190,20 @@ class GpuJpegDecoder:
             for i in np.nonzero(desc["status"])[0]:
                 self._fallback(int(i), desc, bufs, fallback, keep_size=True)
         sizes = list(zip(desc["height"].tolist(), desc["width"].tolist()))
-        desc_host[:desc.nbytes].copy_(torch.from_numpy(desc.view(np.uint8).reshape(-1)))
+        desc_host.numpy()[:desc.nbytes] = desc.view(np.uint8).reshape(-1)     # numpy, not torch copy_: no OpenMP team on this thread
         fb = None
         if fallback:
             with torch.cuda.device(self.device):
                 fb = self._pinned(slot, "fb", sum(a.size for a in fallback.values()))
             o = 0
             for a in fallback.values():
-                fb[o:o + a.size].copy_(torch.from_numpy(a.reshape(-1)))
+                fb.numpy()[o:o + a.size] = a.reshape(-1)
                 o += a.size
         st = self.stats
         st["plan_s"] += t1 - t0
         st["ring_wait_s"] += t2 - t1
         st["entropy_s"] += t3 - t2
+        self._upload(slot, desc.nbytes, totals[0])
         return StagedJpegBatch(self, slot, desc, fallback, totals, sizes, fb)
 
     def host_stage(self, files) -> "StagedJpegBatch":
@@ -209,20 +240,21 @@ class GpuJpegDecoder:
         with torch.cuda.device(self.device):
             desc_host = self._pinned(slot, "desc", desc.nbytes)
             fb = self._pinned(slot, "fb", sum(a.size for a in fallback.values())) if fallback else None
-        desc_host[:desc.nbytes].copy_(torch.from_numpy(desc.view(np.uint8).reshape(-1)))
+        desc_host.numpy()[:desc.nbytes] = desc.view(np.uint8).reshape(-1)     # numpy, not torch copy_: no OpenMP team on this thread
         if fallback:
             o = 0
             for a in fallback.values():
-                fb[o:o + a.size].copy_(torch.from_numpy(a.reshape(-1)))
+                fb.numpy()[o:o + a.size] = a.reshape(-1)
                 o += a.size
         st = self.stats
         st["plan_s"] += t1 - t0
         st["ring_wait_s"] += t2 - t1
         st["entropy_s"] += t3 - t2
+        self._upload(slot, desc.nbytes, totals[0])
         return StagedJpegBatch(self, slot, desc, fallback, totals, sizes, fb)
 
     def device_stage(self, staged: "StagedJpegBatch", stream=None):
-        """GPU half: coefficient blocks + descriptors to the device (non-blocking copies from the pinned slot), `ch_jpeg_reconstruct`, the
+        """GPU half: wait (on the stream) for the host half's uploads, `ch_jpeg_reconstruct` from the slot's device buffers, the
         PIL-decoded files into their slots.  -> (pixels, sizes)."""
         dev = self.device
         n = len(staged.sizes)
@@ -235,14 +267,11 @@ class GpuJpegDecoder:
         with torch.cuda.device(dev), torch.cuda.stream(s):
             pixels = torch.empty(max(total_pix, 1), dtype=torch.uint8, device=dev)
             desc_host = slot["desc"]
-            desc_dev = torch.empty(desc.nbytes, dtype=torch.uint8, device=dev)
-            desc_dev.copy_(desc_host[:desc.nbytes], non_blocking=True)
+            s.wait_event(slot["copied"])                     # the host half's uploads (copy stream)
             if total_coef:
-                coef_dev = torch.empty(total_coef * 2, dtype=torch.uint8, device=dev)
-                coef_dev.copy_(slot["coef"][:total_coef * 2], non_blocking=True)
                 planes = torch.empty(max(total_plane, 16), dtype=torch.uint8, device=dev)
-                _lib.check(self.lib.ch_jpeg_reconstruct(_lib.ptr(coef_dev), _lib.ptr(desc_dev), desc_host.data_ptr(), n, _lib.ptr(planes),
-                                                        _lib.ptr(pixels), _lib.stream_ptr(s)), "ch_jpeg_reconstruct")
+                _lib.check(self.lib.ch_jpeg_reconstruct(_lib.ptr(slot["coef_dev"]), _lib.ptr(slot["desc_dev"]), desc_host.data_ptr(), n,
+                                                        _lib.ptr(planes), _lib.ptr(pixels), _lib.stream_ptr(s)), "ch_jpeg_reconstruct")
             o = 0
             for i, a in fallback.items():
                 po = int(desc["pix_offset"][i])

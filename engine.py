@@ -8,7 +8,9 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
-default_workers = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+from concepthash_amd.hostcpu import cpu_budget, limit_torch_threads
+
+default_workers = min(16, cpu_budget())     # the container's CPU quota, not the cores it can see (hostcpu.py)
 
 
 _forkserver_ready = False
@@ -37,6 +39,7 @@ def _worker_context(workers):
 def dataloader(d, bs=256, shuffle=False, workers=-1, drop_last=False, sampler=None):
     if len(d) == 0:
         return []
+    limit_torch_threads()                   # torch's CPU pool inside the container's quota before any loader thread starts (hostcpu.py)
     if workers < 0:
         workers = default_workers
     if getattr(d, "in_memory", False):      # tensor-backed datasets need no worker processes
@@ -44,11 +47,13 @@ def dataloader(d, bs=256, shuffle=False, workers=-1, drop_last=False, sampler=No
     if getattr(d, "gpu_decode", False):
         # `gpu_decode` datasets fetch a whole BATCH per call (one read loop into one buffer, no per-item tensors, no collate): the
         # loader hands the dataset index lists.  Workers only read files; the host cores belong to the trainer's entropy-decode threads.
+        # The workers PERSIST across epochs (the trainers iterate the same loader object every epoch): starting six of them costs
+        # 0.35-1.1 s, a third of a 6 K-image epoch at this path's rate (tools/loader_probe.py).
         from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
         workers = min(workers, 6)
         base = sampler if sampler is not None else (RandomSampler(d) if shuffle else SequentialSampler(d))
         return DataLoader(d, batch_size=None, sampler=BatchSampler(base, bs, drop_last), num_workers=workers, pin_memory=False,
-                          multiprocessing_context=_worker_context(workers), persistent_workers=False)
+                          multiprocessing_context=_worker_context(workers), persistent_workers=workers > 0)
     return DataLoader(d, bs, shuffle, drop_last=drop_last, num_workers=workers, sampler=sampler,
                       pin_memory=workers > 0, collate_fn=getattr(d, "collate_fn", None), multiprocessing_context=_worker_context(workers))
 

@@ -16,8 +16,37 @@ from concepthash_amd.preprocess import GpuPreprocess
 from utils.datasets import HashingDataset, OneHot
 
 
+def _cpu_stat():
+    """cgroup-v2 CPU bandwidth accounting of this container: (periods, periods throttled, throttled microseconds, usage microseconds)."""
+    try:
+        kv = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return tuple(int(kv.get(k, 0)) for k in ("nr_periods", "nr_throttled", "throttled_usec", "usage_usec"))
+    except OSError:
+        return (0, 0, 0, 0)
+
+
+def _thread_cpu():
+    """CPU seconds of every live thread of this process, by name, plus the process total and the reaped children's total."""
+    import resource
+    tick = os.sysconf("SC_CLK_TCK")
+    live = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            f = open(f"/proc/self/task/{tid}/stat").read()
+            name = f[f.index("(") + 1:f.rindex(")")]
+            rest = f[f.rindex(")") + 2:].split()
+            live[f"{name}:{tid}"] = (int(rest[11]) + int(rest[12])) / tick
+        except OSError:
+            pass
+    ru, rc = resource.getrusage(resource.RUSAGE_SELF), resource.getrusage(resource.RUSAGE_CHILDREN)
+    return live, ru.ru_utime + ru.ru_stime, rc.ru_utime + rc.ru_stime
+
+
 def main():
     nimg = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    if "--affinity" in sys.argv:        # confine this process (and the workers it starts) to the first N cores it may use
+        ncore = int(sys.argv[sys.argv.index("--affinity") + 1])
+        os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:ncore])
     dev = torch.device("cuda:0")
     cfg = syn.CONFIGS["vit_b16"]
     enc = ConceptHashEncoder(syn.synthetic_state_dict(cfg, nbit=64, nclass=200, seed=42), heads=cfg["heads"], max_batch=256, device=dev)
@@ -33,15 +62,27 @@ def main():
     dec = GpuJpegDecoder(device=dev)
     ds = HashingDataset(root, "test.txt", target_transform=OneHot(200), gpu_decode=True)
     import engine
+    from concepthash_amd.hostcpu import cpu_budget, limit_torch_threads
+    if "--no-thread-limit" not in sys.argv:
+        limit_torch_threads()
+    print("cpu budget", cpu_budget(), "torch threads", torch.get_num_threads(), flush=True)
     combos = [(16, 6), (8, 6), (12, 2), (16, 2), (8, 2), (24, 3)] if "--matrix" in sys.argv else [(16, 6)]
+    if "--workers" in sys.argv:            # e.g. `--workers 0` under rocprofv3 (no child processes)
+        combos = [(16, int(sys.argv[sys.argv.index("--workers") + 1]))]
     for threads, nworkers in combos:
         dec.threads = threads
+        dec.pretouch = "--pretouch" in sys.argv
         for rep in range(2):
-            for k in ("plan_s", "ring_wait_s", "entropy_s", "enqueue_s"):
+            for k in ("plan_s", "ring_wait_s", "entropy_s", "enqueue_s", "touch_s"):
                 dec.stats[k] = 0.0
             dl = engine.dataloader(ds, 256, shuffle=False, drop_last=False, workers=nworkers)
+            if "--no-thread-limit" in sys.argv:
+                torch.set_num_threads(128)
             workers, pin, ctx = dl.num_workers, False, f"forkserver threads {threads}"
             tw = td = tp = te = 0.0
+            t_first = None
+            cs0 = _cpu_stat()
+            th0 = _thread_cpu()
             t_all = time.perf_counter()
             from concepthash_amd.jpeg import prefetch_decoded
             it = iter(prefetch_decoded(dl, dec) if "--no-prefetch" not in sys.argv else dl)
@@ -53,6 +94,8 @@ def main():
                 except StopIteration:
                     break
                 t1 = time.perf_counter()
+                if t_first is None:
+                    t_first = t1 - t_all
                 px, sizes = image.finish() if hasattr(image, "staged") else dec.decode(image.files)
                 t2 = time.perf_counter()
                 x = pre(px, sizes)
@@ -64,10 +107,20 @@ def main():
             torch.cuda.synchronize()
             tot = time.perf_counter() - t_all
             nb = -(-n // 256)
-            print(f"workers {workers} pin {pin} ctx {ctx} pass {rep}: {n / tot:8.0f} images/s | per batch ms: wait {tw / nb * 1e3:7.1f} decode {td / nb * 1e3:7.1f} "
-                  f"(plan {dec.stats['plan_s'] / nb * 1e3:.1f} ring-wait {dec.stats['ring_wait_s'] / nb * 1e3:.1f} entropy {dec.stats['entropy_s'] / nb * 1e3:.1f} "
+            cs1 = _cpu_stat()
+            print(f"  cgroup cpu: {cs1[1] - cs0[1]} of {cs1[0] - cs0[0]} periods throttled, {(cs1[2] - cs0[2]) / 1e3:.0f} ms throttled, "
+                  f"{(cs1[3] - cs0[3]) / 1e6 / tot:.1f} cores busy on average over {tot * 1e3:.0f} ms")
+            print(f"workers {workers} pin {pin} ctx {ctx} pass {rep}: {n / tot:8.0f} images/s ({(n - 256) / max(tot - t_first, 1e-9):.0f} after the first batch, which took {t_first * 1e3:.0f} ms) | per batch ms: wait {tw / nb * 1e3:7.1f} decode {td / nb * 1e3:7.1f} "
+                  f"(plan {dec.stats['plan_s'] / nb * 1e3:.1f} ring-wait {dec.stats['ring_wait_s'] / nb * 1e3:.1f} entropy {dec.stats['entropy_s'] / nb * 1e3:.1f} touch {dec.stats['touch_s'] / nb * 1e3:.1f} "
                   f"enqueue {dec.stats['enqueue_s'] / nb * 1e3:.1f}) preprocess {tp / nb * 1e3:6.1f} encode-launch {te / nb * 1e3:6.1f}", flush=True)
             del it, dl
+            time.sleep(0.5)                 # let the workers exit so that RUSAGE_CHILDREN holds their time
+            th1 = _thread_cpu()
+            d_live = {k: v - th0[0].get(k, 0.0) for k, v in th1[0].items()}
+            top = sorted(d_live.items(), key=lambda kv: -kv[1])[:8]
+            self_d, child_d = th1[1] - th0[1], th1[2] - th0[2]
+            print(f"  cpu seconds: process {self_d:.2f} (live threads {sum(d_live.values()):.2f}, exited threads {self_d - sum(d_live.values()):.2f}), "
+                  f"reaped children {child_d:.2f}; top live threads: " + ", ".join(f"{k} {v:.2f}" for k, v in top), flush=True)
     shutil.rmtree(root, ignore_errors=True)
 
 
