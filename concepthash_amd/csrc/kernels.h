@@ -230,7 +230,11 @@ int ch_normalize_bf16(const bf16_t *x, const float *stats, int64_t rows, int D, 
 // may alias dres_in, may be null), out_b (bf16, may be null)
 // xhat_out (optional): also write x_hat = (x - mean) * rstd as bf16
 int ch_ln_bwd(const bf16_t *dyg, const bf16_t *x, const float *stats, int64_t rows, int D, float eps, const float *dres_in,
-              float *dres_out, bf16_t *out_b, hipStream_t s, bf16_t *xhat_out = nullptr);
+              float *dres_out, bf16_t *out_b, hipStream_t s, bf16_t *xhat_out = nullptr, float *colsum_out = nullptr,
+              float *colsum_ws = nullptr, const bf16_t *dres_in_b = nullptr);
+// dres_in_b (optional): read the bypass gradient from this bf16 copy instead of dres_in
+// colsum_out (optional, D floats): the column sums of the result as a by-product; colsum_ws: ch_ln_bwd_colsum_ws_floats(rows, D) floats
+size_t ch_ln_bwd_colsum_ws_floats(int64_t rows, int D);
 // out[n][k] = sum_m A[m][n] * B[m][k]  (A [rows, N] ld lda, B [rows, K] ld ldb, bf16; out [N, K] fp32); ws: ch_wgrad_ws_floats floats.
 // Rows up to the next multiple of 32 are read: they must be allocated; A's are zeroed by the call, B's must be finite.
 int ch_wgrad_tn(bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int64_t rows_alloc, int N, int K, float *out,
@@ -260,4 +264,4 @@ int ch_gather_concept_rows(const float *H, int B, int ntok, int Q, int D, float 
 // qkv [B*ntok, 3D] (q | k | v), dO [B*ntok, D] -> dqkv [B*ntok, 3D]; head_dim 64
 // dpext (optional): [B, heads, ncon, ntok - ncon - 1] fp32 cotangent of the last `ncon` tokens' attention rows over tokens 1 .. ntok-ncon-1
 int ch_attention_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s,
-                     const float *dpext = nullptr, int ncon = 0);
+                     const float *dpext = nullptr, int ncon = 0, int rotate = 0);
