@@ -111,7 +111,7 @@ SIGNATURES = {
 # handle is created.  The library itself reads no environment variable; code that needs a setting passes `options=` / set_option().
 OPTION_KEYS = ("streams", "ln_fold", "prune_last", "pp_min_k", "small_kernel", "serpentine", "pp_sched", "fused_adapter", "resid_nt",
                "nt_out", "group_n", "splitk", "gemm_rows", "wide_kernel", "graph_max_batch", "train_chains", "train_chain_min_rows", "train_prune_last",
-               "train_fused_colsum", "train_attn_rotate", "train_bf16_bypass")
+               "train_batched_grads")
 _ENV_OVERRIDES = {  # env name -> (option key, value map)
     "CH_STREAMS": ("streams", int), "CH_LN_FOLD": ("ln_fold", int), "CH_PRUNE_LAST": ("prune_last", int),
     "CH_GEMM_PP_MIN_K": ("pp_min_k", int), "CH_GEMM_SMALL": ("small_kernel", int), "CH_SERPENTINE": ("serpentine", int),

@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) v4s lds_v4s;
 template <int KB, bool EXT>
 __global__ __launch_bounds__(NW * 64, 4) void attention_bwd_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dO, int ntok,
                                                                int heads, float scale_log2e, bf16_t *__restrict__ dqkv,
-                                                               const float *__restrict__ dpext, int ncon, int rotate) {
+                                                               const float *__restrict__ dpext, int ncon) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT = KB * 2;   // 16-row tiles
     constexpr int KP = KB * 32;  // padded rows (keys and queries)
@@ -45,11 +45,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bwd_kernel(const bf16_t 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Tile ownership: tiles wown, wown + NW, ...  With 13 tiles (201 tokens) over 8 waves five waves carry two tiles; unrotated those
-    // are waves 0-4, and waves 0 and 4 share SIMD 0 -- with two workgroups per CU that SIMD issues 8 tile-units of VALU work while the
-    // others issue 6 (the kernel is VALU-issue bound).  Rotating the ownership by the workgroup's dispatch round moves the heavy SIMD
-    // (rotation 0/1/2/3 -> SIMD 0/3/2/1), so co-resident workgroups load different SIMDs: 7 units at worst.
-    const int wown = rotate ? (wid + ((blockIdx.x >> 8) & 3)) & (NW - 1) : wid;
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
     const int D = heads * HD;
     const size_t ld = (size_t)3 * D;
@@ -93,7 +88,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bwd_kernel(const bf16_t 
     __syncthreads();
 
     // ================================ phase A: per query tile -> statistics and dQ ==========================================
-    for (int qt = wown; qt < QT; qt += NW) {
+    for (int qt = wid; qt < QT; qt += NW) {
         const int q = qt * 16 + fr;
         const bool qvalid = q < ntok;
         bf16x8 qf0, qf1, gf0, gf1;      // not prefetched a tile ahead: 16 VGPRs that the four-waves-per-SIMD budget does not have
@@ -222,19 +217,19 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bwd_kernel(const bf16_t 
         }
     }
     bf16x8 k0, k1, v0, v1;   // this wave's first key tile, from global, under the restaging
-    if (wown < QT) {
-        row_frag(base + D, ld, wown, k0, k1);
-        row_frag(base + 2 * D, ld, wown, v0, v1);
+    if (wid < QT) {
+        row_frag(base + D, ld, wid, k0, k1);
+        row_frag(base + 2 * D, ld, wid, v0, v1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // ================================ phase B: per key tile -> dK, dV ========================================================
-    for (int kt = wown; kt < QT; kt += NW) {
+    for (int kt = wid; kt < QT; kt += NW) {
         const int key = kt * 16 + fr;
         const bool kvalid = key < ntok;
         const bool edge_tile = kt * 16 + 16 > ntok;
-        if (kt != wown) {
+        if (kt != wid) {
             row_frag(base + D, ld, kt, k0, k1);
             row_frag(base + 2 * D, ld, kt, v0, v1);
         }
@@ -300,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_bwd_kernel(const bf16_t 
 }
 
 template <int KB, bool EXT>
-int launch_bwd_inst(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, const float *dpext, int ncon, int rotate, hipStream_t s) {
+int launch_bwd_inst(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, const float *dpext, int ncon, hipStream_t s) {
     constexpr int KP = KB * 32;
     const size_t lds = (size_t)KP * 128 * 2 + (size_t)KP * 16;
     CH_REQUIRE(lds <= 160 * 1024, "attention backward: sequence too long for the LDS-resident kernel");
@@ -308,14 +303,14 @@ int launch_bwd_inst(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int he
     if (int e = ch_func_max_lds((const void *)attention_bwd_kernel<KB, EXT>, (int)lds, lds_once)) return e;
     const float scale_log2e = 0.125f * 1.4426950408889634f;
     hipLaunchKernelGGL((attention_bwd_kernel<KB, EXT>), dim3(B * heads), dim3(NW * 64), lds, s, qkv, dO, ntok, heads, scale_log2e, dqkv, dpext,
-                       ncon, rotate);
+                       ncon);
     CH_LAUNCH_CHECK();
     return 0;
 }
 template <int KB>
-int launch_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, const float *dpext, int ncon, int rotate, hipStream_t s) {
-    return dpext ? launch_bwd_inst<KB, true>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s)
-                 : launch_bwd_inst<KB, false>(qkv, dO, B, ntok, heads, dqkv, nullptr, 0, rotate, s);
+int launch_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, const float *dpext, int ncon, hipStream_t s) {
+    return dpext ? launch_bwd_inst<KB, true>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s)
+                 : launch_bwd_inst<KB, false>(qkv, dO, B, ntok, heads, dqkv, nullptr, 0, s);
 }
 
 }  // namespace
@@ -323,20 +318,20 @@ int launch_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, 
 // qkv [B*ntok, 3D] bf16 (q | k | v), dO [B*ntok, D] bf16 -> dqkv [B*ntok, 3D] bf16 (dq | dk | dv); head_dim 64
 // dpext (optional): [B, heads, ncon, ntok - ncon - 1] fp32 cotangent of the concept tokens' attention rows over the patch tokens
 int ch_attention_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s, const float *dpext,
-                     int ncon, int rotate) {
+                     int ncon) {
     CH_REQUIRE(B > 0 && ntok > 0 && heads > 0, "attention backward: empty problem");
     CH_REQUIRE(!dpext || (ncon >= 1 && ncon < ntok - 1), "attention backward: the probability cotangent needs 1 <= ncon < ntok - 1");
     const int KB = (ntok + 31) / 32;
     switch (KB) {
-        case 1: return launch_bwd<1>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s);
-        case 2: return launch_bwd<2>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s);
-        case 3: return launch_bwd<3>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s);
-        case 4: return launch_bwd<4>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s);
-        case 5: return launch_bwd<5>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s);
-        case 6: return launch_bwd<6>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s);
-        case 7: return launch_bwd<7>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s);
-        case 8: return launch_bwd<8>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s);
-        case 9: return launch_bwd<9>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, rotate, s);
+        case 1: return launch_bwd<1>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 2: return launch_bwd<2>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 3: return launch_bwd<3>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 4: return launch_bwd<4>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 5: return launch_bwd<5>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 6: return launch_bwd<6>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 7: return launch_bwd<7>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 8: return launch_bwd<8>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
+        case 9: return launch_bwd<9>(qkv, dO, B, ntok, heads, dqkv, dpext, ncon, s);
     }
     ch_set_error("attention backward: more than 288 tokens per image is not built (LDS-resident Q/K/V/dO)");
     return 2;

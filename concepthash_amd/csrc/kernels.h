@@ -230,18 +230,23 @@ int ch_normalize_bf16(const bf16_t *x, const float *stats, int64_t rows, int D, 
 // may alias dres_in, may be null), out_b (bf16, may be null)
 // xhat_out (optional): also write x_hat = (x - mean) * rstd as bf16
 int ch_ln_bwd(const bf16_t *dyg, const bf16_t *x, const float *stats, int64_t rows, int D, float eps, const float *dres_in,
-              float *dres_out, bf16_t *out_b, hipStream_t s, bf16_t *xhat_out = nullptr, float *colsum_out = nullptr,
-              float *colsum_ws = nullptr, const bf16_t *dres_in_b = nullptr);
-// dres_in_b (optional): read the bypass gradient from this bf16 copy instead of dres_in
-// colsum_out (optional, D floats): the column sums of the result as a by-product; colsum_ws: ch_ln_bwd_colsum_ws_floats(rows, D) floats
-size_t ch_ln_bwd_colsum_ws_floats(int64_t rows, int D);
+              float *dres_out, bf16_t *out_b, hipStream_t s, bf16_t *xhat_out = nullptr);
 // out[n][k] = sum_m A[m][n] * B[m][k]  (A [rows, N] ld lda, B [rows, K] ld ldb, bf16; out [N, K] fp32); ws: ch_wgrad_ws_floats floats.
 // Rows up to the next multiple of 32 are read: they must be allocated; A's are zeroed by the call, B's must be finite.
+// chunks_out (optional): leave the chunk slabs in ws unreduced and report how many there are (-> ch_reduce_partials_multi); out unused
 int ch_wgrad_tn(bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int64_t rows_alloc, int N, int K, float *out,
-                float *ws, hipStream_t s);
+                float *ws, hipStream_t s, int *chunks_out = nullptr);
+// out[i] = sum over chunks of partial[c][i], i < 4 * n4, fixed association; up to four such reductions in one launch
+struct ChReduceJob {
+    const float *partial;
+    float *out;
+    int nchunks;
+    int n4;
+};
+int ch_reduce_partials_multi(const ChReduceJob *jobs, int njobs, hipStream_t s);
 size_t ch_wgrad_ws_floats(int64_t rows, int N, int K);
 // out[n] = sum_m A[m][n]; A bf16 (is_f32 = 0) or fp32 (1); ws: ch_colsum_ws_floats(N) floats
-int ch_colsum(const void *A, int is_f32, int lda, int64_t rows, int N, float *out, float *ws, hipStream_t s);
+int ch_colsum(const void *A, int is_f32, int lda, int64_t rows, int N, float *out, float *ws, hipStream_t s, int *chunks_out = nullptr);
 size_t ch_colsum_ws_floats(int N);
 // dst[c][r] = bf16(src[r][c] * (colscale ? colscale[c] : 1)); dst [C, ld_dst]
 int ch_transpose_f32_to_bf16(const float *src, int R, int C, int ld_src, const float *colscale, bf16_t *dst, int ld_dst, hipStream_t s);
@@ -249,7 +254,8 @@ int ch_transpose_bf16(const bf16_t *src, int R, int C, int ld_src, bf16_t *dst, 
 // gradients of one adapter's parameters from G = dH^T g [D, bpad], cu = colsum(dH), T = dpre^T x_hat [bpad, D], cd = colsum(dpre);
 // params / grads: one adapter's block of the arena ([ln_w D][ln_b D][down_w b*D][down_b b][up_w D*b][up_b D][scale 1])
 int ch_adapter_grads(const float *G, const float *cu, const float *T, const float *cd, const float *params, int D, int b, int bpad,
-                     float *grads, float *ws /* >= 256 floats */, hipStream_t s);
+                     float *grads, float *ws /* >= 256 floats per adapter */, hipStream_t s, int nad = 1, int64_t stride = 0);
+// nad > 1: slot arrays (G / T stride D * bpad, cu D, cd bpad, params / grads `stride`, ws 256), one launch pair for all of them
 // bf16 / LayerNorm-folded / transposed working copies of `nad` adapters from the parameter arena (slot arrays, one slot per adapter)
 int ch_adapter_refresh(const float *params, int64_t stride, int nad, int D, int b, int bpad, bf16_t *down_wf, float *fold_c, float *fold_d,
                        bf16_t *up_w, bf16_t *up_wT, bf16_t *down_wgT, hipStream_t s);
@@ -264,4 +270,4 @@ int ch_gather_concept_rows(const float *H, int B, int ntok, int Q, int D, float 
 // qkv [B*ntok, 3D] (q | k | v), dO [B*ntok, D] -> dqkv [B*ntok, 3D]; head_dim 64
 // dpext (optional): [B, heads, ncon, ntok - ncon - 1] fp32 cotangent of the last `ncon` tokens' attention rows over tokens 1 .. ntok-ncon-1
 int ch_attention_bwd(const bf16_t *qkv, const bf16_t *dO, int B, int ntok, int heads, bf16_t *dqkv, hipStream_t s,
-                     const float *dpext = nullptr, int ncon = 0, int rotate = 0);
+                     const float *dpext = nullptr, int ncon = 0);

@@ -664,9 +664,7 @@ const OptionRef g_options[] = {
     {"train_chains", 0, CH_OPT_FIELD(train_chains), 1, 2},
     {"train_chain_min_rows", 2, CH_OPT_FIELD(train_chain_min_rows), 1, (int64_t)1 << 40},
     {"train_prune_last", 1, CH_OPT_FIELD(train_prune_last), 0, 1},
-    {"train_fused_colsum", 1, CH_OPT_FIELD(train_fused_colsum), 0, 1},
-    {"train_attn_rotate", 1, CH_OPT_FIELD(train_attn_rotate), 0, 1},
-    {"train_bf16_bypass", 1, CH_OPT_FIELD(train_bf16_bypass), 0, 1},
+    {"train_batched_grads", 1, CH_OPT_FIELD(train_batched_grads), 0, 1},
 };
 #undef CH_OPT_FIELD
 const OptionRef *find_option(const char *key) {

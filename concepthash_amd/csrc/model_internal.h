@@ -107,9 +107,7 @@ struct ch_model {
     int train_chains = 2;           // two micro-batch chains when each has >= train_chain_min_rows rows (round 4: -4.6 % at batch 256, -5.3 % at 128)
     int64_t train_chain_min_rows = 12000;
     bool train_prune_last = true;
-    bool train_attn_rotate = false;   // attention backward: rotate the wave -> tile ownership per dispatch round (attention_bwd.hip)
-    bool train_bf16_bypass = false;   // adapter LayerNorm backward reads the bypass gradient from dH's bf16 copy (experiment)
-    bool train_fused_colsum = false;  // the adapters' up-bias gradient (column sums of dH) as a by-product of the LayerNorm backward that writes dH
+    bool train_batched_grads = true;  // one reduction launch per adapter, one gradient-assembly launch pair per step (train.hip)
     float *Hc = nullptr;
     float *head_xn = nullptr, *head_cls = nullptr;  // head.hip: left operands of the two dense optional outputs
     float *statsA = nullptr, *statsH = nullptr;  // [rows, D/64, 2] partial (sum, sumsq) of the rows of A / of bf16(H) in Xn

@@ -71,17 +71,20 @@ struct ch_trainer {
     // final-layer row pruning (as ch_encode): past the last attention only CLS + the Q concept tokens of
     // every image are carried, forward and backward -- the loss reads nothing else, so every other row's gradient is zero there
     bool prune_last = true;
-    bool fused_colsum = false;
-    int attn_rotate = 0;
-    bool bf16_bypass = false;
     int64_t hc_rows = 0;
     float *Hc = nullptr, *dHc = nullptr;
     bf16_t *dHcb = nullptr;
     bf16_t *dHb = nullptr, *dMb = nullptr, *tD = nullptr, *tD2 = nullptr, *tB = nullptr, *tM = nullptr, *tQKV = nullptr, *F1act = nullptr,
            *PATCH = nullptr, *XnDummy = nullptr;
     float *stDummy = nullptr;
-    float *ws_wgrad[TR_CHAINS] = {}, *ws_colsum[TR_CHAINS] = {}, *G[TR_CHAINS] = {}, *T[TR_CHAINS] = {}, *cu[TR_CHAINS] = {}, *ws_lncs[TR_CHAINS] = {},
+    float *ws_wgrad[TR_CHAINS] = {}, *ws_colsum[TR_CHAINS] = {}, *G[TR_CHAINS] = {}, *T[TR_CHAINS] = {}, *cu[TR_CHAINS] = {},
           *cd[TR_CHAINS] = {}, *dctx_sum[TR_CHAINS] = {};
+    // batched gradient assembly (model option "train_batched_grads"): the four chunk-slab sets of an adapter live side by side and are
+    // reduced by ONE launch into that adapter's slot of Gs / Ts / cus / cds; the gradients of all 2 L adapters are assembled by one
+    // launch pair at the end of the backward chain
+    bool batched_grads = true;
+    float *ws_wgradT[TR_CHAINS] = {}, *ws_colsumD[TR_CHAINS] = {}, *Gs[TR_CHAINS] = {}, *Ts[TR_CHAINS] = {}, *cus[TR_CHAINS] = {},
+          *cds[TR_CHAINS] = {}, *ws_ag[TR_CHAINS] = {};
     bool forward_done = false;
     bool attn_all_layers = false;   // layout of the concept-attention tap, latched by ch_train_forward for the matching ch_train_backward
 };
@@ -275,7 +278,6 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, const float *dca
     // the loss reads only hash_features = H[:, -Q:, :] (models/arch/coop.py:484-486): dH is zero elsewhere
     if (int e = ch_scatter_concept_rows(dhf_all + (size_t)img0 * Q * D, B, prune ? nq : ntok, Q, D, dH, dHb, s)) return e;
 
-    bool have_cu = false;   // cu[ch] already holds colsum(dH) (by-product of the ln_bwd that produced dH)
     // gradient of the block output arrives in dH / dHb; leaves d(branch input) = dH + adapter path in dMb (bf16 only)
     auto adapter_bwd = [&](int l, int a) -> int {
         const AdWork &aw = t->ad[l * 2 + a];
@@ -286,11 +288,12 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, const float *dca
         const float *stin = R.st(a == 0 ? v.stA : v.stA2);
         const int64_t dalloc = dHb == dHcb ? t->hc_rows : ralloc;
         // up projection: weight-gradient products (unscaled) and dgrad
-        if (int e = ch_wgrad_tn(dHb, D, G, bpad, cur, dalloc, D, bpad, t->G[ch], t->ws_wgrad[ch], s)) return e;
+        const bool bg = t->batched_grads;
+        const int ai = l * 2 + a;
+        int nchunk[4] = {0, 0, 0, 0};   // G, cu, T, cd
+        if (int e = ch_wgrad_tn(dHb, D, G, bpad, cur, dalloc, D, bpad, t->G[ch], t->ws_wgrad[ch], s, bg ? &nchunk[0] : nullptr)) return e;
         // of the fp32 gradient: a bias gradient is a sum over rows that largely cancels, the bf16 copy costs 1e-1 relative there
-        // (the LayerNorm backward that wrote dH left the sums in cu as a by-product, except in front of the first adapter)
-        if (!have_cu)
-            if (int e = ch_colsum(dH, 1, D, cur, D, t->cu[ch], t->ws_colsum[ch], s)) return e;
+        if (int e = ch_colsum(dH, 1, D, cur, D, t->cu[ch], t->ws_colsum[ch], s, bg ? &nchunk[1] : nullptr)) return e;
         GemmCall g{bpad, D, dHb, aw.up_wT, zero, EPI_BIAS_DACT_GELU};   // dpre = s (dH W_up) o gelu'(pre), in the epilogue
         g.out = tB; g.ldo = bpad; g.aux = P; g.scale = ap.scale;
         if (int e = gemm(t, ch, cur, g, s, dalloc)) return e;
@@ -299,9 +302,17 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, const float *dca
         g = GemmCall{D, bpad, tB, aw.down_wgT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;
         if (int e = gemm(t, ch, cur, g, s)) return e;
-        if (int e = ch_ln_bwd(tD, in, stin, cur, D, 1e-5f, dH, nullptr, dMb, s, tD2, nullptr, nullptr, t->bf16_bypass ? dHb : nullptr)) return e;
-        if (int e = ch_wgrad_tn(tB, bpad, tD2, D, cur, ralloc, bpad, D, t->T[ch], t->ws_wgrad[ch], s)) return e;
-        if (int e = ch_colsum(tB, 0, bpad, cur, bpad, t->cd[ch], t->ws_colsum[ch], s)) return e;
+        if (int e = ch_ln_bwd(tD, in, stin, cur, D, 1e-5f, dH, nullptr, dMb, s, tD2)) return e;
+        if (int e = ch_wgrad_tn(tB, bpad, tD2, D, cur, ralloc, bpad, D, t->T[ch], bg ? t->ws_wgradT[ch] : t->ws_wgrad[ch], s, bg ? &nchunk[2] : nullptr))
+            return e;
+        if (int e = ch_colsum(tB, 0, bpad, cur, bpad, t->cd[ch], bg ? t->ws_colsumD[ch] : t->ws_colsum[ch], s, bg ? &nchunk[3] : nullptr)) return e;
+        if (bg) {
+            const ChReduceJob jobs[4] = {{t->ws_wgrad[ch], t->Gs[ch] + (size_t)ai * D * bpad, nchunk[0], D * bpad / 4},
+                                         {t->ws_colsum[ch], t->cus[ch] + (size_t)ai * D, nchunk[1], D / 4},
+                                         {t->ws_wgradT[ch], t->Ts[ch] + (size_t)ai * bpad * D, nchunk[2], bpad * D / 4},
+                                         {t->ws_colsumD[ch], t->cds[ch] + (size_t)ai * bpad, nchunk[3], bpad / 4}};
+            return ch_reduce_partials_multi(jobs, 4, s);
+        }
         return ch_adapter_grads(t->G[ch], t->cu[ch], t->T[ch], t->cd[ch], pbase, D, b, bpad, grads + (int64_t)(l * 2 + a) * t->ad_numel,
                                 t->ws_colsum[ch], s);
     };
@@ -317,10 +328,7 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, const float *dca
         g = GemmCall{D, M, tM, x.fc1_wgT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;
         if (int e = gemm(t, ch, cur, g, s)) return e;
-        if (int e = ch_ln_bwd(tD, R.d(v.Xn2), R.st(v.st2), cur, D, c.ln_eps, dH, dH, dHb, s, nullptr, t->fused_colsum ? t->cu[ch] : nullptr,
-                              t->ws_lncs[ch]))
-            return e;
-        have_cu = t->fused_colsum;
+        if (int e = ch_ln_bwd(tD, R.d(v.Xn2), R.st(v.st2), cur, D, c.ln_eps, dH, dH, dHb, s)) return e;
         // ---- x_mid = x_in + a + adapter_1(a),  a = out_proj(attention(qkv(LN1(x_in))))
         if (int e = adapter_bwd(l, 0)) return e;
         g = GemmCall{D, D, dMb, x.out_wT, zero, EPI_BIAS};
@@ -340,15 +348,15 @@ int backward_chain(ch_trainer *t, int ch, const float *dhf_all, const float *dca
         const float *dpext = !dcattn_all ? nullptr
                              : t->attn_all_layers ? dcattn_all + ((size_t)l * t->B + img0) * c.heads * Q * (ntok - Q - 1)
                              : l == L - 1 ? dcattn_all + (size_t)img0 * c.heads * Q * (ntok - Q - 1) : nullptr;
-        if (int e = ch_attention_bwd(R.d3(v.QKV), dctx, B, ntok, c.heads, tQKV, s, dpext, Q, t->attn_rotate)) return e;
+        if (int e = ch_attention_bwd(R.d3(v.QKV), dctx, B, ntok, c.heads, tQKV, s, dpext, Q)) return e;
         g = GemmCall{D, 3 * D, tQKV, x.qkv_wgT, zero, EPI_BIAS};
         g.out = tD; g.ldo = D;
         if (int e = gemm(t, ch, cur, g, s)) return e;
-        const bool more = l > 0 && t->fused_colsum;   // the next adapter (layer l - 1, MLP side) wants colsum(dH)
-        if (int e = ch_ln_bwd(tD, R.d(v.Xn1), R.st(v.st1), cur, D, c.ln_eps, dH, dH, dHb, s, nullptr, more ? t->cu[ch] : nullptr, t->ws_lncs[ch]))
-            return e;
-        have_cu = more;
+        if (int e = ch_ln_bwd(tD, R.d(v.Xn1), R.st(v.st1), cur, D, c.ln_eps, dH, dH, dHb, s)) return e;
     }
+    if (t->batched_grads)   // every adapter's reduced products are in their slots: one launch pair assembles all the gradients
+        if (int e = ch_adapter_grads(t->Gs[ch], t->cus[ch], t->Ts[ch], t->cds[ch], t->params, D, b, bpad, grads, t->ws_ag[ch], s, 2 * L, t->ad_numel))
+            return e;
     // ---- concept tokens: rows ntok-Q.. of every image are pre_layrnorm(ctx[q]) (models/arch/coop.py:470-472)
     return ch_concept_rows_sum(dH, B, ntok, Q, D, t->dctx_sum[ch], s);
 }
@@ -395,9 +403,7 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
     t->nchains = std::max(1, std::min(m->train_chains, TR_CHAINS));
     t->chain_min_rows = std::max<int64_t>(1, m->train_chain_min_rows);
     t->prune_last = m->train_prune_last;
-    t->fused_colsum = m->train_fused_colsum;
-    t->attn_rotate = m->train_attn_rotate ? 1 : 0;
-    t->bf16_bypass = m->train_bf16_bypass;
+    t->batched_grads = m->train_batched_grads;
     const int D = c.dim, L = c.layers, M = c.ffn, bpad = m->bpad, Q = c.ncontext;
     // region 0 holds a whole batch (one chain) or the first half (two chains); region 1 the second half
     const int half = (max_batch + 1) / 2;
@@ -467,7 +473,16 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
     for (int ch = 0; ch < t->nchains; ++ch) {
         t->ws_wgrad[ch] = (float *)talloc(t, sizeof(float) * std::max(ch_wgrad_ws_floats(max_rows, D, bpad), ch_wgrad_ws_floats(max_rows, bpad, D)), ok);
         t->ws_colsum[ch] = (float *)talloc(t, sizeof(float) * ch_colsum_ws_floats(std::max(D, bpad)), ok);
-        t->ws_lncs[ch] = (float *)talloc(t, sizeof(float) * ch_ln_bwd_colsum_ws_floats(max_rows, D), ok);
+        if (t->batched_grads) {
+            const size_t nad = (size_t)L * 2;
+            t->ws_wgradT[ch] = (float *)talloc(t, sizeof(float) * std::max(ch_wgrad_ws_floats(max_rows, D, bpad), ch_wgrad_ws_floats(max_rows, bpad, D)), ok);
+            t->ws_colsumD[ch] = (float *)talloc(t, sizeof(float) * ch_colsum_ws_floats(std::max(D, bpad)), ok);
+            t->Gs[ch] = (float *)talloc(t, sizeof(float) * nad * D * bpad, ok);
+            t->Ts[ch] = (float *)talloc(t, sizeof(float) * nad * bpad * D, ok);
+            t->cus[ch] = (float *)talloc(t, sizeof(float) * nad * D, ok);
+            t->cds[ch] = (float *)talloc(t, sizeof(float) * nad * bpad, ok);
+            t->ws_ag[ch] = (float *)talloc(t, sizeof(float) * nad * 256, ok);
+        }
         t->G[ch] = (float *)talloc(t, sizeof(float) * (size_t)D * bpad, ok);
         t->T[ch] = (float *)talloc(t, sizeof(float) * (size_t)bpad * D, ok);
         t->cu[ch] = (float *)talloc(t, sizeof(float) * D, ok);

@@ -128,83 +128,42 @@ __global__ __launch_bounds__(256) void normalize_kernel(const bf16_t *__restrict
 // ---- LayerNorm backward of a row: result = dres_in + rstd * (dyg - mean(dyg) - x_hat * mean(dyg * x_hat)) ---------------------
 // dres_in: the gradient that bypasses the LayerNorm'd branch (the residual path); the result goes to dres_out (fp32, may alias
 // dres_in, may be null) and / or out_b (bf16 GEMM operand, may be null)
-// CS: the column sums of the RESULT (the bias gradient of the adapter that consumes it next: cu = colsum(dH), train.hip) are a by-product
-// -- a wave walks LNB_RPW rows (row = 32 * block + wave + 4 * i, so the four waves stay on adjacent rows) and keeps the running sum of
-// its rows' results in 2 * npass registers; the four waves' sums are added in wave order through LDS -> colsum_partial[block][D]
-// (fixed association; reduce_partials finishes it).  Replaces a separate 158 MB read of dH per adapter (colsum_kernel<fp32>, 27 us).
-constexpr int LNB_RPW = 8;
-template <bool CS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t *__restrict__ dyg, const bf16_t *__restrict__ x,
                                                      const float *__restrict__ stats, int64_t rows, int D, float eps,
                                                      const float *dres_in, float *dres_out, bf16_t *__restrict__ out_b,
-                                                     bf16_t *__restrict__ xhat_out, float *__restrict__ colsum_partial,
-                                                     const bf16_t *__restrict__ dres_in_b) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+                                                     bf16_t *__restrict__ xhat_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float mean, rstd;
+    row_mean_rstd(stats + row * (D >> 6) * 2, D, eps, lane, mean, rstd);
     const int npass = D >> 7;
-    float2 cs[MAXP];
-    if constexpr (CS) {
+    float2 g[MAXP], xh[MAXP];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXP; ++j) cs[j] = make_float2(0.f, 0.f);
-    }
-#pragma unroll 2
-    for (int it = 0; it < (CS ? LNB_RPW : 1); ++it) {
-        const int64_t row = CS ? (int64_t)blockIdx.x * (4 * LNB_RPW) + it * 4 + wid : (int64_t)blockIdx.x * 4 + wid;
-        if (row >= rows) break;
-        float mean, rstd;
-        row_mean_rstd(stats + row * (D >> 6) * 2, D, eps, lane, mean, rstd);
-        float2 g[MAXP], xh[MAXP];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < MAXP; ++j)
-            if (j < npass) {
-                const uint32_t ug = *(const uint32_t *)(dyg + row * D + (j * 64 + lane) * 2);
-                const uint32_t ux = *(const uint32_t *)(x + row * D + (j * 64 + lane) * 2);
-                g[j] = make_float2(bf2f((bf16_t)(ug & 0xffff)), bf2f((bf16_t)(ug >> 16)));
-                xh[j] = make_float2((bf2f((bf16_t)(ux & 0xffff)) - mean) * rstd, (bf2f((bf16_t)(ux >> 16)) - mean) * rstd);
-                // x_hat as a bf16 GEMM operand (the adapter's weight-gradient product consumes it): a by-product here, a separate
-                // read of x otherwise (normalize_kernel)
-                if (xhat_out) *(uint32_t *)(xhat_out + row * D + (j * 64 + lane) * 2) = pack_bf16x2(xh[j].x, xh[j].y);
-                s1 += g[j].x + g[j].y;
-                s2 += g[j].x * xh[j].x + g[j].y * xh[j].y;
-            }
-        s1 = wave_sum(s1) / (float)D;
-        s2 = wave_sum(s2) / (float)D;
-#pragma unroll
-        for (int j = 0; j < MAXP; ++j)
-            if (j < npass) {
-                float2 d;
-                if (dres_in_b) {   // the bypass gradient from its bf16 copy (2 instead of 4 bytes per element; the result is bf16 anyway)
-                    const uint32_t ub = *(const uint32_t *)(dres_in_b + row * D + (j * 64 + lane) * 2);
-                    d = make_float2(bf2f((bf16_t)(ub & 0xffff)), bf2f((bf16_t)(ub >> 16)));
-                } else {
-                    d = *(const float2 *)(dres_in + row * D + (j * 64 + lane) * 2);   // (non-temporal here: measured, no gain)
-                }
-                d.x += rstd * (g[j].x - s1 - xh[j].x * s2);
-                d.y += rstd * (g[j].y - s1 - xh[j].y * s2);
-                if (dres_out) *(float2 *)(dres_out + row * D + (j * 64 + lane) * 2) = d;
-                if (out_b) *(uint32_t *)(out_b + row * D + (j * 64 + lane) * 2) = pack_bf16x2(d.x, d.y);
-                if constexpr (CS) {
-                    cs[j].x += d.x;
-                    cs[j].y += d.y;
-                }
-            }
-    }
-    if constexpr (CS) {
-        __shared__ float2 red[4][MAXP * 64];
-#pragma unroll
-        for (int j = 0; j < MAXP; ++j)
-            if (j < npass) red[wid][j * 64 + lane] = cs[j];
-        __syncthreads();
-        for (int i = threadIdx.x; i < npass * 64; i += 256) {
-            float2 t = red[0][i];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                t.x += red[w][i].x;
-                t.y += red[w][i].y;
-            }
-            *(float2 *)(colsum_partial + (size_t)blockIdx.x * D + i * 2) = t;
+    for (int j = 0; j < MAXP; ++j)
+        if (j < npass) {
+            const uint32_t ug = *(const uint32_t *)(dyg + row * D + (j * 64 + lane) * 2);
+            const uint32_t ux = *(const uint32_t *)(x + row * D + (j * 64 + lane) * 2);
+            g[j] = make_float2(bf2f((bf16_t)(ug & 0xffff)), bf2f((bf16_t)(ug >> 16)));
+            xh[j] = make_float2((bf2f((bf16_t)(ux & 0xffff)) - mean) * rstd, (bf2f((bf16_t)(ux >> 16)) - mean) * rstd);
+            // x_hat as a bf16 GEMM operand (the adapter's weight-gradient product consumes it): a by-product here, a separate
+            // read of x otherwise (normalize_kernel)
+            if (xhat_out) *(uint32_t *)(xhat_out + row * D + (j * 64 + lane) * 2) = pack_bf16x2(xh[j].x, xh[j].y);
+            s1 += g[j].x + g[j].y;
+            s2 += g[j].x * xh[j].x + g[j].y * xh[j].y;
         }
-    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j)
+        if (j < npass) {
+            float2 d = *(const float2 *)(dres_in + row * D + (j * 64 + lane) * 2);   // (non-temporal here: measured, no gain)
+            d.x += rstd * (g[j].x - s1 - xh[j].x * s2);
+            d.y += rstd * (g[j].y - s1 - xh[j].y * s2);
+            if (dres_out) *(float2 *)(dres_out + row * D + (j * 64 + lane) * 2) = d;
+            if (out_b) *(uint32_t *)(out_b + row * D + (j * 64 + lane) * 2) = pack_bf16x2(d.x, d.y);
+        }
 }
 
 // ---- weight gradient: out[n][k] = sum_m A[m][n] * B[m][k] ---------------------------------------------------------------------
@@ -332,22 +291,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const bf16_t *__restri
 // out[i] = sum over chunks of partial[c][i]; n4 = elements / 4.  256 threads = 32 float4 columns x 8 chunk lanes: lane l sums
 // chunks l, l + 8, ... in order, the 8 lane sums are added in lane order -- a fixed association, so run-to-run identical -- and the
 // serial chain is chunks / 8 loads instead of chunks (the one-block column-sum reduction was a 15 us latency chain of 101 loads)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int nchunks, int64_t n4,
-                                                              float *__restrict__ out, int per_group = 0) {
+__device__ __forceinline__ void reduce_partials_body(const float *__restrict__ partial, int nchunks, int64_t n4, float *__restrict__ out,
+                                                     int bx) {
     __shared__ f32x4 red[8][32];
     const int col = threadIdx.x & 31, cl = threadIdx.x >> 5;
-    const int64_t i = (int64_t)blockIdx.x * 32 + col;
-    // per_group > 0: block row y sums chunks [y * per_group, (y + 1) * per_group) into out[y] (first level of a two-level reduction
-    // over many chunks: six workgroups walking 1,600 chunks would be a 200-load chain each)
-    int c0 = 0, c1 = nchunks;
-    if (per_group > 0) {
-        c0 = blockIdx.y * per_group;
-        c1 = min(nchunks, c0 + per_group);
-        out += (size_t)blockIdx.y * n4 * 4;
-    }
+    const int64_t i = (int64_t)bx * 32 + col;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n4)
-        for (int c = c0 + cl; c < c1; c += 8) s += *(const f32x4 *)(partial + ((size_t)c * n4 + i) * 4);
+        for (int c = cl; c < nchunks; c += 8) s += *(const f32x4 *)(partial + ((size_t)c * n4 + i) * 4);
     red[cl][col] = s;
     __syncthreads();
     if (cl == 0 && i < n4) {
@@ -356,6 +307,21 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
         for (int j = 1; j < 8; ++j) t += red[j][col];
         *(f32x4 *)(out + i * 4) = t;
     }
+}
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int nchunks, int64_t n4,
+                                                              float *__restrict__ out) {
+    reduce_partials_body(partial, nchunks, n4, out, blockIdx.x);
+}
+// up to four reductions in ONE launch (an adapter's two weight-gradient products and two column sums: four 5 us launches otherwise,
+// 96 per step -- at batch 32 the step is a chain of ~600 dependent launches and each tiny one costs its start-up latency)
+struct ReduceJobsArg {
+    ChReduceJob job[4];
+    int first_block[5];
+};
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceJobsArg a) {
+    int j = 0;
+    while (j < 3 && (int)blockIdx.x >= a.first_block[j + 1]) ++j;
+    reduce_partials_body(a.job[j].partial, a.job[j].nchunks, a.job[j].n4, a.job[j].out, blockIdx.x - a.first_block[j]);
 }
 
 // column sums of a [rows, N] matrix over a chunk of rows -> partial[chunk][N].  256 threads = 32 column groups x 8 row lanes; a thread
@@ -516,7 +482,10 @@ constexpr int AG_BLOCKS = 256;
 __global__ __launch_bounds__(256) void adapter_grads_elem_kernel(const float *__restrict__ G, const float *__restrict__ cu,
                                                                  const float *__restrict__ T, const float *__restrict__ cd,
                                                                  const float *__restrict__ P, int D, int b, int bpad, float *__restrict__ gr,
-                                                                 float *__restrict__ part) {
+                                                                 float *__restrict__ part, int64_t pstride) {
+    // blockIdx.y: the adapter (slot arrays: G / T stride D * bpad, cu D, cd bpad, parameters and gradients pstride, partials AG_BLOCKS)
+    G += (size_t)blockIdx.y * D * bpad, T += (size_t)blockIdx.y * bpad * D, cu += (size_t)blockIdx.y * D, cd += (size_t)blockIdx.y * bpad;
+    P += blockIdx.y * pstride, gr += blockIdx.y * pstride, part += blockIdx.y * AG_BLOCKS;
     const float *ln_w = P, *ln_b = P + D, *down_w = P + 2 * D, *up_w = down_w + (size_t)b * D + b, *up_b = up_w + (size_t)D * b;
     const float s = up_b[D];
     float *g_down_w = gr + 2 * D, *g_down_b = g_down_w + (size_t)b * D, *g_up_w = g_down_b + b, *g_up_b = g_up_w + (size_t)D * b;
@@ -550,8 +519,10 @@ __global__ __launch_bounds__(256) void adapter_grads_elem_kernel(const float *__
 // (6 dependent loads per thread for b = 384; with 64 columns x 16 lanes it was a 24-load chain on 13 blocks):
 // dgamma[k] = sum_j T[j][k] W_dn[j][k], dbeta[k] = sum_j cd[j] W_dn[j][k]
 __global__ __launch_bounds__(1024) void adapter_grads_red_kernel(const float *__restrict__ T, const float *__restrict__ cd,
-                                                                 const float *__restrict__ P, int D, int b, float *__restrict__ gr,
-                                                                 const float *__restrict__ part) {
+                                                                 const float *__restrict__ P, int D, int b, int bpad, float *__restrict__ gr,
+                                                                 const float *__restrict__ part, int64_t pstride) {
+    T += (size_t)blockIdx.y * bpad * D, cd += (size_t)blockIdx.y * bpad;
+    P += blockIdx.y * pstride, gr += blockIdx.y * pstride, part += blockIdx.y * AG_BLOCKS;
     __shared__ float ra[64][17], rc[64][17];
     if (blockIdx.x == 0) {
         __shared__ float red[256];
@@ -718,29 +689,11 @@ int ch_normalize_bf16(const bf16_t *x, const float *stats, int64_t rows, int D, 
     CH_LAUNCH_CHECK();
     return 0;
 }
-size_t ch_ln_bwd_colsum_ws_floats(int64_t rows, int D) {
-    const int64_t blocks = ceil_div64(rows, 4 * LNB_RPW);
-    return (size_t)(blocks + ceil_div64(blocks, 32)) * D;
-}
 int ch_ln_bwd(const bf16_t *dyg, const bf16_t *x, const float *stats, int64_t rows, int D, float eps, const float *dres_in,
-              float *dres_out, bf16_t *out_b, hipStream_t s, bf16_t *xhat_out, float *colsum_out, float *colsum_ws, const bf16_t *dres_in_b) {
+              float *dres_out, bf16_t *out_b, hipStream_t s, bf16_t *xhat_out) {
     CH_REQUIRE(D % 128 == 0 && D <= 128 * MAXP, "ln_bwd: D must be a multiple of 128, <= 1280");
-    if (!colsum_out) {
-        hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, s, dyg, x, stats, rows, D, eps, dres_in,
-                           dres_out, out_b, xhat_out, nullptr, dres_in_b);
-        CH_LAUNCH_CHECK();
-        return 0;
-    }
-    CH_REQUIRE(colsum_ws != nullptr, "ln_bwd: the column-sum by-product needs its workspace");
-    const int blocks = (int)ceil_div64(rows, 4 * LNB_RPW), groups = (blocks + 31) / 32;
-    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dyg, x, stats, rows, D, eps, dres_in, dres_out, out_b, xhat_out,
-                       colsum_ws, dres_in_b);
-    CH_LAUNCH_CHECK();
-    const int64_t n4 = D / 4;
-    float *level1 = colsum_ws + (size_t)blocks * D;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(n4, 32), groups), dim3(256), 0, s, colsum_ws, blocks, n4, level1, 32);
-    CH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(n4, 32)), dim3(256), 0, s, level1, groups, n4, colsum_out, 0);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, s, dyg, x, stats, rows, D, eps, dres_in, dres_out,
+                       out_b, xhat_out);
     CH_LAUNCH_CHECK();
     return 0;
 }
@@ -762,7 +715,7 @@ int ch_wgrad_chunks(int64_t rows, int N, int K) {
 size_t ch_wgrad_ws_floats(int64_t rows, int N, int K) { return (size_t)ch_wgrad_chunks(rows, N, K) * N * K; }
 
 int ch_wgrad_tn(bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int64_t rows_alloc, int N, int K, float *out,
-                float *ws, hipStream_t s) {
+                float *ws, hipStream_t s, int *chunks_out) {
     CH_REQUIRE(N % WG_TILE == 0 && K % WG_TILE == 0, "wgrad: N and K must be multiples of 128");
     CH_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "wgrad: leading dimensions must be multiples of 8");
     const int chunks = ch_wgrad_chunks(rows, N, K);
@@ -777,12 +730,16 @@ int ch_wgrad_tn(bf16_t *A, int lda, const bf16_t *B, int ldb, int64_t rows, int6
     hipLaunchKernelGGL(wgrad_tn_kernel, dim3(8 * ((chunks + 7) / 8) * tiles), dim3(256), 0, s, A, lda, B, ldb, N, K, spc, total_steps, chunks,
                        ws);
     CH_LAUNCH_CHECK();
+    if (chunks_out) {   // the caller reduces the slabs itself (ch_reduce_partials_multi)
+        *chunks_out = chunks;
+        return 0;
+    }
     const int64_t n4 = (int64_t)N * K / 4;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(n4, 32)), dim3(256), 0, s, ws, chunks, n4, out, 0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(n4, 32)), dim3(256), 0, s, ws, chunks, n4, out);
     CH_LAUNCH_CHECK();
     return 0;
 }
-int ch_colsum(const void *A, int is_f32, int lda, int64_t rows, int N, float *out, float *ws, hipStream_t s) {
+int ch_colsum(const void *A, int is_f32, int lda, int64_t rows, int N, float *out, float *ws, hipStream_t s, int *chunks_out) {
     CH_REQUIRE(N % 8 == 0 && lda % 8 == 0, "colsum: N and the leading dimension must be multiples of 8");
     const int chunks = (int)std::min<int64_t>(128, ceil_div64(rows, 256));
     const int chunk_rows = (int)ceil_div64(rows, chunks);
@@ -791,7 +748,11 @@ int ch_colsum(const void *A, int is_f32, int lda, int64_t rows, int N, float *ou
     else
         hipLaunchKernelGGL(colsum_kernel<false>, dim3((N / 8 + 31) / 32, chunks), dim3(256), 0, s, A, lda, rows, N, chunk_rows, ws);
     CH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(N / 4, 32)), dim3(256), 0, s, ws, chunks, (int64_t)N / 4, out, 0);
+    if (chunks_out) {
+        *chunks_out = chunks;
+        return 0;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div64(N / 4, 32)), dim3(256), 0, s, ws, chunks, (int64_t)N / 4, out);
     CH_LAUNCH_CHECK();
     return 0;
 }
@@ -823,10 +784,27 @@ int ch_adapter_refresh(const float *params, int64_t stride, int nad, int D, int 
     return 0;
 }
 int ch_adapter_grads(const float *G, const float *cu, const float *T, const float *cd, const float *params, int D, int b, int bpad,
-                     float *grads, float *ws, hipStream_t s) {
-    hipLaunchKernelGGL(adapter_grads_elem_kernel, dim3(AG_BLOCKS), dim3(256), 0, s, G, cu, T, cd, params, D, b, bpad, grads, ws);
+                     float *grads, float *ws, hipStream_t s, int nad, int64_t stride) {
+    hipLaunchKernelGGL(adapter_grads_elem_kernel, dim3(AG_BLOCKS, nad), dim3(256), 0, s, G, cu, T, cd, params, D, b, bpad, grads, ws, stride);
     CH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(adapter_grads_red_kernel, dim3(1 + (D + 15) / 16), dim3(1024), 0, s, T, cd, params, D, b, grads, ws);
+    hipLaunchKernelGGL(adapter_grads_red_kernel, dim3(1 + (D + 15) / 16, nad), dim3(1024), 0, s, T, cd, params, D, b, bpad, grads, ws, stride);
+    CH_LAUNCH_CHECK();
+    return 0;
+}
+int ch_reduce_partials_multi(const ChReduceJob *jobs, int njobs, hipStream_t s) {
+    CH_REQUIRE(njobs >= 1 && njobs <= 4, "reduce_partials_multi: 1..4 jobs");
+    ReduceJobsArg a{};
+    int blocks = 0;
+    for (int j = 0; j < 4; ++j) {
+        a.first_block[j] = blocks;
+        if (j < njobs) {
+            a.job[j] = jobs[j];
+            blocks += (int)ceil_div64(jobs[j].n4, 32);
+        }
+    }
+    a.first_block[4] = blocks;
+    for (int j = njobs; j < 4; ++j) a.first_block[j] = blocks;
+    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, s, a);
     CH_LAUNCH_CHECK();
     return 0;
 }

@@ -98,7 +98,7 @@ size_t ch_model_device_bytes(const ch_model *m);
  *   "splitk"        0/1    split-K tail of the 256x256 GEMM (default 0; allocates 64 MiB per chain on first use)
  *   "serpentine"    0/1    alternate the row direction of consecutive launches (default 0)
  *   "small_kernel", "pp_sched", "fused_adapter", "gemm_rows", "wide_kernel"  experiment kernels: non-zero values need the experiments build
- *   "train_chains" 1..2, "train_chain_min_rows", "train_prune_last" 0/1, "train_fused_colsum" 0/1, "train_attn_rotate" 0/1, "train_bf16_bypass" 0/1   read by ch_trainer_create from the model it is created on */
+ *   "train_chains" 1..2, "train_chain_min_rows", "train_prune_last" 0/1, "train_batched_grads" 0/1   read by ch_trainer_create from the model it is created on */
 int ch_model_set_option(ch_model *m, const char *key, int64_t value);
 int ch_model_get_option(ch_model *m, const char *key, int64_t *value);
 
