@@ -544,9 +544,12 @@ def loader_block(torch, np, enc, B, dev, nimg, value):
                "host_cpu_quota": budget, "host_cores_used": min(16, budget), "torch_cpu_threads": torch.get_num_threads(), "generate_s": round(gen_s, 1)}
         log(f"[bench] loader: {nimg} JPEG files ({out['mean_file_kb']} KiB mean) in {gen_s:.1f} s; {cores} host cores")
 
-        def run(mode, n, epochs):
-            ds = HashingDataset(root, "test.txt", transform=chain, target_transform=OneHot(NCLASS), gpu_preprocess=mode == "gpu_preprocess",
-                                gpu_decode=mode == "gpu_decode")
+        train_chain = [T.RandomResizedCrop(224, interpolation=T.interpolation("bicubic")), T.RandomHorizontalFlip(), T.ToTensor(),
+                       T.normalize_transform(3)]
+
+        def run(mode, n, epochs, train=False):
+            ds = HashingDataset(root, "test.txt", transform=train_chain if train else chain, target_transform=OneHot(NCLASS),
+                                gpu_preprocess=mode == "gpu_preprocess", gpu_decode=mode == "gpu_decode")
             ds.items = ds.items[:n]
             dl = engine.dataloader(ds, B, shuffle=False, drop_last=False)
             rates = []
@@ -556,10 +559,11 @@ def loader_block(torch, np, enc, B, dev, nimg, value):
                 it = prefetch_decoded(dl, dec) if mode == "gpu_decode" else dl      # host half of the decode one or two batches ahead
                 for image, labels, index in it:
                     if mode == "gpu_decode":
-                        image = pre(*image.finish())
+                        boxes, flips = image.boxes, image.flips            # training chain: the workers' draws ride along
+                        image = pre(*image.finish(), boxes=boxes, flips=flips)
                     elif mode == "gpu_preprocess":
                         image = image.to(dev, non_blocking=True)
-                        image = pre(image.pixels, image.sizes)
+                        image = pre(image.pixels, image.sizes, boxes=image.boxes, flips=image.flips)
                     else:
                         image = image.to(dev, non_blocking=True)
                     enc.encode(image, want=("codes", "packed"))
@@ -580,6 +584,17 @@ def loader_block(torch, np, enc, B, dev, nimg, value):
             if mode == "gpu_decode":
                 out[mode].update(decode_threads=dec.threads, pil_fallback=dec.stats["pil_fallback"])
             log(f"[bench] loader {mode}: {rates[1]:.0f} images/s (first epoch {rates[0]:.0f})")
+        # the TRAINING transforms of the same configs (RandomResizedCrop(224, bicubic) -> RandomHorizontalFlip -> ToTensor -> normalize,
+        # configs/dataset/cub200.yaml:13-23): the reference's arrangement runs them on PIL images in the workers; the GPU path lets the
+        # workers draw the crop box and the flip (same random calls) and resizes the box on the GPU.  Same consumer as above (ch_encode),
+        # so the number is the FEED rate an arrangement can sustain; the training step itself takes `train_step` ms per batch.
+        out["train_transforms"] = {}
+        for mode in ("cpu_loader", "gpu_decode"):
+            run(mode, max(B, nimg // 4), 1, train=True)
+            rates, workers = run(mode, nimg, 2, train=True)
+            out["train_transforms"][mode] = {"images_per_s": round(rates[1], 1), "first_epoch_images_per_s": round(rates[0], 1),
+                                             "loader_workers": workers}
+            log(f"[bench] loader (training transforms) {mode}: {rates[1]:.0f} images/s (first epoch {rates[0]:.0f})")
         # the decoder split alone, files already in memory: host entropy decode -> H2D -> reconstruct (no loader, no encode)
         files = [np.fromfile(os.path.join(root, "img", f"{i}.jpg"), dtype=np.uint8) for i in range(B)]
         dec.decode(files)

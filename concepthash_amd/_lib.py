@@ -13,7 +13,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconcepthash_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ModelConfig(Structure):
@@ -24,7 +24,7 @@ class ModelConfig(Structure):
 
 class ImageDesc(Structure):
     _fields_ = [("src_offset", c_int64), ("tmp_offset", c_int64)] + \
-               [(n, c_int32) for n in ("h", "w", "nh", "nw", "top", "left", "row0", "nrows")]
+               [(n, c_int32) for n in ("h", "w", "nh", "nw", "top", "left", "row0", "nrows", "stride", "flip")]
 
 
 class JpegDesc(Structure):

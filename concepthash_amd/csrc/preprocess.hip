@@ -1,5 +1,7 @@
 // Image pre-processing on the GPU: uint8 HWC images of arbitrary size -> Resize(shorter side, bicubic) -> CenterCrop -> /255 ->
-// (x - mean) / std -> the NCHW batch the encoder reads (bf16 or fp32).
+// (x - mean) / std -> the NCHW batch the encoder reads (bf16 or fp32); and, with a crop box and a flip flag per image, the training
+// chain RandomResizedCrop(bicubic) -> RandomHorizontalFlip -> ToTensor -> normalize (configs/dataset/cub200.yaml:13-23; the random
+// draws stay on the host, in the loader workers, so the random stream is the CPU chain's).
 //
 // Replaces, for the evaluation loop, the CPU-worker transform chain of the reference's dataset configs
 // (configs/dataset/cub200.yaml:31-47: torchvision Resize(256, bicubic) -> CenterCrop(224) -> ToTensor -> normalize; loader
@@ -73,8 +75,9 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *__restrict
     const uint8_t *src = pixels + d.src_offset;
     uint8_t *dst = tmp + d.tmp_offset;
     const int r_end = min(r_begin + ROWS_PER_BLOCK, d.nrows);
+    const int stride = d.stride ? d.stride : d.w;   // a crop box inside a wider image (training transforms)
     for (int r = r_begin; r < r_end; ++r) {
-        const uint8_t *row = src + ((size_t)(d.row0 + r) * d.w + b.x) * 3;
+        const uint8_t *row = src + ((size_t)(d.row0 + r) * stride + b.x) * 3;
         int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
         for (int t = 0; t < b.y; ++t) {
             const int k = kk[t * 256 + x];
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t *__restrict
     const float v1 = ((float)clip8(a1) / 255.0f - m1) / s1;
     const float v2 = ((float)clip8(a2) / 255.0f - m2) / s2;
     const size_t plane = (size_t)crop * crop;
-    OUT *o = out + (size_t)blockIdx.x * 3 * plane + (size_t)y * crop + x;
+    OUT *o = out + (size_t)blockIdx.x * 3 * plane + (size_t)y * crop + (d.flip ? crop - 1 - x : x);
     if constexpr (sizeof(OUT) == 2) {
         o[0] = f2bf(v0);
         o[plane] = f2bf(v1);

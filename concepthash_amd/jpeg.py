@@ -207,6 +207,11 @@ class GpuJpegDecoder:
         return StagedJpegBatch(self, slot, desc, fallback, totals, sizes, fb)
 
     def host_stage(self, files) -> "StagedJpegBatch":
+        staged = self._host_stage(files)
+        staged.boxes, staged.flips = getattr(files, "boxes", None), getattr(files, "flips", None)
+        return staged
+
+    def _host_stage(self, files) -> "StagedJpegBatch":
         """HOST half: headers, PIL for the files outside the subset, offsets, Huffman decode into a pinned ring slot.  No GPU call except
         waiting for the slot's previous copies: may run on a background thread one or two batches ahead of `device_stage`
         (`prefetch_decoded`); the ring holds `_RING` slots, so at most `_RING - 1` staged batches may wait for their device stage.
@@ -312,6 +317,7 @@ class StagedJpegBatch:
     def __init__(self, decoder, slot, desc, fallback, totals, sizes, fb):
         self.decoder, self.slot, self.desc, self.fallback, self.totals, self.sizes, self.fb = decoder, slot, desc, fallback, totals, sizes, fb
         self.staged = True
+        self.boxes = self.flips = None      # a training dataset's crop boxes / flips ride along (utils.datasets.RawJpegBatch)
 
     def size(self, dim=0):
         if dim != 0:

@@ -58,7 +58,8 @@ class GpuPreprocess:
         self._ring_pos = 0
 
     _DESC_DTYPE = np.dtype([("src_offset", "<i8"), ("tmp_offset", "<i8"), ("h", "<i4"), ("w", "<i4"), ("nh", "<i4"), ("nw", "<i4"),
-                            ("top", "<i4"), ("left", "<i4"), ("row0", "<i4"), ("nrows", "<i4")])   # == ch_image_desc / _lib.ImageDesc
+                            ("top", "<i4"), ("left", "<i4"), ("row0", "<i4"), ("nrows", "<i4"), ("stride", "<i4"),
+                            ("flip", "<i4")])   # == ch_image_desc / _lib.ImageDesc
     _RING = 8          # pinned descriptor staging buffers in flight
 
     def _geometry(self, h: int, w: int):
@@ -91,6 +92,33 @@ class GpuPreprocess:
             desc[name] = geo[:, j]
         return desc, int(src.sum()), int(tmp.sum()), int(max(1, geo[:, 5].max())) if B else 1
 
+    def plan_boxes(self, sizes: Sequence[tuple], boxes, flips=None):
+        """The training chain (configs/dataset/cub200.yaml:13-23): RandomResizedCrop(crop, bicubic) -> RandomHorizontalFlip.  boxes:
+        [(top, left, box_h, box_w)] drawn on the host (utils.transforms.RandomResizedCrop.get_params, the reference's random stream),
+        flips: [bool].  PIL crops the box and resizes it as an image of its own to crop x crop, so the descriptor describes the box:
+        (h, w) = its size, src_offset = its first pixel, stride = the full image's width, nothing cropped afterwards."""
+        B = len(sizes)
+        hw = np.asarray(sizes, dtype=np.int64).reshape(B, 2)
+        bx = np.asarray(boxes, dtype=np.int64).reshape(B, 4)
+        if B and ((bx[:, 0] < 0).any() or (bx[:, 1] < 0).any() or (bx[:, 2] < 1).any() or (bx[:, 3] < 1).any()
+                  or (bx[:, 0] + bx[:, 2] > hw[:, 0]).any() or (bx[:, 1] + bx[:, 3] > hw[:, 1]).any()):
+            raise ValueError("a crop box leaves its image")
+        for n_in in set(bx[:, 2].tolist()) | set(bx[:, 3].tolist()):
+            if 2 * math.ceil(2.0 * max(n_in / self.crop, 1.0)) + 1 > self.max_taps:
+                raise ValueError(f"a {n_in}-pixel box side needs more than {self.max_taps} filter taps (down-scaling > ~15x)")
+        desc = np.zeros(B, dtype=self._DESC_DTYPE)
+        src = hw[:, 0] * hw[:, 1] * 3
+        tmp = bx[:, 2] * self.crop * 3                      # every source row of the box feeds the vertical pass
+        desc["src_offset"] = np.cumsum(src) - src + (bx[:, 0] * hw[:, 1] + bx[:, 1]) * 3
+        desc["tmp_offset"] = np.cumsum(tmp) - tmp
+        desc["h"], desc["w"] = bx[:, 2], bx[:, 3]
+        desc["nh"] = desc["nw"] = self.crop
+        desc["nrows"] = bx[:, 2]
+        desc["stride"] = hw[:, 1]
+        if flips is not None:
+            desc["flip"] = np.asarray(flips, dtype=np.int64).reshape(B) != 0
+        return desc, int(src.sum()), int(tmp.sum()), int(max(1, bx[:, 2].max())) if B else 1
+
     def _stage(self, desc: np.ndarray, device, stream=None) -> torch.Tensor:
         """descriptors -> device without synchronising: through a ring of pinned host buffers and a non-blocking copy (a copy from
         pageable memory would wait for everything queued on the stream -- once per batch, in the evaluator loop).  The copy and the
@@ -113,15 +141,16 @@ class GpuPreprocess:
         slot["event"] = ev
         return ddev
 
-    def __call__(self, pixels: torch.Tensor, sizes: Sequence[tuple], stream=None) -> torch.Tensor:
-        """pixels: uint8 device tensor, the images' HWC bytes back to back (image i is [h_i, w_i, 3]); sizes: [(h, w)]."""
+    def __call__(self, pixels: torch.Tensor, sizes: Sequence[tuple], stream=None, boxes=None, flips=None) -> torch.Tensor:
+        """pixels: uint8 device tensor, the images' HWC bytes back to back (image i is [h_i, w_i, 3]); sizes: [(h, w)].
+        boxes / flips given: the training chain (`plan_boxes`) instead of Resize -> CenterCrop."""
         if pixels.dtype != torch.uint8 or not pixels.is_cuda:
             raise TypeError("pixels must be a uint8 GPU tensor (decoded RGB bytes, images concatenated)")
         B = len(sizes)
         out = torch.empty(B, 3, self.crop, self.crop, dtype=self.out_dtype, device=pixels.device)
         if B == 0:
             return out
-        desc, nbytes, ws_bytes, max_rows = self.plan(sizes)
+        desc, nbytes, ws_bytes, max_rows = self.plan(sizes) if boxes is None else self.plan_boxes(sizes, boxes, flips)
         if pixels.numel() != nbytes:
             raise ValueError(f"pixels holds {pixels.numel()} bytes, the sizes add up to {nbytes}")
         pixels = pixels.contiguous()

@@ -29,7 +29,7 @@ extern "C" {
 /* 2 (round 4): ch_encode / ch_train_forward take the layout of the concept-attention tap as an argument (ch_model_set_concept_attn_layers
  * is gone), ch_model_profile_end takes the capacity of the caller's arrays, ch_model_set_option / ch_model_get_option replace every
  * environment variable the library used to read. */
-#define CH_ABI_VERSION 2
+#define CH_ABI_VERSION 3
 
 typedef struct ch_model ch_model; /* opaque: weights (bf16/fp32, device) + activation workspace */
 
@@ -200,11 +200,18 @@ double ch_model_flops_per_image(const ch_model *m);
  *   nw, nh      size after Resize(size): shorter side = size, the other int(size * long / short);
  *   left, top   CenterCrop origin int(round((n - crop) / 2.0)) (round-half-even);
  *   row0, nrows source rows the vertical pass needs for the crop's rows; tmp_offset: byte offset of this image's
- *               [nrows, crop, 3] intermediate in the workspace. */
+ *               [nrows, crop, 3] intermediate in the workspace.
+ * The training transforms of the same configs (configs/dataset/cub200.yaml:13-23: RandomResizedCrop(crop, bicubic) ->
+ * RandomHorizontalFlip -> ToTensor -> normalize) use the same kernels: (h, w) is then the SIZE OF THE BOX the host drew
+ * (torchvision get_params; PIL crops the box, then resizes it as an image of its own), src_offset points at the box's first
+ * pixel, stride = the full image's width, nh = nw = crop, top = left = 0, and flip mirrors the output columns
+ * (PIL FLIP_LEFT_RIGHT after the resize). */
 typedef struct ch_image_desc {
-    int64_t src_offset; /* bytes from `pixels` to this image's first pixel */
+    int64_t src_offset; /* bytes from `pixels` to the first pixel that is read (the image's, or the crop box's) */
     int64_t tmp_offset;
     int32_t h, w, nh, nw, top, left, row0, nrows;
+    int32_t stride;     /* pixels per source row; 0 = w */
+    int32_t flip;       /* 1: output column x is written to crop - 1 - x */
 } ch_image_desc;
 
 /* pixels: device uint8; desc_device: device array of B descriptors; max_rows = max nrows over the batch;

@@ -101,3 +101,17 @@ def preprocess(img: np.ndarray, resize: int, crop: int, mean, std) -> np.ndarray
     m = np.asarray(mean, dtype=np.float32)[:, None, None]
     s = np.asarray(std, dtype=np.float32)[:, None, None]
     return (x - m) / s
+
+
+def preprocess_train(img: np.ndarray, box, flip: bool, crop: int, mean, std) -> np.ndarray:
+    """The TRAINING chain (configs/dataset/cub200.yaml:13-23) for given random draws: crop `box` = (top, left, height, width)
+    (torchvision RandomResizedCrop.get_params), resize the box to crop x crop as an image of its own (PIL `img.crop(box).resize`),
+    mirror the columns when `flip` (PIL FLIP_LEFT_RIGHT), /255, (x - mean) / std.  uint8 [H, W, 3] -> fp32 [3, crop, crop]."""
+    top, left, bh, bw = (int(v) for v in box)
+    r = resize_bicubic(np.ascontiguousarray(img[top:top + bh, left:left + bw, :]), crop, crop)
+    if flip:
+        r = r[:, ::-1, :]
+    x = r.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
+    m = np.asarray(mean, dtype=np.float32)[:, None, None]
+    s = np.asarray(std, dtype=np.float32)[:, None, None]
+    return (x - m) / s

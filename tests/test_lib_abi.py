@@ -45,7 +45,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_abi_version_and_error_string(lib):
     from concepthash_amd import _lib
     header = open(os.path.join(ROOT, "include", "concepthash_hip.h")).read()
-    assert lib.ch_abi_version() == 2 == _lib.ABI_VERSION == int(re.search(r"#define CH_ABI_VERSION (\d+)", header).group(1))
+    assert lib.ch_abi_version() == 3 == _lib.ABI_VERSION == int(re.search(r"#define CH_ABI_VERSION (\d+)", header).group(1))
     st = lib.ch_pack_sign(None, -1, 0, 0.0, None, None)
     assert st != 0 and b"pack_sign" in lib.ch_last_error()
     st = lib.ch_hamming_topk(None, 4, None, 4, 9, 10, 0, None, None, None, 0, None)

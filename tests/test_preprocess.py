@@ -46,6 +46,121 @@ def test_resize_truncates_the_long_side_like_torchvision():
         assert T.Resize(256, Image.BICUBIC)(img).size == want
 
 
+# ---- the training chain: RandomResizedCrop(224, bicubic) -> RandomHorizontalFlip -> ToTensor -> normalize (configs/dataset/cub200.yaml:13-23)
+
+def _train_chain(norm=3):
+    from utils import transforms as T
+    return [T.RandomResizedCrop(224, interpolation=T.interpolation("bicubic")), T.RandomHorizontalFlip(), T.ToTensor(), T.normalize_transform(norm)]
+
+
+def _write_dataset(root, sizes, quality=90, progressive_every=0):
+    import os
+    os.makedirs(os.path.join(root, "img"), exist_ok=True)
+    lines = []
+    for i, (h, w) in enumerate(sizes):
+        Image.fromarray(_image(h, w, i)).save(os.path.join(root, "img", f"{i}.jpg"), "JPEG", quality=quality,
+                                               progressive=bool(progressive_every and i % progressive_every == 0))
+        lines.append(f"img/{i}.jpg {i % 5}\n")
+    open(os.path.join(root, "train.txt"), "w").write("".join(lines))
+
+
+def test_jpeg_size_reads_the_frame_header(tmp_path):
+    import io
+    from utils.datasets import jpeg_size
+    for i, (h, w) in enumerate(SIZES):
+        for kw in ({}, {"progressive": True}, {"optimize": True}, {"subsampling": 0}):
+            bio = io.BytesIO()
+            Image.fromarray(_image(h, w, i)).save(bio, "JPEG", quality=80, **kw)
+            assert jpeg_size(memoryview(bio.getvalue())) == (h, w)
+    bio = io.BytesIO()
+    Image.fromarray(_image(40, 56, 0)[..., 0]).save(bio, "JPEG")                      # greyscale
+    assert jpeg_size(bio.getvalue()) == (40, 56)
+    bio = io.BytesIO()
+    Image.fromarray(_image(40, 56, 0)).save(bio, "PNG")
+    assert jpeg_size(bio.getvalue()) is None and jpeg_size(b"") is None and jpeg_size(b"\xff\xd8\xff") is None
+
+
+def test_training_draws_are_the_cpu_chains_and_the_oracle_reproduces_its_images(tmp_path):
+    """The loader worker of a GPU-path TRAINING dataset draws the crop box and the flip with the CPU chain's random calls: with the same
+    seed the boxes are the ones RandomResizedCrop / RandomHorizontalFlip would have used, and crop-box resize + flip of the decoded
+    image (the arithmetic the GPU kernel restates, here through the oracle) gives the CPU chain's tensors bit for bit."""
+    from oracle import preprocess_oracle as po
+    from utils.datasets import HashingDataset, OneHot
+    from utils.transforms import _NORMS
+    root = str(tmp_path)
+    sizes = SIZES[:6]
+    _write_dataset(root, sizes)
+    cpu = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5))
+    raw = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5), gpu_preprocess=True)
+    jpg = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5), gpu_decode=True)
+    assert cpu.augment is None and raw.augment is not None and jpg.augment is not None
+    torch.manual_seed(123)
+    want = [cpu[i][0] for i in range(len(sizes))]
+    torch.manual_seed(123)
+    items = [raw[i][0] for i in range(len(sizes))]
+    torch.manual_seed(123)
+    batch, targets, index = jpg[list(range(len(sizes)))]            # the batch-level read of a gpu_decode dataset
+    torch.manual_seed(123)
+    single = [jpg[i][0] for i in range(len(sizes))]
+    flips = []
+    for i, (img, box, flip) in enumerate(items):
+        assert tuple(batch.boxes[i].tolist()) == tuple(box) == tuple(single[i][1]) and bool(batch.flips[i]) == flip == single[i][2]
+        top, left, bh, bw = box
+        assert 0 <= top and 0 <= left and top + bh <= sizes[i][0] and left + bw <= sizes[i][1]
+        got = po.preprocess_train(img.numpy(), box, flip, 224, *_NORMS[3])
+        assert np.array_equal(got, want[i].numpy()), i
+        flips.append(flip)
+    assert targets.shape == (len(sizes), 5) and index.tolist() == list(range(len(sizes)))
+    # a list the GPU cannot reproduce is refused when the dataset is built, not silently replaced by the evaluation chain
+    from utils import transforms as T
+    with pytest.raises(ValueError):
+        HashingDataset(root, "train.txt", transform=[T.RandomResizedCrop(224, interpolation=T.interpolation("bilinear")), T.ToTensor()],
+                       gpu_preprocess=True)
+    with pytest.raises(ValueError):
+        HashingDataset(root, "train.txt", transform=[T.Resize(256), T.RandomResizedCrop(224, interpolation=T.interpolation("bicubic"))],
+                       gpu_decode=True)
+
+
+@pytest.mark.gpu
+def test_gpu_training_chain_equals_the_pil_chain_bit_for_bit(tmp_path):
+    """RandomResizedCrop -> RandomHorizontalFlip -> ToTensor -> normalize on the GPU (crop box + flip per image) against the CPU chain
+    run with the same seed, through both GPU data paths: decoded images (gpu_preprocess) and undecoded files (gpu_decode).  fp32
+    outputs are EQUAL; bf16 is the RNE rounding."""
+    from concepthash_amd.jpeg import GpuJpegDecoder
+    from concepthash_amd.preprocess import GpuPreprocess
+    from utils.datasets import HashingDataset, OneHot, raw_collate
+    from utils.transforms import _NORMS
+    dev = torch.device("cuda:0")
+    root = str(tmp_path)
+    sizes = SIZES + [(224, 224), (30, 40)]               # a box the size of the output, and up-scaling of a tiny image
+    _write_dataset(root, sizes, progressive_every=4)     # progressive files take the decoder's PIL route
+    n = len(sizes)
+    cpu = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5))
+    raw = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5), gpu_preprocess=True)
+    jpg = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5), gpu_decode=True)
+    pre32 = GpuPreprocess(256, 224, *_NORMS[3], out_dtype=torch.float32, device=dev)
+    pre16 = GpuPreprocess(256, 224, *_NORMS[3], out_dtype=torch.bfloat16, device=dev)
+    dec = GpuJpegDecoder(device=dev)
+    for seed in (5, 77):
+        torch.manual_seed(seed)
+        want = torch.stack([cpu[i][0] for i in range(n)])
+        torch.manual_seed(seed)
+        b, _, _ = raw_collate([raw[i] for i in range(n)])
+        got = pre32(b.pixels.to(dev), b.sizes, boxes=b.boxes, flips=b.flips).cpu()
+        assert torch.equal(got, want), float((got - want).abs().max())
+        assert torch.equal(pre16(b.pixels.to(dev), b.sizes, boxes=b.boxes, flips=b.flips).cpu(), want.to(torch.bfloat16))
+        assert bool(b.flips.any()) and not bool(b.flips.all())
+        torch.manual_seed(seed)
+        jb, _, _ = jpg[list(range(n))]
+        staged = dec.host_stage(jb)
+        assert torch.equal(staged.boxes, b.boxes) and torch.equal(staged.flips, b.flips)
+        pixels, psizes = staged.finish()
+        got = pre32(pixels, psizes, boxes=staged.boxes, flips=staged.flips).cpu()
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        pre32(b.pixels.to(dev), b.sizes, boxes=b.boxes + 400, flips=b.flips)     # a box outside its image
+
+
 @pytest.mark.gpu
 def test_gpu_preprocess_equals_the_pil_chain_bit_for_bit():
     from concepthash_amd.preprocess import GpuPreprocess

@@ -69,7 +69,9 @@ class COOPTrainer(BaseTrainer):
             ds = self.config.dataset
             mean, std = _NORMS[int(ds.get("norm", 3))]
             self._gpu_pre = GpuPreprocess(int(ds.get("resize", 256)), int(ds.get("crop", 224)), mean, std, device=self.device)
-        return self._gpu_pre(raw.pixels, raw.sizes)
+        # a training dataset's batches carry the crop boxes / flips its workers drew (RandomResizedCrop -> RandomHorizontalFlip,
+        # configs/dataset/cub200.yaml:13-23): the same kernels resize the box instead of Resize -> CenterCrop
+        return self._gpu_pre(raw.pixels, raw.sizes, boxes=getattr(raw, "boxes", None), flips=getattr(raw, "flips", None))
 
     def _jpeg_decoder(self):
         if getattr(self, "_gpu_jpeg", None) is None:
@@ -83,7 +85,7 @@ class COOPTrainer(BaseTrainer):
         a RawJpegBatch (undecoded files) or, from `iterate_loader`, a StagedJpegBatch whose host half already ran on the prefetch thread."""
         from utils.datasets import RawImageBatch
         pixels, sizes = raw.finish() if hasattr(raw, "staged") else self._jpeg_decoder().decode(raw)
-        return RawImageBatch(pixels, sizes)
+        return RawImageBatch(pixels, sizes, getattr(raw, "boxes", None), getattr(raw, "flips", None))
 
     def iterate_loader(self, loader):
         """A `gpu_decode` loader is iterated with the host half of the JPEG decode one or two batches ahead, on a background thread."""

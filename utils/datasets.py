@@ -31,12 +31,63 @@ def read_list(path: str):
     return items
 
 
+def jpeg_size(buf):
+    """(height, width) from a JPEG file's frame header (the SOFn marker), without decoding; None when `buf` is not a JPEG this
+    parser follows.  A `gpu_decode` worker needs the size to draw a training crop box and must not pay for a decode."""
+    n = len(buf)
+    if n < 4 or buf[0] != 0xFF or buf[1] != 0xD8:
+        return None
+    i = 2
+    while i + 3 < n:
+        if buf[i] != 0xFF:
+            return None
+        m = buf[i + 1]
+        if m == 0xFF:                      # fill byte
+            i += 1
+            continue
+        if m == 0xD8 or m == 0x01 or 0xD0 <= m <= 0xD7:
+            i += 2
+            continue
+        seg = (buf[i + 2] << 8) | buf[i + 3]
+        if 0xC0 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
+            if i + 8 < n:
+                return (buf[i + 5] << 8) | buf[i + 6], (buf[i + 7] << 8) | buf[i + 8]
+            return None
+        if m == 0xDA or m == 0xD9:         # scan data before any frame header
+            return None
+        i += 2 + seg
+    return None
+
+
+def gpu_augmentation(transform):
+    """The random part of a TRAINING transform list that the GPU pre-processing can take over: (RandomResizedCrop, RandomHorizontalFlip
+    or None) when the list is RandomResizedCrop(bicubic) [-> RandomHorizontalFlip] -> ToTensor -> normalize (configs/dataset/
+    cub200.yaml:13-23), None for the evaluation chain (Resize -> CenterCrop, whose geometry the trainer takes from the dataset
+    config).  Anything else cannot be reproduced there and raises."""
+    from utils import transforms as T
+    from PIL import Image
+    items = list(getattr(transform, "transforms", transform) or [])
+    rrc = [t for t in items if isinstance(t, T.RandomResizedCrop)]
+    if not rrc:
+        return None
+    flips = [t for t in items if isinstance(t, T.RandomHorizontalFlip)]
+    other = [t for t in items if not isinstance(t, (T.RandomResizedCrop, T.RandomHorizontalFlip, T.ToTensor, T.Normalize))]
+    if len(rrc) != 1 or len(flips) > 1 or other or items.index(rrc[0]) != 0 or rrc[0].interp != Image.BICUBIC \
+            or rrc[0].size[0] != rrc[0].size[1]:
+        raise ValueError("gpu_preprocess / gpu_decode: the training transform list must be RandomResizedCrop(square, bicubic) "
+                         "[-> RandomHorizontalFlip] -> ToTensor -> normalize")
+    return rrc[0], (flips[0] if flips else None)
+
+
 class RawImageBatch:
     """Decoded, untransformed images of one batch for the GPU pre-processing path: `pixels` = the uint8 RGB bytes of all images
-    back to back (image i is [h_i, w_i, 3]), `sizes` = [(h, w)].  Quacks enough like a tensor for the trainer's plumbing."""
+    back to back (image i is [h_i, w_i, 3]), `sizes` = [(h, w)].  Quacks enough like a tensor for the trainer's plumbing.
+    `boxes` [B, 4] (top, left, height, width) / `flips` [B]: the draws of the training transforms, made in the loader worker with the
+    CPU chain's own random calls; None for the evaluation chain."""
 
-    def __init__(self, pixels: torch.Tensor, sizes):
+    def __init__(self, pixels: torch.Tensor, sizes, boxes=None, flips=None):
         self.pixels, self.sizes = pixels, list(sizes)
+        self.boxes, self.flips = boxes, flips
 
     def size(self, dim=0):
         if dim != 0:
@@ -44,19 +95,24 @@ class RawImageBatch:
         return len(self.sizes)
 
     def to(self, device, non_blocking=False):
-        return RawImageBatch(self.pixels.to(device, non_blocking=non_blocking), self.sizes)
+        return RawImageBatch(self.pixels.to(device, non_blocking=non_blocking), self.sizes, self.boxes, self.flips)
 
     def pin_memory(self):
-        return RawImageBatch(self.pixels.pin_memory(), self.sizes)
+        return RawImageBatch(self.pixels.pin_memory(), self.sizes, self.boxes, self.flips)
 
 
 def raw_collate(batch):
     """collate_fn of a `gpu_preprocess` dataset: images stay decoded uint8 of their own sizes (no CPU resize), targets and
     indices are stacked as usual."""
     imgs, targets, idxs = zip(*batch)
+    boxes = flips = None
+    if isinstance(imgs[0], tuple):         # (image, box, flip): a training dataset
+        boxes = torch.as_tensor([im[1] for im in imgs], dtype=torch.int32)
+        flips = torch.as_tensor([im[2] for im in imgs], dtype=torch.bool)
+        imgs = [im[0] for im in imgs]
     pixels = torch.cat([im.reshape(-1) for im in imgs])
     targets = torch.stack([t if torch.is_tensor(t) else torch.as_tensor(t) for t in targets])
-    return RawImageBatch(pixels, [tuple(im.shape[:2]) for im in imgs]), targets, torch.as_tensor(idxs)
+    return RawImageBatch(pixels, [tuple(im.shape[:2]) for im in imgs], boxes, flips), targets, torch.as_tensor(idxs)
 
 
 class RawJpegBatch:
@@ -65,9 +121,10 @@ class RawJpegBatch:
     Stays on the host -- the entropy decode runs on host threads -- until the trainer hands `files` to
     `concepthash_amd.jpeg.GpuJpegDecoder`, which returns the RawImageBatch the GPU pre-processing takes."""
 
-    def __init__(self, data: torch.Tensor, lengths):
+    def __init__(self, data: torch.Tensor, lengths, boxes=None, flips=None):
         self.data = data
         self.lengths = [int(n) for n in lengths]
+        self.boxes, self.flips = boxes, flips      # training transforms' draws (see RawImageBatch), or None
 
     @property
     def files(self):
@@ -92,8 +149,13 @@ class RawJpegBatch:
 def jpeg_collate(batch):
     """collate_fn of a `gpu_decode` dataset: the items are file bytes; nothing is decoded or resized on the CPU."""
     files, targets, idxs = zip(*batch)
+    boxes = flips = None
+    if isinstance(files[0], tuple):
+        boxes = torch.as_tensor([f[1] for f in files], dtype=torch.int32)
+        flips = torch.as_tensor([f[2] for f in files], dtype=torch.bool)
+        files = [f[0] for f in files]
     targets = torch.stack([t if torch.is_tensor(t) else torch.as_tensor(t) for t in targets])
-    return RawJpegBatch(torch.cat(files), [f.numel() for f in files]), targets, torch.as_tensor(idxs)
+    return RawJpegBatch(torch.cat(files), [f.numel() for f in files], boxes, flips), targets, torch.as_tensor(idxs)
 
 
 class HashingDataset(Dataset):
@@ -128,6 +190,8 @@ class HashingDataset(Dataset):
             self.items = keep
         self.transform = Compose(transform) if isinstance(transform, (list, tuple)) else transform
         self.target_transform = target_transform
+        # a TRAINING transform list on a GPU path: the worker keeps the random draws (crop box, flip), the GPU does the arithmetic
+        self.augment = gpu_augmentation(self.transform) if self.gpu_preprocess else None
         self._paths = {}          # index -> resolved path (a worker resolves each file once)
 
     def __len__(self):
@@ -138,6 +202,23 @@ class HashingDataset(Dataset):
             if os.path.exists(cand):
                 return cand
         raise FileNotFoundError(f"image '{rel}' not found (list root {self.root}); use dataset=synthetic_* without images")
+
+    def _draw(self, h, w):
+        """One image's training draws, with the random calls and in the order of the CPU chain (RandomResizedCrop.get_params, then
+        RandomHorizontalFlip's torch.rand): the same worker seed gives the same boxes and flips as the reference's loader."""
+        rrc, flip = self.augment
+        box = rrc.get_params(w, h)
+        return box, (bool(float(torch.rand(1)) < flip.p) if flip is not None else False)
+
+    def _file_size(self, buf):
+        """(h, w) of an undecoded file: the JPEG frame header, or PIL's lazy open for anything else"""
+        hw = jpeg_size(buf)
+        if hw is None:
+            import io
+            from PIL import Image
+            w, h = Image.open(io.BytesIO(bytes(buf))).size
+            hw = (h, w)
+        return hw
 
     def _read_batch(self, indices):
         """`gpu_decode`: the files of a whole batch read back to back into ONE uint8 buffer (no decode, no per-item tensors, no collate)."""
@@ -159,7 +240,15 @@ class HashingDataset(Dataset):
             o += n
         targets = [self.target_transform(self.items[i][1]) if self.target_transform is not None else self.items[i][1] for i in indices]
         targets = torch.stack([t if torch.is_tensor(t) else torch.as_tensor(t) for t in targets])
-        return RawJpegBatch(data, lengths), targets, torch.as_tensor(list(indices))
+        boxes = flips = None
+        if self.augment is not None:
+            draws, o = [], 0
+            for n in lengths:
+                draws.append(self._draw(*self._file_size(view[o:o + n])))
+                o += n
+            boxes = torch.as_tensor([d[0] for d in draws], dtype=torch.int32)
+            flips = torch.as_tensor([d[1] for d in draws], dtype=torch.bool)
+        return RawJpegBatch(data, lengths, boxes, flips), targets, torch.as_tensor(list(indices))
 
     def __getitem__(self, index):
         from PIL import Image
@@ -169,11 +258,17 @@ class HashingDataset(Dataset):
         target = self.target_transform(lab) if self.target_transform is not None else lab
         if self.gpu_decode:
             import numpy as np
-            return torch.from_numpy(np.fromfile(self._resolve(rel), dtype=np.uint8)), target, index      # read only: no decode on the CPU
+            buf = np.fromfile(self._resolve(rel), dtype=np.uint8)      # read only: no decode on the CPU
+            item = torch.from_numpy(buf)
+            if self.augment is not None:
+                item = (item,) + self._draw(*self._file_size(memoryview(buf)))
+            return item, target, index
         img = Image.open(self._resolve(rel)).convert("RGB")
         if self.gpu_preprocess:
             import numpy as np
             img = torch.from_numpy(np.array(img, dtype=np.uint8))          # decode only; resize / crop / normalise on the GPU
+            if self.augment is not None:
+                img = (img,) + self._draw(img.shape[0], img.shape[1])
         elif self.transform is not None:
             img = self.transform(img)
         return img, target, index
