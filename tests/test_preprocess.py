@@ -257,3 +257,44 @@ def test_trainer_with_gpu_preprocess_gives_the_codes_of_the_cpu_chain(tmp_path):
         codes[mode] = out["codes"]
         assert out["codes"].shape == (7, 32) and out["labels"].shape == (7, 3)
     assert torch.equal(codes[True], codes[False])
+
+
+@pytest.mark.gpu
+def test_trainer_train_loader_on_the_gpu_paths_sees_the_cpu_loaders_batches(tmp_path, monkeypatch):
+    """`dataset.gpu_decode / gpu_preprocess: true` on the TRAINING split, through COOPTrainer's own plumbing (shuffling loader ->
+    iterate_loader -> compute_features_one_batch): with the same seed every batch holds the same images, crops and flips as the CPU
+    loader's (in-process loading, so that one random stream feeds the sampler and the transforms in both runs); the GPU paths hand the
+    model the bf16 rounding of the CPU chain's fp32 tensors."""
+    import engine
+    from concepthash_amd import config as cfglib
+    from trainers.coop import COOPTrainer
+    from utils.datasets import HashingDataset, OneHot
+    monkeypatch.setattr(engine, "default_workers", 0)
+    root = str(tmp_path)
+    sizes = SIZES + [(300, 300)]
+    _write_dataset(root, sizes)
+    seen = {}
+
+    class Model(torch.nn.Module):
+        def forward(self, x):
+            return None, {"codes": x.float().mean(dim=(1, 2, 3)).view(-1, 1)}
+
+    for mode in ("cpu", "gpu_preprocess", "gpu_decode"):
+        conf = cfglib.DictConfig(device="cuda", batch_size=4, model=cfglib.DictConfig(),
+                                 dataset=cfglib.DictConfig(multiclass=False, resize=256, crop=224, norm=3))
+        tr = COOPTrainer(conf)
+        tr.dataset = {"test": [], "db": [], "train": HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5),
+                                                                     gpu_preprocess=mode == "gpu_preprocess", gpu_decode=mode == "gpu_decode")}
+        tr.load_dataloader()
+        tr.model = Model()
+        torch.manual_seed(2024)
+        batches = []
+        for data in tr.iterate_loader(tr.dataloader["train"]):
+            (image, labels, index), _ = tr.compute_features_one_batch(data)
+            batches.append((image.detach().to(torch.bfloat16).cpu(), labels.cpu(), index.cpu()))
+        assert len(batches) == len(sizes) // 4                      # drop_last
+        seen[mode] = batches
+    for mode in ("gpu_preprocess", "gpu_decode"):
+        for (ia, la, xa), (ib, lb, xb) in zip(seen["cpu"], seen[mode]):
+            assert torch.equal(xa, xb) and torch.equal(la, lb)
+            assert torch.equal(ia, ib), mode
