@@ -267,6 +267,11 @@ def main():
         if rank == 0:
             result["hamming"] = hb
 
+    # ---- CPU baselines: oracle on the host cores, bounded samples (rank 0, N == 1 only).  Before the loader blocks: measured after them the
+    # same oracle ran at 0.55-0.65 of its rate (16.5 vs 25-29 images/s, no cgroup throttling; gpurun_out r04n) -- a clean process state, as in rounds 1-3 -------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result.update(cpu_baselines(torch, np, syn, sd, cfg, g_np))
+
     # ---- PCIe-inclusive variant (outside the timed region): the same step fed from pinned host memory each time -----
     if rank == 0 and not args.encode_only:
         result["pcie_inclusive"] = pcie_block(torch, enc, images, B)
@@ -286,10 +291,6 @@ def main():
     # ---- training step of the adapters (outside the timed region) -------------------------------
     if rank == 0 and not args.no_train_step:
         result["train_step"] = train_block(torch, syn, sd, cfg, B, dev)
-
-    # ---- CPU baselines: oracle on the host cores, bounded samples (rank 0, N == 1 only) -------------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result.update(cpu_baselines(torch, np, syn, sd, cfg, g_np))
 
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -851,6 +852,14 @@ def cpu_baselines(torch, np, syn, sd, cfg, g_np):
     x = syn.synthetic_images(bs, cfg["image"], seed=42)
     eo.encode(sd, x[:1], heads=cfg["heads"], with_pooled=False)  # warm-up
     log(f"[bench] cpu baseline: {cores} threads, warm-up done")
+
+    def cpu_stat():     # cgroup-v2 bandwidth accounting of the container: a throttled baseline says so in the line
+        try:
+            kv = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+            return int(kv.get("nr_periods", 0)), int(kv.get("nr_throttled", 0)), int(kv.get("usage_usec", 0))
+        except OSError:
+            return 0, 0, 0
+    cs0 = cpu_stat()
     t0 = time.perf_counter()
     nb = 0
     while nb < BATCH // bs and (nb == 0 or time.perf_counter() - t0 < 12.0):   # 10-30 s of CPU work, at most one bench batch
@@ -859,11 +868,15 @@ def cpu_baselines(torch, np, syn, sd, cfg, g_np):
         ho.topk(pk, g_np, TOPK)
         nb += 1
     cpu_s = time.perf_counter() - t0
-    log(f"[bench] cpu baseline: {nb} batches in {cpu_s:.1f} s")
+    cs1 = cpu_stat()
+    log(f"[bench] cpu baseline: {nb} batches in {cpu_s:.1f} s; cgroup: {cs1[1] - cs0[1]} of {cs1[0] - cs0[0]} periods throttled, "
+        f"{(cs1[2] - cs0[2]) / 1e6 / max(cpu_s, 1e-9):.1f} cores busy on average")
     out["cpu_baseline"] = {"value": round(nb * bs / cpu_s, 2), "unit": "images/s", "cores": cores, "kind": "port",
                            "sample": f"{nb} batches of {bs} images: oracle/encoder_oracle.py (PyTorch CPU fp32 "
                                      f"restatement of the reference forward) + oracle/hamming_oracle.c pack + "
-                                     f"top-{TOPK} vs the same {GALLERY_ROWS}-row gallery; {cpu_s:.1f} s"}
+                                     f"top-{TOPK} vs the same {GALLERY_ROWS}-row gallery; {cpu_s:.1f} s",
+                           "cgroup_periods_throttled": [cs1[1] - cs0[1], cs1[0] - cs0[0]],
+                           "cores_busy_avg": round((cs1[2] - cs0[2]) / 1e6 / max(cpu_s, 1e-9), 1)}
     # ---- Hamming, SURVEY.md section 8(d): reference-style float matmul + topk on all granted cores, a packed numpy
     # XOR/popcount, and the C oracle; 3 warm-up + 5 timed iterations each, median
     G, nbit = 1_000_000, 128

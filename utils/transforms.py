@@ -64,7 +64,7 @@ class CenterCrop:
 
 class ToTensor:
     def __call__(self, img):
-        a = np.asarray(img.convert("RGB"), dtype=np.uint8)
+        a = np.array(img.convert("RGB"), dtype=np.uint8)      # a writable copy: torch.from_numpy warns about PIL's read-only buffer
         return torch.from_numpy(a).permute(2, 0, 1).float().div_(255.0)
 
 
