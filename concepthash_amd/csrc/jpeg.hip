@@ -13,10 +13,12 @@
 // (jdsample.c: triangle filter, biases 1/2 and 8/7, edge columns special-cased, context rows clamped at the image's first / last sample
 // row as jdmainct.c's funny pointers do) and `ycc_rgb_convert` (jdcolor.c: 16-bit fixed-point tables).  Integer arithmetic throughout:
 // the RGB bytes are BIT-EQUAL to Pillow's on every supported file (tests/test_jpeg.py, against PIL itself).
-// Supported: 8-bit baseline / extended-sequential Huffman (SOF0 / SOF1), one interleaved scan, 1 component (grey) or 3 components
-// (YCbCr) with luma sampling 1x1 (4:4:4), 2x1 (4:2:2) or 2x2 (4:2:0) and chroma 1x1, restart intervals.  Anything else (progressive,
-// arithmetic, CMYK / Adobe RGB, 12 bit, multi-scan, exotic sampling, tiny images) gets a non-zero `status` in its descriptor: the host
-// side of the loader decodes exactly those files with PIL -- the reference's own path -- and counts them.
+// Supported: 8-bit Huffman-coded files -- baseline / extended-sequential (SOF0 / SOF1) with one interleaved scan, and PROGRESSIVE (SOF2:
+// any scan script of spectral selection + successive approximation that ends with every coefficient at bit 0) -- with 1 component (grey)
+// or 3 components (YCbCr), luma sampling 1x1 (4:4:4), 2x1 (4:2:2) or 2x2 (4:2:0) and chroma 1x1, restart intervals.  Anything else
+// (arithmetic, lossless, CMYK / Adobe RGB, 12 bit, multi-scan sequential, exotic sampling, tiny images, a progressive file whose low
+// coefficients are not fully refined -- libjpeg smooths those) gets a non-zero `status` in its descriptor: the host side of the loader
+// decodes exactly those files with PIL -- the reference's own path -- and counts them.
 #include <atomic>
 #include <cstring>
 #include <string>
@@ -106,6 +108,9 @@ struct Parsed {
     bool have_q[4] = {false, false, false, false};
     Huff dc[4], ac[4];
     int64_t scan_begin = 0;   // first byte of the entropy-coded segment
+    bool progressive = false; // SOF2: several scans (spectral selection / successive approximation); decoded by decode_progressive
+    int64_t first_sos = 0;    // progressive: position of the first SOS marker's 0xFF (the scan walk starts there)
+    int comp_id[3] = {0, 0, 0};
 };
 
 // status codes (also documented in include/concepthash_hip.h)
@@ -154,9 +159,10 @@ void parse(const uint8_t *d, int64_t n, Parsed &P, bool full) {
                 }
                 break;
             }
-            case 0xC0: case 0xC1: {
+            case 0xC0: case 0xC1: case 0xC2: {
                 if (sof) { P.status = JS_CORRUPT; return; }
                 sof = true;
+                P.progressive = m == 0xC2;
                 if (sl < 6) { P.status = JS_TRUNCATED; return; }
                 if (s[0] != 8) { P.status = JS_PRECISION; return; }
                 P.height = rd16(s + 1);
@@ -165,7 +171,7 @@ void parse(const uint8_t *d, int64_t n, Parsed &P, bool full) {
                 if (P.ncomp != 1 && P.ncomp != 3) { P.status = JS_COMPONENTS; return; }
                 if (sl < 6 + 3 * P.ncomp || P.height == 0 || P.width == 0) { P.status = JS_CORRUPT; return; }
                 for (int c = 0; c < P.ncomp; ++c) {
-                    comp_id[c] = s[6 + 3 * c];
+                    comp_id[c] = P.comp_id[c] = s[6 + 3 * c];
                     comp_h[c] = s[7 + 3 * c] >> 4;
                     comp_v[c] = s[7 + 3 * c] & 15;
                     P.tq[c] = s[8 + 3 * c];
@@ -173,7 +179,7 @@ void parse(const uint8_t *d, int64_t n, Parsed &P, bool full) {
                 }
                 break;
             }
-            case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+            case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
                 if (sl >= 6) {   // every SOFn has the same header: the caller's own decoder is told the size of the slot it fills
                     P.height = rd16(s + 1);
                     P.width = rd16(s + 3);
@@ -202,18 +208,25 @@ void parse(const uint8_t *d, int64_t n, Parsed &P, bool full) {
             case 0xDD: if (sl >= 2) P.restart = rd16(s); break;
             case 0xDA: {
                 if (!sof) { P.status = JS_CORRUPT; return; }
-                if (sl < 1 || s[0] != P.ncomp || sl < 1 + 2 * P.ncomp + 3) { P.status = JS_MULTISCAN; return; }
-                for (int c = 0; c < P.ncomp; ++c) {
-                    if (s[1 + 2 * c] != comp_id[c]) { P.status = JS_MULTISCAN; return; }
-                    P.td[c] = s[2 + 2 * c] >> 4;
-                    P.ta[c] = s[2 + 2 * c] & 15;
-                    if (P.td[c] > 3 || P.ta[c] > 3 || !P.dc[P.td[c]].present || !P.ac[P.ta[c]].present || !P.have_q[P.tq[c]]) {
-                        P.status = JS_TABLES;
-                        return;
+                if (!P.progressive) {
+                    if (sl < 1 || s[0] != P.ncomp || sl < 1 + 2 * P.ncomp + 3) { P.status = JS_MULTISCAN; return; }
+                    for (int c = 0; c < P.ncomp; ++c) {
+                        if (s[1 + 2 * c] != comp_id[c]) { P.status = JS_MULTISCAN; return; }
+                        P.td[c] = s[2 + 2 * c] >> 4;
+                        P.ta[c] = s[2 + 2 * c] & 15;
+                        if (P.td[c] > 3 || P.ta[c] > 3 || !P.dc[P.td[c]].present || !P.ac[P.ta[c]].present || !P.have_q[P.tq[c]]) {
+                            P.status = JS_TABLES;
+                            return;
+                        }
                     }
+                    const uint8_t *t = s + 1 + 2 * P.ncomp;
+                    if (t[0] != 0 || t[1] != 63 || t[2] != 0) { P.status = JS_PROGRESSIVE_OR_OTHER_SOF; return; }
+                } else {
+                    for (int c = 0; c < P.ncomp; ++c)
+                        if (!P.have_q[P.tq[c]]) { P.status = JS_TABLES; return; }   // (libjpeg latches the tables at the first scan of a component)
+                    P.first_sos = pos - 2;
+                    while (P.first_sos > 0 && d[P.first_sos] != 0xFF) --P.first_sos;   // (fill bytes in front of the marker code)
                 }
-                const uint8_t *t = s + 1 + 2 * P.ncomp;
-                if (t[0] != 0 || t[1] != 63 || t[2] != 0) { P.status = JS_PROGRESSIVE_OR_OTHER_SOF; return; }
                 // colour space, as libjpeg's default_decompress_parms decides it
                 if (P.ncomp == 3) {
                     bool ycc;
@@ -374,11 +387,244 @@ bool decode_block(BitReader &br, const Huff &dc, const Huff &ac, int &pred, int1
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host: progressive JPEG (SOF2) -- the scans of ITU-T T.81 annex G (spectral selection + successive approximation) accumulated into the
+// same coefficient blocks the sequential decoder fills; the GPU half is unchanged (libjpeg runs the same IDCT / upsampling / colour
+// conversion on a progressive file's final coefficients).  One thing libjpeg adds for progressive files only: inter-block smoothing
+// (jdcoefct.c) when the low AC coefficients are not fully refined.  That cannot happen for a file whose scans bring DC and the first
+// nine AC coefficients of every component down to bit 0; a file that does not is reported (status 3) and decoded by the caller's PIL.
+// ---------------------------------------------------------------------------------------------------------------------------------
+inline int get_bits(BitReader &br, int n) {   // n <= 16
+    br.ensure32();
+    const int v = (int)br.peek(n);
+    br.skip(n);
+    return v;
+}
+
+struct CompGrid {
+    int16_t *base;   // first block of the component
+    int stride;      // blocks per row of the (MCU-padded) component array
+    int h, v;        // sampling factors inside an interleaved MCU
+    int bw, bh;      // blocks per row / column of a NON-interleaved scan: ceil(component size / 8)
+};
+
+// byte-align and consume the expected RSTn; false when it is not there
+inline bool take_restart(BitReader &br, int &next_rst) {
+    br.acc = 0;
+    br.bits = 0;
+    br.marker = false;
+    const uint8_t *q = br.p;
+    while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) {
+        if (q[0] == 0xFF && q[1] != 0 && q[1] != 0xFF) return false;
+        ++q;
+    }
+    if (q + 1 >= br.end || q[1] != 0xD0 + next_rst) return false;
+    br.p = q + 2;
+    next_rst = (next_rst + 1) & 7;
+    return true;
+}
+
+// one AC refinement pass over a block (T.81 figure G.7): returns false on a bad code
+inline bool refine_block(BitReader &br, const Huff &ac, int16_t *blk, int Ss, int Se, int Al, int &eobrun) {
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    int k = Ss;
+    // a coefficient that is already non-zero takes one correction bit as it is passed
+    auto correct = [&](int16_t &c) {
+        if (get_bits(br, 1) && !(c & p1)) c = (int16_t)(c >= 0 ? c + p1 : c + m1);
+    };
+    if (eobrun == 0) {
+        for (; k <= Se; ++k) {
+            br.ensure32();
+            const int rs = decode_sym(br, ac);
+            if (rs < 0) return false;
+            int r = rs >> 4;
+            const int sz = rs & 15;
+            int value = 0;
+            if (sz) {
+                if (sz != 1) return false;
+                value = get_bits(br, 1) ? p1 : m1;      // a newly non-zero coefficient: its sign now, its position after the run
+            } else if (r != 15) {
+                eobrun = 1 << r;
+                if (r) eobrun += get_bits(br, r);
+                break;                                   // the rest of the band belongs to the end-of-band run (below)
+            }
+            // advance over r ZERO-history coefficients, correcting the non-zero ones met on the way
+            for (; k <= Se; ++k) {
+                int16_t &c = blk[kZigzag[k]];
+                if (c) correct(c);
+                else if (--r < 0) break;
+            }
+            if (value) {
+                if (k > Se) return false;
+                blk[kZigzag[k]] = (int16_t)value;
+            }
+        }
+    }
+    if (eobrun > 0) {
+        for (; k <= Se; ++k) {
+            int16_t &c = blk[kZigzag[k]];
+            if (c) correct(c);
+        }
+        --eobrun;
+    }
+    return true;
+}
+
+int decode_progressive(const uint8_t *d, int64_t n, const ch_jpeg_desc &desc, Parsed &P, int16_t *coef) {
+    const int ybw = desc.mcu_w * desc.hs, ybh = desc.mcu_h * desc.vs;
+    CompGrid grid[3];
+    grid[0] = {coef, ybw, desc.hs, desc.vs, (desc.width + 7) / 8, (desc.height + 7) / 8};
+    if (desc.ncomp == 3) {
+        const int cw = (desc.width + desc.hs - 1) / desc.hs, chh = (desc.height + desc.vs - 1) / desc.vs;   // component size, rounded up
+        grid[1] = {coef + (int64_t)64 * ybw * ybh, desc.mcu_w, 1, 1, (cw + 7) / 8, (chh + 7) / 8};
+        grid[2] = {grid[1].base + (int64_t)64 * desc.mcu_w * desc.mcu_h, desc.mcu_w, 1, 1, (cw + 7) / 8, (chh + 7) / 8};
+    }
+    std::memset(coef, 0, sizeof(int16_t) * 64 * (size_t)desc.nblocks);
+    int8_t coef_al[3][10];   // successive-approximation bit of the last scan that carried zig-zag coefficient 0..9; -1 = never seen
+    std::memset(coef_al, -1, sizeof(coef_al));
+    int restart = P.restart;
+    int64_t pos = P.first_sos;
+    bool eoi = false;
+    while (!eoi) {
+        if (pos + 2 > n) return JS_TRUNCATED;
+        if (d[pos] != 0xFF) return JS_CORRUPT;
+        while (pos < n && d[pos] == 0xFF) ++pos;
+        if (pos >= n) return JS_TRUNCATED;
+        const int m = d[pos++];
+        if (m == 0xD9) break;
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (pos + 2 > n) return JS_TRUNCATED;
+        const int len = rd16(d + pos);
+        if (len < 2 || pos + len > n) return JS_TRUNCATED;
+        const uint8_t *sg = d + pos + 2;
+        const int sl = len - 2;
+        if (m == 0xC4) {
+            int o = 0;
+            while (o < sl) {
+                if (o + 17 > sl) return JS_TABLES;
+                const int cls = sg[o] >> 4, id = sg[o] & 15;
+                if (cls > 1 || id > 3) return JS_TABLES;
+                Huff &h = cls ? P.ac[id] : P.dc[id];
+                int total = 0;
+                for (int i = 1; i <= 16; ++i) { h.counts[i] = sg[o + i]; total += sg[o + i]; }
+                o += 17;
+                if (total > 256 || o + total > sl) return JS_TABLES;
+                std::memcpy(h.vals, sg + o, total);
+                o += total;
+                if (!build_huff(h, false)) return JS_TABLES;   // (the combined run / size / value table is the sequential decoder's)
+            }
+        } else if (m == 0xDD) {
+            if (sl >= 2) restart = rd16(sg);
+        } else if (m == 0xDB || (m >= 0xC0 && m <= 0xCF)) {
+            return JS_PROGRESSIVE_OR_OTHER_SOF;   // tables or frames redefined between scans: the caller's decoder
+        } else if (m == 0xDA) {
+            if (sl < 1) return JS_CORRUPT;
+            const int ns = sg[0];
+            if (ns < 1 || ns > desc.ncomp || sl < 1 + 2 * ns + 3) return JS_CORRUPT;
+            int ci[3], td[3], ta[3];
+            for (int i = 0; i < ns; ++i) {
+                ci[i] = -1;
+                for (int c = 0; c < desc.ncomp; ++c)
+                    if (P.comp_id[c] == sg[1 + 2 * i]) ci[i] = c;
+                if (ci[i] < 0 || (i && ci[i] <= ci[i - 1])) return JS_CORRUPT;
+                td[i] = sg[2 + 2 * i] >> 4;
+                ta[i] = sg[2 + 2 * i] & 15;
+                if (td[i] > 3 || ta[i] > 3) return JS_TABLES;
+            }
+            const uint8_t *t = sg + 1 + 2 * ns;
+            const int Ss = t[0], Se = t[1], Ah = t[2] >> 4, Al = t[2] & 15;
+            if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah && Ah != Al + 1)) return JS_CORRUPT;
+            for (int i = 0; i < ns; ++i) {
+                if (Ss == 0 && !Ah && !P.dc[td[i]].present) return JS_TABLES;
+                if (Ss > 0 && !P.ac[ta[i]].present) return JS_TABLES;
+                for (int k = Ss; k <= Se && k < 10; ++k) coef_al[ci[i]][k] = (int8_t)Al;
+            }
+            BitReader br;
+            br.p = d + pos + len;
+            br.end = d + n;
+            int pred[3] = {0, 0, 0}, eobrun = 0, to_restart = restart, next_rst = 0;
+            // MCU raster of the scan: the frame's MCU grid when interleaved, the component's own block raster otherwise
+            const bool inter = ns > 1;
+            const int rows = inter ? desc.mcu_h : grid[ci[0]].bh, cols = inter ? desc.mcu_w : grid[ci[0]].bw;
+            for (int my = 0; my < rows; ++my)
+                for (int mx = 0; mx < cols; ++mx) {
+                    if (restart) {
+                        if (to_restart == 0) {
+                            if (!take_restart(br, next_rst)) return JS_CORRUPT;
+                            pred[0] = pred[1] = pred[2] = 0;
+                            eobrun = 0;
+                            to_restart = restart;
+                        }
+                        --to_restart;
+                    }
+                    for (int i = 0; i < ns; ++i) {
+                        const CompGrid &g = grid[ci[i]];
+                        const int nh = inter ? g.h : 1, nv = inter ? g.v : 1;
+                        for (int v = 0; v < nv; ++v)
+                            for (int h = 0; h < nh; ++h) {
+                                int16_t *blk = g.base + (int64_t)64 * ((int64_t)(my * nv + v) * g.stride + mx * nh + h);
+                                if (Ss == 0) {
+                                    if (!Ah) {   // DC, first pass: the sequential decoder's difference coding, scaled by the point transform
+                                        br.ensure32();
+                                        const int sz = decode_sym(br, P.dc[td[i]]);
+                                        if (sz < 0 || sz > 11) return JS_CORRUPT;
+                                        if (sz) pred[i] += extend(get_bits(br, sz), sz);
+                                        blk[0] = (int16_t)(pred[i] * (1 << Al));
+                                    } else if (get_bits(br, 1)) {   // DC refinement: one more bit
+                                        blk[0] = (int16_t)(blk[0] | (1 << Al));
+                                    }
+                                } else if (!Ah) {   // AC band, first pass (figure G.3 with end-of-band runs)
+                                    if (eobrun > 0) {
+                                        --eobrun;
+                                        continue;
+                                    }
+                                    const Huff &ac = P.ac[ta[i]];
+                                    for (int k = Ss; k <= Se; ++k) {
+                                        br.ensure32();
+                                        const int rs = decode_sym(br, ac);
+                                        if (rs < 0) return JS_CORRUPT;
+                                        const int r = rs >> 4, sz = rs & 15;
+                                        if (sz) {
+                                            k += r;
+                                            if (k > Se) return JS_CORRUPT;
+                                            blk[kZigzag[k]] = (int16_t)(extend(get_bits(br, sz), sz) * (1 << Al));
+                                        } else if (r == 15) {
+                                            k += 15;
+                                        } else {
+                                            eobrun = 1 << r;
+                                            if (r) eobrun += get_bits(br, r);
+                                            --eobrun;
+                                            break;
+                                        }
+                                    }
+                                } else if (!refine_block(br, P.ac[ta[i]], blk, Ss, Se, Al, eobrun)) {
+                                    return JS_CORRUPT;
+                                }
+                            }
+                    }
+                }
+            // the next marker: the reader never steps over one, so it is at or after br.p
+            const uint8_t *q = br.p;
+            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0 && q[1] != 0xFF && !(q[1] >= 0xD0 && q[1] <= 0xD7))) ++q;
+            if (q + 1 >= br.end) break;   // no EOI: what has been decoded stands, as libjpeg's premature-end handling leaves it
+            pos = q - d;
+            continue;
+        }
+        pos += len;
+    }
+    // libjpeg smooths blocks of a progressive file whose DC / first AC coefficients are not known to bit 0: not reproduced here
+    for (int c = 0; c < desc.ncomp; ++c)
+        for (int k = 0; k < 10; ++k)
+            if (coef_al[c][k] != 0) return JS_PROGRESSIVE_OR_OTHER_SOF;
+    return JS_OK;
+}
+
 // coef: this image's blocks -- component 0 [rows][cols][64], then components 1, 2
 int entropy_decode_one(const uint8_t *d, int64_t n, const ch_jpeg_desc &desc, int16_t *coef) {
     Parsed P;
     parse(d, n, P, true);
     if (P.status) return P.status;
+    if (P.progressive) return decode_progressive(d, n, desc, P, coef);
     BitReader br;
     br.p = d + P.scan_begin;
     br.end = d + n;

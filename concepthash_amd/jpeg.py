@@ -29,7 +29,7 @@ DESC_DTYPE = np.dtype([("coef_offset", "<i8"), ("pix_offset", "<i8"), ("plane_of
                        ("nblocks", "<i4"), ("reserved", "<i4"), ("quant", "<u2", (3, 64))])   # == ch_jpeg_desc / _lib.JpegDesc
 assert DESC_DTYPE.itemsize == ctypes.sizeof(_lib.JpegDesc)
 
-STATUS = {0: "ok", 1: "not a JPEG", 2: "truncated", 3: "progressive / lossless / arithmetic", 4: "not 8 bit", 5: "component count",
+STATUS = {0: "ok", 1: "not a JPEG", 2: "truncated", 3: "lossless / arithmetic / unfinished progressive", 4: "not 8 bit", 5: "component count",
           6: "sampling factors", 7: "multi-scan", 8: "colour space", 9: "tables", 10: "smaller than 16x16", 11: "corrupt entropy data"}
 
 
@@ -83,6 +83,7 @@ class GpuJpegDecoder:
         self.strict = bool(strict)     # True: a file outside the supported subset raises instead of going through PIL
         self._ring = [dict(coef=None, desc=None, fb=None, event=None, coef_dev=None, desc_dev=None, copied=None) for _ in range(self._RING)]
         self._pos = 0
+        self._pool = None              # thread pool of the PIL route (files outside the supported subset), created on first use
         self._copy_stream = None       # host -> device copies of a staged batch run here, beside the caller's kernels (SDMA engine)
         self.stats = {"images": 0, "gpu": 0, "pil_fallback": 0, "fallback_reasons": {}, "plan_s": 0.0, "ring_wait_s": 0.0, "entropy_s": 0.0,
                       "enqueue_s": 0.0, "touch_s": 0.0}
@@ -187,8 +188,7 @@ class GpuJpegDecoder:
         fallback = {}
         if desc["status"].any():                       # a corrupt stream (rare): PIL for that file, its slot keeps its size
             bufs = [data[int(offsets[i]):int(offsets[i + 1])].numpy() for i in range(n)]
-            for i in np.nonzero(desc["status"])[0]:
-                self._fallback(int(i), desc, bufs, fallback, keep_size=True)
+            self._fallback([int(i) for i in np.nonzero(desc["status"])[0]], desc, bufs, fallback, keep_size=True)
         sizes = list(zip(desc["height"].tolist(), desc["width"].tolist()))
         desc_host.numpy()[:desc.nbytes] = desc.view(np.uint8).reshape(-1)     # numpy, not torch copy_: no OpenMP team on this thread
         fb = None
@@ -227,8 +227,7 @@ class GpuJpegDecoder:
         t0 = time.perf_counter()
         desc, bufs, ptrs, lens = self.plan(files)
         fallback = {}                                  # index -> decoded RGB array (PIL)
-        for i in np.nonzero(desc["status"])[0]:
-            self._fallback(int(i), desc, bufs, fallback)
+        self._fallback([int(i) for i in np.nonzero(desc["status"])[0]], desc, bufs, fallback)
         totals = self.layout(desc)
         t1 = time.perf_counter()
         with torch.cuda.device(self.device):           # (a prefetch thread starts on device 0: events / pinned buffers belong to OUR device)
@@ -238,9 +237,8 @@ class GpuJpegDecoder:
         _lib.check(self.lib.ch_jpeg_entropy_decode(ptrs, lens, n, desc.ctypes.data, coef_host.data_ptr(), self.threads),
                    "ch_jpeg_entropy_decode")
         t3 = time.perf_counter()
-        for i in np.nonzero(desc["status"])[0]:        # streams that turned out corrupt: their slots keep their sizes
-            if int(i) not in fallback:
-                self._fallback(int(i), desc, bufs, fallback, keep_size=True)
+        # streams that turned out corrupt: their slots keep their sizes
+        self._fallback([int(i) for i in np.nonzero(desc["status"])[0] if int(i) not in fallback], desc, bufs, fallback, keep_size=True)
         sizes = [(int(h), int(w)) for h, w in zip(desc["height"], desc["width"])]
         with torch.cuda.device(self.device):
             desc_host = self._pinned(slot, "desc", desc.nbytes)
@@ -296,17 +294,31 @@ class GpuJpegDecoder:
     def decode(self, files: Sequence, stream=None):
         return self.device_stage(self.host_stage(files), stream)
 
-    def _fallback(self, i, desc, bufs, fallback, keep_size=False):
-        reason = STATUS.get(int(desc["status"][i]), str(int(desc["status"][i])))
-        if self.strict:
-            raise ValueError(f"image {i}: outside the GPU JPEG subset ({reason}) and strict=True")
-        a = self._pil(bufs[i])
-        if keep_size and (a.shape[0] != int(desc["height"][i]) or a.shape[1] != int(desc["width"][i])):
-            raise ValueError(f"image {i}: corrupt entropy data and PIL decodes it to another size")
-        desc["height"][i], desc["width"][i] = a.shape[0], a.shape[1]
-        fallback[i] = a
+    def _fallback(self, indices, desc, bufs, fallback, keep_size=False):
+        """The files outside the supported subset (or with corrupt entropy data) through PIL, the reference's own decoder.  More than a
+        couple of them are decoded on the decoder's thread pool (PIL releases the GIL while it decodes): a dataset with many such
+        files must not fall back to one image at a time on the host-stage thread."""
+        if not indices:
+            return
+        for i in indices:
+            if self.strict:
+                reason = STATUS.get(int(desc["status"][i]), str(int(desc["status"][i])))
+                raise ValueError(f"image {i}: outside the GPU JPEG subset ({reason}) and strict=True")
+        if len(indices) > 2 and self.threads > 1:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self.threads, thread_name_prefix="jpeg-pil")
+            decoded = list(self._pool.map(lambda i: self._pil(bufs[i]), indices))
+        else:
+            decoded = [self._pil(bufs[i]) for i in indices]
         r = self.stats["fallback_reasons"]
-        r[reason] = r.get(reason, 0) + 1
+        for i, a in zip(indices, decoded):
+            if keep_size and (a.shape[0] != int(desc["height"][i]) or a.shape[1] != int(desc["width"][i])):
+                raise ValueError(f"image {i}: corrupt entropy data and PIL decodes it to another size")
+            desc["height"][i], desc["width"][i] = a.shape[0], a.shape[1]
+            fallback[i] = a
+            reason = STATUS.get(int(desc["status"][i]), str(int(desc["status"][i])))
+            r[reason] = r.get(reason, 0) + 1
 
     __call__ = decode
 

@@ -242,9 +242,11 @@ typedef struct ch_jpeg_desc {
     int32_t ncomp;        /* 1 (grey, replicated to RGB as PIL's convert("RGB") does) or 3 (YCbCr) */
     int32_t hs, vs;       /* luma sampling factors: 1x1 (4:4:4), 2x1 (4:2:2), 2x2 (4:2:0); chroma is 1x1 */
     int32_t mcu_w, mcu_h; /* MCUs per row / column */
-    int32_t status;       /* 0 = decoded by this path; 1 not a JPEG, 2 truncated, 3 progressive / lossless / arithmetic or spectral
-                             selection, 4 not 8 bit, 5 component count, 6 sampling factors, 7 multi-scan, 8 colour space, 9 tables,
-                             10 smaller than 16x16, 11 corrupt entropy data (set by ch_jpeg_entropy_decode) */
+    int32_t status;       /* 0 = decoded by this path (baseline, extended-sequential and progressive Huffman files); 1 not a JPEG,
+                             2 truncated, 3 lossless / arithmetic coding, or a progressive file whose scans leave DC or the first AC
+                             coefficients above bit 0 (libjpeg smooths those; set by ch_jpeg_entropy_decode), 4 not 8 bit, 5 component
+                             count, 6 sampling factors, 7 multi-scan sequential, 8 colour space, 9 tables, 10 smaller than 16x16,
+                             11 corrupt entropy data (set by ch_jpeg_entropy_decode) */
     int32_t nblocks;      /* 8x8 blocks of all components = coefficient elements / 64 */
     int32_t reserved;
     uint16_t quant[3][64]; /* quantisation tables per component, natural (row-major) order */
@@ -256,7 +258,8 @@ typedef struct ch_jpeg_desc {
 int ch_jpeg_plan(const uint8_t *const *files, const int64_t *lens, int32_t n, ch_jpeg_desc *desc, int64_t *total_coef, int64_t *total_pix,
                  int64_t *total_plane);
 /* HOST: Huffman-decode the entropy-coded segments of the files with status 0 on `nthreads` threads into coef_host (host memory,
- * ideally pinned; every block fully written, DC prediction undone, natural order).  A corrupt stream sets that descriptor's status. */
+ * ideally pinned; every block fully written, DC prediction undone, natural order; a progressive file's scans -- spectral selection and
+ * successive approximation, ITU-T T.81 annex G -- are accumulated into the same blocks).  A corrupt stream sets that descriptor's status. */
 int ch_jpeg_entropy_decode(const uint8_t *const *files, const int64_t *lens, int32_t n, ch_jpeg_desc *desc, int16_t *coef_host,
                            int32_t nthreads);
 /* HOST: the same two calls for a batch whose files sit back to back in ONE buffer (what a `gpu_decode` loader worker hands over):

@@ -4,7 +4,7 @@ CPU: the HOST half of the product (`ch_jpeg_plan` / `ch_jpeg_entropy_decode`: ma
 without a GPU) feeds oracle/jpeg_oracle.py (numpy restatement of libjpeg-turbo's islow IDCT, fancy upsampling and YCbCr -> RGB); the
 result must equal PIL's bytes -- this pins both the entropy decoder and the restatement against Pillow itself.
 GPU: `GpuJpegDecoder` (host entropy decode + `ch_jpeg_reconstruct`) equals PIL bit for bit on the same files, mixed batches with
-unsupported files (progressive -> PIL on the host, counted) included, and `dataset.gpu_decode: true` gives the codes of the
+unsupported files (CMYK, tiny -> PIL on the host, counted) included; progressive files (SOF2) are decoded by the same split, and `dataset.gpu_decode: true` gives the codes of the
 reference-style CPU loader through `COOPTrainer.inference_one_epoch`."""
 import ctypes
 import io
@@ -48,7 +48,13 @@ CASES = [((375, 500), 2, 75, "RGB", {}), ((500, 375), 2, 90, "RGB", {}), ((333, 
          ((17, 16), 2, 75, "RGB", {}), ((16, 33), 1, 50, "RGB", {}), ((64, 64), 0, 30, "RGB", {}), ((480, 640), 2, 20, "RGB", {}),
          ((375, 500), 2, 75, "L", {}), ((129, 67), 0, 90, "L", {}), ((375, 500), 2, 75, "RGB", dict(optimize=True)),
          ((375, 500), 2, 75, "RGB", dict(restart_marker_blocks=5)), ((300, 401), 1, 85, "RGB", dict(restart_marker_rows=1)),
-         ((99, 1001), 2, 60, "RGB", {}), ((1001, 99), 2, 60, "RGB", {}), ((257, 259), 2, 100, "RGB", {})]
+         ((99, 1001), 2, 60, "RGB", {}), ((1001, 99), 2, 60, "RGB", {}), ((257, 259), 2, 100, "RGB", {}),
+         # progressive (SOF2): spectral selection + successive approximation, every sampling, grey, optimised tables, restart intervals
+         ((375, 500), 2, 75, "RGB", dict(progressive=True)), ((333, 500), 1, 85, "RGB", dict(progressive=True)),
+         ((241, 255), 0, 95, "RGB", dict(progressive=True)), ((129, 67), 0, 90, "L", dict(progressive=True)),
+         ((17, 16), 2, 30, "RGB", dict(progressive=True)), ((480, 640), 2, 100, "RGB", dict(progressive=True, optimize=True)),
+         ((300, 401), 2, 80, "RGB", dict(progressive=True, restart_marker_rows=1)),
+         ((203, 310), 1, 60, "RGB", dict(progressive=True, restart_marker_blocks=7))]
 
 
 def _files():
@@ -106,7 +112,7 @@ def test_files_outside_the_subset_are_flagged_not_guessed():
     good = _jpeg(img, quality=80)
     trunc = good[: len(good) // 2]
     desc, _ = _host_decode([prog, cmyk.getvalue(), tiny, png.getvalue(), good, good[:100], trunc])
-    assert list(desc["status"][:5]) == [3, 5, 10, 1, 0]
+    assert list(desc["status"][:5]) == [0, 5, 10, 1, 0]           # (progressive files are decoded since round 4)
     assert desc["status"][5] != 0                                 # cut inside the headers
     assert desc["status"][6] in (0, 11)                           # cut inside the entropy data: zero-filled tail or flagged corrupt
     assert (desc["height"][0], desc["width"][0]) == (120, 160)    # the size of a file the caller decodes itself is still reported
@@ -117,7 +123,9 @@ def test_gpu_jpeg_decoder_equals_pillow_bit_for_bit():
     from concepthash_amd.jpeg import GpuJpegDecoder, decode_to_list
     dev = torch.device("cuda:0")
     files = _files()
-    files.insert(3, _jpeg(_image(200, 300, 77), quality=85, progressive=True))     # outside the subset: PIL on the host, same bytes
+    cmyk = io.BytesIO()
+    Image.fromarray(_image(200, 300, 77)).convert("CMYK").save(cmyk, "JPEG", quality=85)
+    files.insert(3, cmyk.getvalue())                                                # outside the subset: PIL on the host, same bytes
     dec = GpuJpegDecoder(device=dev, threads=4)
     for rep in range(3):                                                             # the pinned ring is reused
         outs = decode_to_list(dec, files)
@@ -127,7 +135,7 @@ def test_gpu_jpeg_decoder_equals_pillow_bit_for_bit():
             assert tuple(o.shape) == ref.shape
             assert np.array_equal(o.cpu().numpy(), ref)
     assert dec.stats["pil_fallback"] == 3 and dec.stats["gpu"] == 3 * (len(files) - 1)
-    assert dec.stats["fallback_reasons"] == {"progressive / lossless / arithmetic": 3}
+    assert dec.stats["fallback_reasons"] == {"component count": 3}
     with pytest.raises(ValueError, match="strict"):
         GpuJpegDecoder(device=dev, strict=True).decode(files)
     pixels, sizes = dec.decode([])
@@ -153,10 +161,11 @@ def test_trainer_with_gpu_decode_gives_the_codes_of_the_cpu_loader(tmp_path):
     root = tmp_path / "d"
     (root / "img").mkdir(parents=True)
     lines = []
-    cases = [((375, 500), 2, 75), ((500, 375), 2, 90), ((333, 500), 1, 85), ((300, 300), 0, 95), ((64, 48), 2, 80), ((400, 731), 2, 70),
+    # (file 4 is smaller than 16 x 16 blocks allow on the GPU path -> PIL on the host; file 5 is progressive -> GPU)
+    cases = [((375, 500), 2, 75), ((500, 375), 2, 90), ((333, 500), 1, 85), ((300, 300), 0, 95), ((12, 48), 2, 80), ((400, 731), 2, 70),
              ((257, 300), 2, 90)]
     for i, ((h, w), sub, q) in enumerate(cases):
-        (root / "img" / f"{i}.jpg").write_bytes(_jpeg(_image(h, w, i), quality=q, subsampling=sub, progressive=(i == 4)))
+        (root / "img" / f"{i}.jpg").write_bytes(_jpeg(_image(h, w, i), quality=q, subsampling=sub, progressive=(i == 5)))
         lines.append(f"img/{i}.jpg {i % 3}")
     (root / "test.txt").write_text("\n".join(lines) + "\n")
     cfg = dict(syn.CONFIGS["vit_s16"])

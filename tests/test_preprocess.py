@@ -133,7 +133,7 @@ def test_gpu_training_chain_equals_the_pil_chain_bit_for_bit(tmp_path):
     dev = torch.device("cuda:0")
     root = str(tmp_path)
     sizes = SIZES + [(224, 224), (30, 40)]               # a box the size of the output, and up-scaling of a tiny image
-    _write_dataset(root, sizes, progressive_every=4)     # progressive files take the decoder's PIL route
+    _write_dataset(root, sizes, progressive_every=4)     # baseline and progressive files
     n = len(sizes)
     cpu = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5))
     raw = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5), gpu_preprocess=True)
