@@ -33,6 +33,14 @@ def _worker_context(workers):
         except Exception:
             pass
         _forkserver_ready = True
+        try:
+            # start the server NOW (its `import torch` takes a second or more): the first loader is created well before it is iterated
+            # -- the model build and the checkpoint load sit in between -- so the start-up runs beside them instead of in front of the
+            # first batch
+            from multiprocessing import forkserver
+            forkserver.ensure_running()
+        except Exception:
+            pass
     return mp.get_context("forkserver")
 
 

@@ -39,16 +39,24 @@ class RetrievalEvaluation:
         engine.seeding(config["seed"])
         logdir = config.logdir
         modelfn = "last" if config.get("use_last") else "best"
+        self.timing = {}                      # seconds per phase of the command (printed at the end, kept in history.json)
+
+        def phase(name, fn, *a, **k):
+            t0 = time.perf_counter()
+            out = fn(*a, **k)
+            self.timing[name] = round(self.timing.get(name, 0.0) + time.perf_counter() - t0, 3)
+            return out
+        self._phase = phase
         trainer = instantiate(config.trainer, config)
-        trainer.load_dataset(load_db=True)
-        trainer.load_dataloader()
+        phase("datasets", trainer.load_dataset, load_db=True)
+        phase("loaders", trainer.load_dataloader)
         if config.exp not in ("descriptor", "extract"):
             trainer.load_for_inference(logdir)
-        trainer.load_model()
+        phase("model_build", trainer.load_model)
         trainer.load_criterion()
         if config.exp not in ("descriptor", "extract"):
-            trainer.load_model_state(f"{logdir}/models/{modelfn}.pth")
-        trainer.to_device()
+            phase("checkpoint", trainer.load_model_state, f"{logdir}/models/{modelfn}.pth")
+        phase("to_device", trainer.to_device)
         # one process per GPU: `eval_logdir` defaults to a time-stamped directory (configs/val.yaml), which every rank would
         # compose differently -> rank 0 decides and broadcasts, and only rank 0 writes files
         import torch.distributed as dist
@@ -79,8 +87,8 @@ class RetrievalEvaluation:
         cfg = self.config
         print("Testing Start")
         res = {}
-        test_meters, test_out = self.trainer.inference_one_epoch("test", True)
-        db_meters, db_out = self.trainer.inference_one_epoch("db", True)
+        test_meters, test_out = self._phase("encode_test", self.trainer.inference_one_epoch, "test", True)
+        db_meters, db_out = self._phase("encode_db", self.trainer.inference_one_epoch, "db", True)
         for k, m in test_meters.items():
             res["test_" + k] = m.avg
         for k, m in db_meters.items():
@@ -103,9 +111,9 @@ class RetrievalEvaluation:
                 as_db = bool(cfg.get("test_as_database"))
                 g_codes, g_labels = (test_codes, test_labels) if as_db else (db_codes, db_labels)
                 if cfg.get("compute_mAP"):
-                    mAPs, recalls, precisions = calculate_mAP(g_codes, g_labels, test_codes, test_labels, cfg.R,
-                                                              threshold=cfg.ternary_threshold, dist_metric=cfg.dist_metric,
-                                                              PRs=cfg.PRs, remove_first_retrieved=as_db)
+                    mAPs, recalls, precisions = self._phase("retrieval", calculate_mAP, g_codes, g_labels, test_codes, test_labels, cfg.R,
+                                                            threshold=cfg.ternary_threshold, dist_metric=cfg.dist_metric,
+                                                            PRs=cfg.PRs, remove_first_retrieved=as_db)
                     res["mAP" + postfix], res["recalls" + postfix], res["precisions" + postfix] = mAPs, recalls, precisions
                     if isinstance(mAPs, list):
                         for R, m in zip(cfg.R, mAPs):
@@ -122,6 +130,7 @@ class RetrievalEvaluation:
                     for R, r, p in zip(Rs, recalls, precisions):
                         print(f"P@{R}: {p:.4f}; R@{R}: {r:.4f}")
                 print()
+            res["timing_s"] = dict(self.timing, since_start=round(time.time() - self.start_time, 3))
             if self.rank == 0:
                 with open(os.path.join(self.eval_logdir, "history.json"), "w") as f:
                     json.dump(res, f)
@@ -135,6 +144,7 @@ class RetrievalEvaluation:
         total = time.time() - self.start_time
         print(f'Testing End at {datetime.today().strftime("%Y-%m-%d %H:%M:%S")}')
         print(f"Total time used: {total / 3600:.2f} hours")
+        print("Phases (s): " + ", ".join(f"{k} {v:.2f}" for k, v in self.timing.items()))
         io.join_save_queue()
         print(f"Done: {self.eval_logdir}")
         self.results = res
