@@ -71,6 +71,8 @@ SIGNATURES = {
     "ch_jpeg_entropy_decode": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32]),
     "ch_jpeg_plan_packed": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "ch_jpeg_entropy_decode_packed": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32]),
+    "ch_io_file_sizes": (c_int, [c_void_p, c_int32, c_void_p]),
+    "ch_io_read_files": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32]),
     "ch_jpeg_reconstruct": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "ch_pack_sign": (c_int, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "ch_hamming_dist": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

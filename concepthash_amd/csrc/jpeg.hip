@@ -19,7 +19,12 @@
 // (arithmetic, lossless, CMYK / Adobe RGB, 12 bit, multi-scan sequential, exotic sampling, tiny images, a progressive file whose low
 // coefficients are not fully refined -- libjpeg smooths those) gets a non-zero `status` in its descriptor: the host side of the loader
 // decodes exactly those files with PIL -- the reference's own path -- and counts them.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <atomic>
+#include <cerrno>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -945,6 +950,62 @@ extern "C" int ch_jpeg_entropy_decode_packed(const uint8_t *data, const int64_t 
         lens[i] = offsets[i + 1] - offsets[i];
     }
     return ch_jpeg_entropy_decode(files.data(), lens.data(), n, desc, coef_host, nthreads);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host: reading a batch's files (what is left of the reference's loader workers once nothing is decoded on the CPU: engine.py:41-54 +
+// the dataset classes' `Image.open(path)`).  Plain POSIX reads on a few threads, no Python in the loop: a `gpu_decode` loader needs no
+// worker PROCESSES (0.35-1.1 s to start per loader, a shared-memory hop per batch) -- concepthash_amd/engine.FileBatchLoader.
+// ---------------------------------------------------------------------------------------------------------------------------------
+extern "C" int ch_io_file_sizes(const char *const *paths, int32_t n, int64_t *sizes) {
+    CH_REQUIRE(n >= 0 && (n == 0 || (paths && sizes)), "io_file_sizes: null argument");
+    for (int i = 0; i < n; ++i) {
+        struct stat st;
+        if (!paths[i] || ::stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode)) {
+            ch_set_error((std::string("io_file_sizes: cannot stat '") + (paths[i] ? paths[i] : "(null)") + "'").c_str());
+            return 3;
+        }
+        sizes[i] = (int64_t)st.st_size;
+    }
+    return 0;
+}
+// file i -> dst[offsets[i], offsets[i] + sizes[i]); fails (status 3) when a file is shorter or cannot be opened
+extern "C" int ch_io_read_files(const char *const *paths, int32_t n, const int64_t *offsets, const int64_t *sizes, uint8_t *dst,
+                                int32_t nthreads) {
+    CH_REQUIRE(n >= 0 && (n == 0 || (paths && offsets && sizes && dst)), "io_read_files: null argument");
+    if (n == 0) return 0;
+    std::atomic<int> next{0}, bad{-1};
+    auto work = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            const int fd = ::open(paths[i], O_RDONLY | O_CLOEXEC);
+            bool ok = fd >= 0;
+            int64_t got = 0;
+            while (ok && got < sizes[i]) {
+                const ssize_t r = ::read(fd, dst + offsets[i] + got, (size_t)(sizes[i] - got));
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) ok = false;
+                else got += r;
+            }
+            if (fd >= 0) ::close(fd);
+            if (!ok) {
+                int expect = -1;
+                bad.compare_exchange_strong(expect, i);
+            }
+        }
+    };
+    const int nt = std::max(1, std::min<int>(nthreads, n));
+    if (nt == 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+    }
+    if (bad.load() >= 0) {
+        ch_set_error((std::string("io_read_files: cannot read '") + paths[bad.load()] + "' (missing, or shorter than its size a moment ago)").c_str());
+        return 3;
+    }
+    return 0;
 }
 
 extern "C" int ch_jpeg_reconstruct(const int16_t *coef_dev, const ch_jpeg_desc *desc_dev, const ch_jpeg_desc *desc_host, int32_t n,

@@ -44,6 +44,33 @@ def _worker_context(workers):
     return mp.get_context("forkserver")
 
 
+class FileBatchLoader:
+    """The loader of a `gpu_decode` dataset: nothing is decoded on the CPU, so what the reference's worker processes would do
+    (engine.py:48-53) is reading files -- done here by `HashingDataset._read_batch` through the library's host helpers (a few threads
+    of plain reads, no Python in the loop).  No worker processes: nothing to start per loader (0.35-1.1 s with six forkserver workers,
+    a third of a CUB-sized epoch at this path's rate), no shared-memory hop per batch, no forkserver.  Iterating is synchronous -- the
+    asynchrony is `concepthash_amd.jpeg.prefetch_decoded`'s fetch thread, which the trainers put around a `gpu_decode` loader
+    (`COOPTrainer.iterate_loader`).  Same batches as `DataLoader(d, bs, shuffle, drop_last=..., sampler=...)`: the torch samplers draw
+    from the same generators."""
+    num_workers = 0
+
+    def __init__(self, dataset, batch_sampler):
+        self.dataset, self.batch_sampler = dataset, batch_sampler
+        self.batch_size = getattr(batch_sampler, "batch_size", None)
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+    def __iter__(self):
+        # a DataLoader draws one int64 from the global generator per epoch (the base seed of its workers) before its sampler draws:
+        # drawn and dropped here, so that one `torch.manual_seed` gives this loader the batches -- and, loading in-process, the crops and
+        # flips -- of `DataLoader(d, bs, shuffle, num_workers=0)` (tests/test_preprocess.py)
+        import torch
+        torch.empty((), dtype=torch.int64).random_()
+        for indices in self.batch_sampler:
+            yield self.dataset[list(indices)]
+
+
 def dataloader(d, bs=256, shuffle=False, workers=-1, drop_last=False, sampler=None):
     if len(d) == 0:
         return []
@@ -53,13 +80,14 @@ def dataloader(d, bs=256, shuffle=False, workers=-1, drop_last=False, sampler=No
     if getattr(d, "in_memory", False):      # tensor-backed datasets need no worker processes
         workers = 0
     if getattr(d, "gpu_decode", False):
-        # `gpu_decode` datasets fetch a whole BATCH per call (one read loop into one buffer, no per-item tensors, no collate): the
-        # loader hands the dataset index lists.  Workers only read files; the host cores belong to the trainer's entropy-decode threads.
-        # The workers PERSIST across epochs (the trainers iterate the same loader object every epoch): starting six of them costs
-        # 0.35-1.1 s, a third of a 6 K-image epoch at this path's rate (tools/loader_probe.py).
+        # `gpu_decode` datasets fetch a whole BATCH per call (one buffer, no per-item tensors, no collate) and need no worker processes:
+        # FileBatchLoader.  (`workers` > 0 with `file_workers=True` on the dataset keeps the earlier arrangement -- DataLoader workers
+        # that only read files, persistent across epochs -- for storage where a read blocks for long.)
         from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
-        workers = min(workers, 6)
         base = sampler if sampler is not None else (RandomSampler(d) if shuffle else SequentialSampler(d))
+        if not getattr(d, "file_workers", False):
+            return FileBatchLoader(d, BatchSampler(base, bs, drop_last))
+        workers = min(workers, 6)
         return DataLoader(d, batch_size=None, sampler=BatchSampler(base, bs, drop_last), num_workers=workers, pin_memory=False,
                           multiprocessing_context=_worker_context(workers), persistent_workers=workers > 0)
     return DataLoader(d, bs, shuffle, drop_last=drop_last, num_workers=workers, sampler=sampler,

@@ -268,6 +268,11 @@ int ch_jpeg_plan_packed(const uint8_t *data, const int64_t *offsets, int32_t n, 
                         int64_t *total_plane);
 int ch_jpeg_entropy_decode_packed(const uint8_t *data, const int64_t *offsets, int32_t n, ch_jpeg_desc *desc, int16_t *coef_host,
                                   int32_t nthreads);
+/* HOST: the file reads of a batch, without Python in the loop and without worker processes (replaces what remains of the reference's
+ * loader workers, engine.py:41-54, once decoding has left the CPU).  ch_io_file_sizes: stat every path; ch_io_read_files: file i ->
+ * dst[offsets[i], offsets[i] + sizes[i]) on `nthreads` threads.  Status 3 + ch_last_error() names the file that failed. */
+int ch_io_file_sizes(const char *const *paths, int32_t n, int64_t *sizes);
+int ch_io_read_files(const char *const *paths, int32_t n, const int64_t *offsets, const int64_t *sizes, uint8_t *dst, int32_t nthreads);
 /* GPU: coefficient blocks -> RGB bytes.  coef_dev: the coefficient buffer on the device; desc_dev / desc_host: the same n descriptors
  * on the device and on the host (the host copy sizes the launch); planes_ws: device workspace of total_plane bytes; pixels: device
  * output (total_pix bytes); images with status != 0 are skipped (their slots are the caller's to fill). */

@@ -121,6 +121,47 @@ def test_training_draws_are_the_cpu_chains_and_the_oracle_reproduces_its_images(
                        gpu_decode=True)
 
 
+def test_file_batch_loader_reads_what_a_dataloader_would_hand_over(tmp_path):
+    """A `gpu_decode` dataset is loaded by `engine.FileBatchLoader` -- in-process reads through `ch_io_file_sizes` / `ch_io_read_files`,
+    no worker processes -- and must hand over the batches `DataLoader(d, bs, shuffle, drop_last, num_workers=0)` would: same index
+    order under the same seed, same targets, the files' exact bytes; a missing file is named in the error."""
+    import ctypes
+    import os
+    import engine
+    from concepthash_amd import _lib
+    from torch.utils.data import DataLoader
+    from utils.datasets import HashingDataset, OneHot
+    root = str(tmp_path)
+    sizes = [(40 + 3 * i, 64 + 5 * i) for i in range(11)]
+    _write_dataset(root, sizes)
+    cpu = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5))
+    jpg = HashingDataset(root, "train.txt", transform=_train_chain(), target_transform=OneHot(5), gpu_decode=True, read_threads=3)
+    fl = engine.dataloader(jpg, 4, shuffle=True, drop_last=True)
+    assert isinstance(fl, engine.FileBatchLoader) and fl.num_workers == 0 and len(fl) == 2
+    for epoch in range(2):                                           # the same loader object, iterated again
+        torch.manual_seed(31 + epoch)
+        want = [(idx.tolist(), tgt) for _, tgt, idx in DataLoader(cpu, 4, shuffle=True, drop_last=True, num_workers=0)]
+        torch.manual_seed(31 + epoch)
+        got = list(fl)
+        assert [b[2].tolist() for b in got] == [w[0] for w in want]
+        for (raw, tgt, idx), (_, wt) in zip(got, want):
+            assert torch.equal(tgt, wt) and raw.boxes.shape == (4, 4) and raw.flips.shape == (4,)
+            for f, i in zip(raw.files, idx.tolist()):
+                assert bytes(f.numpy()) == open(os.path.join(root, "img", f"{i}.jpg"), "rb").read()
+    seq = engine.dataloader(jpg, 4, shuffle=False, drop_last=False)
+    assert [b[2].tolist() for b in seq] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]]
+    # the host helpers themselves: sizes, a short destination offset table, a missing file
+    lib = _lib.load()
+    paths = [os.path.join(root, "img", f"{i}.jpg").encode() for i in range(3)] + [os.path.join(root, "img", "nope.jpg").encode()]
+    arr = (ctypes.c_char_p * 4)(*paths)
+    out = (ctypes.c_int64 * 4)()
+    assert lib.ch_io_file_sizes(arr, 3, out) == 0 and list(out)[:3] == [os.path.getsize(p) for p in paths[:3]]
+    assert lib.ch_io_file_sizes(arr, 4, out) != 0 and b"nope.jpg" in lib.ch_last_error()
+    os.remove(os.path.join(root, "img", "5.jpg"))
+    with pytest.raises(RuntimeError, match="5.jpg"):
+        list(engine.dataloader(jpg, 4, shuffle=False, drop_last=False))
+
+
 @pytest.mark.gpu
 def test_gpu_training_chain_equals_the_pil_chain_bit_for_bit(tmp_path):
     """RandomResizedCrop -> RandomHorizontalFlip -> ToTensor -> normalize on the GPU (crop box + flip per image) against the CPU chain

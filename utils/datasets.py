@@ -192,6 +192,8 @@ class HashingDataset(Dataset):
         self.target_transform = target_transform
         # a TRAINING transform list on a GPU path: the worker keeps the random draws (crop box, flip), the GPU does the arithmetic
         self.augment = gpu_augmentation(self.transform) if self.gpu_preprocess else None
+        self.read_threads = int(kwargs.get("read_threads", 8))
+        self.file_workers = bool(kwargs.get("file_workers", False))   # gpu_decode: DataLoader worker processes instead of in-process reads     # gpu_decode: threads of one batch's file reads (ch_io_read_files)
         self._paths = {}          # index -> resolved path (a worker resolves each file once)
 
     def __len__(self):
@@ -228,16 +230,25 @@ class HashingDataset(Dataset):
             if p is None:
                 p = self._paths[i] = self._resolve(self.items[i][0])
             paths.append(p)
-        lengths = [os.path.getsize(p) for p in paths]
-        data = torch.empty(sum(lengths), dtype=torch.uint8)
+        # sizes and reads by the library's host helpers (ch_io_file_sizes / ch_io_read_files: POSIX reads on a few threads, the GIL
+        # released for the whole batch) -- 256 opens + reads in Python hold the interpreter for milliseconds that the thread launching
+        # GPU work needs
+        import ctypes
+        import numpy as np
+        from concepthash_amd import _lib
+        lib = _lib.load()
+        n = len(paths)
+        enc = [os.fsencode(p) for p in paths]
+        cpaths = (ctypes.c_char_p * n)(*enc)
+        sizes = np.zeros(n, dtype=np.int64)
+        _lib.check(lib.ch_io_file_sizes(cpaths, n, sizes.ctypes.data), "ch_io_file_sizes")
+        offsets = np.zeros(n, dtype=np.int64)
+        np.cumsum(sizes[:-1], out=offsets[1:])
+        lengths = sizes.tolist()
+        data = torch.empty(int(sizes.sum()), dtype=torch.uint8)
+        _lib.check(lib.ch_io_read_files(cpaths, n, offsets.ctypes.data, sizes.ctypes.data, data.data_ptr(), self.read_threads),
+                   "ch_io_read_files")
         view = memoryview(data.numpy())
-        o = 0
-        for p, n in zip(paths, lengths):
-            with open(p, "rb", buffering=0) as f:
-                got = f.readinto(view[o:o + n])
-            if got != n:
-                raise IOError(f"short read of {p}: {got} of {n} bytes")
-            o += n
         targets = [self.target_transform(self.items[i][1]) if self.target_transform is not None else self.items[i][1] for i in indices]
         targets = torch.stack([t if torch.is_tensor(t) else torch.as_tensor(t) for t in targets])
         boxes = flips = None
