@@ -62,7 +62,7 @@ struct Builder {
         if (!t) return nullptr;
         float *d = (float *)alloc(sizeof(float) * numel);
         if (!d) return nullptr;
-        if (hipMemcpy(d, t->data, sizeof(float) * numel, hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMemcpy(d, t->data, sizeof(float) * numel, hipMemcpyDefault) != hipSuccess) {
             ch_set_error("hipMemcpy failed for '" + name + "'");
             ok = false;
         }
@@ -85,7 +85,7 @@ struct Builder {
         }
         if (!dst) dst = (bf16_t *)alloc(sizeof(bf16_t) * rows * cols_pad);
         if (dst) {
-            if (hipMemcpy(tmp, t->data, sizeof(float) * rows * cols, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+            if (hipMemcpy(tmp, t->data, sizeof(float) * rows * cols, hipMemcpyDefault) != hipSuccess) ok = false;
             if (ch_convert_bf16(tmp, rows, cols, cols_pad, dst, s) != 0) ok = false;
             if (hipStreamSynchronize(s) != hipSuccess) ok = false;
         }
@@ -109,8 +109,8 @@ struct Builder {
             const ch_tensor *wt = find(wnames[j], (int64_t)rows_each * D), *bt = find(bnames[j], rows_each);
             if (!wt || !bt) break;
             if (hipMemcpy(w32 + (size_t)j * rows_each * D, wt->data, sizeof(float) * (size_t)rows_each * D,
-                          hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(b32 + (size_t)j * rows_each, bt->data, sizeof(float) * rows_each, hipMemcpyHostToDevice) != hipSuccess)
+                          hipMemcpyDefault) != hipSuccess ||
+                hipMemcpy(b32 + (size_t)j * rows_each, bt->data, sizeof(float) * rows_each, hipMemcpyDefault) != hipSuccess)
                 ok = false;
         }
         bf16_t *w = (bf16_t *)alloc(sizeof(bf16_t) * (size_t)n_pad * D);
@@ -167,7 +167,7 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
         for (int j = 0; j < 3 && B.ok; ++j) {
             B.bf16(pre + "self_attn." + names[j] + ".weight", D, D, D, qkvw + (size_t)j * D * D);
             const ch_tensor *bt = B.find(pre + "self_attn." + names[j] + ".bias", D);
-            if (bt && hipMemcpy(qkvb + (size_t)j * D, bt->data, sizeof(float) * D, hipMemcpyHostToDevice) != hipSuccess)
+            if (bt && hipMemcpy(qkvb + (size_t)j * D, bt->data, sizeof(float) * D, hipMemcpyDefault) != hipSuccess)
                 B.ok = false;
         }
         w.qkv_w = qkvw;
@@ -199,7 +199,7 @@ int build_model(ch_model *m, const ch_tensor *tensors, int ntensors) {
             if (hipMemset(dw, 0, sizeof(bf16_t) * (size_t)m->bpad * D) != hipSuccess) B.ok = false;
             B.bf16(ap + "down_proj.weight", b, D, D, dw);
             const ch_tensor *bt = B.find(ap + "down_proj.bias", b);
-            if (bt && hipMemcpy(db, bt->data, sizeof(float) * b, hipMemcpyHostToDevice) != hipSuccess) B.ok = false;
+            if (bt && hipMemcpy(db, bt->data, sizeof(float) * b, hipMemcpyDefault) != hipSuccess) B.ok = false;
             B.bf16(ap + "up_proj.weight", D, b, m->bpad, uw);
             aw.down_w = dw;
             aw.down_b = db;

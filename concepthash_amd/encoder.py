@@ -120,7 +120,12 @@ class ConceptHashEncoder:
         for k, v in state_dict.items():
             if k.startswith(_SKIP_PREFIXES) or k in _SKIP_KEYS or not torch.is_tensor(v):
                 continue
-            t = v.detach().to("cpu", torch.float32).contiguous()
+            # where it is (a model that was moved to the GPU is ingested device -> device: 572 pageable round trips of a ViT-B/16
+            # were 0.7 s of an evaluation command's first batch); tensors on ANOTHER device go through the host
+            t = v.detach()
+            if t.is_cuda and t.device != self.device:
+                t = t.to("cpu")
+            t = t.to(torch.float32).contiguous()
             keep.append(t)
             entries.append((k.encode(), t))
         arr = (_lib.Tensor * len(entries))()
@@ -130,6 +135,7 @@ class ConceptHashEncoder:
             arr[i].numel = t.numel()
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
+            torch.cuda.current_stream(self.device).synchronize()     # device-resident tensors: whatever produced them has finished
             _lib.check(self.lib.ch_model_create(ctypes.byref(c), arr, len(entries), ctypes.byref(handle)),
                        "ch_model_create")
         self._h = handle

@@ -53,11 +53,12 @@ typedef struct ch_model_config {
     float bn_eps;        /* BatchNorm1d eps (1e-5) */
 } ch_model_config;
 
-/* One named fp32 tensor in HOST memory.  `name` is the reference state_dict key, e.g.
+/* One named fp32 tensor, in host OR device memory (the library copies with hipMemcpyDefault: a model that already sits on the GPU
+ * is ingested without a round trip through the host).  `name` is the reference state_dict key, e.g.
  * "backbone.vision_model.encoder.layers.0.self_attn.q_proj.weight", "hash_fc.weight", "hash_bn.running_var". */
 typedef struct ch_tensor {
     const char *name;
-    const float *data; /* host, fp32, contiguous, PyTorch layout */
+    const float *data; /* host or device, fp32, contiguous, PyTorch layout */
     int64_t numel;
 } ch_tensor;
 

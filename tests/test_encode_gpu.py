@@ -113,6 +113,12 @@ def test_batching_dtype_and_determinism(dev):
     c = enc.encode(xb)
     d = enc.encode(xb.float())                               # bf16 images == the same values given as fp32
     assert torch.equal(c["codes"], d["codes"])
+    # a state dict that already sits on the GPU (what `model.to("cuda")` leaves) is ingested device -> device: the same engine
+    on_gpu = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sd.items()}
+    enc_gpu = _encoder(on_gpu, cfg["heads"], max_batch=4)
+    e = enc_gpu.encode(x)
+    assert all(torch.equal(a[k], e[k]) for k in a)
+    enc_gpu.close()
     enc.close()
 
 

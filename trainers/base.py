@@ -40,6 +40,12 @@ class BaseTrainer:
         self.world_size = dist.get_world_size() if self.distributed else 1
         if self.distributed and self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            # Create the GPU context NOW, before the model is built.  Host memory that was allocated before the HIP runtime came up is
+            # copied to the device on a slow path (measured on MI355X / ROCm 7: the 572 tensors of a ViT-B/16 model built first,
+            # `model.to("cuda")` 2.05 s + 0.22 s of context creation; context first, 0.16 s -- tools/e2e_validation_demo.py phases), and
+            # the reference's order -- build, load the checkpoint, then `.to(device)` (experiments/test_hashing.py:34-43) -- is that case.
+            torch.empty(1, device=self.device)
 
     # ---- loading -------------------------------------------------------------------------------------------------
     def load_criterion(self):
