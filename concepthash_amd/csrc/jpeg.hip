@@ -885,11 +885,11 @@ extern "C" int ch_jpeg_entropy_decode(const uint8_t *const *files, const int64_t
     CH_REQUIRE(n >= 0 && (n == 0 || (files && lens && desc && coef_host)), "jpeg_entropy_decode: null argument");
     if (n == 0) return 0;
     std::atomic<int> next{0};
-    // Each thread decodes an image into its OWN scratch (a 500 x 375 image is 590 KB of blocks: it stays in the core's L2, so the
-    // per-block zero fill + scattered coefficient writes never wait for a line of the destination) and then streams the finished blocks
-    // to the pinned destination with non-temporal stores (no read-for-ownership).  Decoding straight into the pinned buffer made the
-    // call 4-5x slower whenever the buffer's pages sat on the other socket of the host (17-30 ms instead of 5 ms per 256 images on the
-    // MI355X box, bimodal by ring slot: profiles/r04_loader_probe.txt).
+    // Each thread decodes an image into its OWN scratch (a 500 x 375 image is 590 KB of blocks: it stays in the core's L2 while the
+    // per-block zero fill and the scattered coefficient writes happen) and then streams the finished blocks to the (pinned) destination
+    // with non-temporal stores.  Built while chasing a 17-30 ms in-pipeline decode time that turned out to be CPU-quota throttling
+    // (DESIGN.md section 4c): on the MI355X box it measures the same 4.8 ms per 256 images as decoding in place, 5-10 % faster on one
+    // thread; kept because the destination is then written exactly once, front to back.
     auto work = [&]() {
         std::vector<int16_t> scratch;
         for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
