@@ -56,13 +56,7 @@ class RetrievalEvaluation:
         trainer.load_criterion()
         if config.exp not in ("descriptor", "extract"):
             phase("checkpoint", trainer.load_model_state, f"{logdir}/models/{modelfn}.pth")
-        if os.environ.get("CH_DEBUG_PROFILE_TO_DEVICE"):
-            import cProfile, pstats
-            pr = cProfile.Profile(); pr.enable()
-            phase("to_device", trainer.to_device)
-            pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
-        else:
-            phase("to_device", trainer.to_device)
+        phase("to_device", trainer.to_device)
         # one process per GPU: `eval_logdir` defaults to a time-stamped directory (configs/val.yaml), which every rank would
         # compose differently -> rank 0 decides and broadcasts, and only rank 0 writes files
         import torch.distributed as dist
