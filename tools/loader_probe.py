@@ -59,6 +59,7 @@ def main():
         Image.fromarray(np.clip(img + rng.normal(0, 7, img.shape), 0, 255).astype(np.uint8)).save(f"{root}/img/{i}.jpg", "JPEG", quality=85)
     open(root + "/test.txt", "w").write("".join(f"img/{i}.jpg {i % 200}\n" for i in range(nimg)))
     pre = GpuPreprocess(256, 224, out_dtype=torch.bfloat16, device=dev)
+    x_const = syn.synthetic_images(256, cfg["image"]).to(dev, torch.bfloat16)
     dec = GpuJpegDecoder(device=dev)
     ds = HashingDataset(root, "test.txt", target_transform=OneHot(200), gpu_decode=True)
     import engine
@@ -96,9 +97,15 @@ def main():
                 t1 = time.perf_counter()
                 if t_first is None:
                     t_first = t1 - t_all
-                px, sizes = image.finish() if hasattr(image, "staged") else dec.decode(image.files)
-                t2 = time.perf_counter()
-                x = pre(px, sizes)
+                if "--encode-constant" in sys.argv:      # diagnostic: the pipeline runs (reads, entropy decode, uploads) but the consumer
+                    image.slot["busy"] = False           # encodes one resident batch: what do H2D traffic and the pipeline's threads cost?
+                    ev = torch.cuda.Event(); ev.record(); image.slot["event"] = ev
+                    t2 = time.perf_counter()
+                    x = x_const
+                else:
+                    px, sizes = image.finish() if hasattr(image, "staged") else dec.decode(image.files)
+                    t2 = time.perf_counter()
+                    x = pre(px, sizes)
                 t3 = time.perf_counter()
                 enc.encode(x, want=("codes", "packed"))
                 t4 = time.perf_counter()
