@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t *__restrict
     __shared__ int2 bounds;
     const ch_image_desc d = desc[blockIdx.x];
     const int y = blockIdx.y, x = threadIdx.x;
+    if (d.nrows == 0) return;   // block-uniform: an image the host has marked as its own (down-scaling beyond the tap limit)
     if (x == 0) bounds = coeffs_for(d.h, d.nh, y + d.top, kk, 1);
     __syncthreads();
     if (x >= crop) return;

@@ -56,6 +56,7 @@ class GpuPreprocess:
         self._geo = {}
         self._ring = [{"buf": None, "event": None} for _ in range(self._RING)]
         self._ring_pos = 0
+        self.host_routed = 0           # images done by `_host_route` so far
 
     _DESC_DTYPE = np.dtype([("src_offset", "<i8"), ("tmp_offset", "<i8"), ("h", "<i4"), ("w", "<i4"), ("nh", "<i4"), ("nw", "<i4"),
                             ("top", "<i4"), ("left", "<i4"), ("row0", "<i4"), ("nrows", "<i4"), ("stride", "<i4"),
@@ -69,9 +70,11 @@ class GpuPreprocess:
         if g is None:
             nw, nh = _resized_size(w, h, self.resize)
             left, top = int(round((nw - self.crop) / 2.0)), int(round((nh - self.crop) / 2.0))
-            for n_in, n_out in ((w, nw), (h, nh)):
-                if 2 * math.ceil(2.0 * max(n_in / n_out, 1.0)) + 1 > self.max_taps:
-                    raise ValueError(f"a {h}x{w} image needs more than {self.max_taps} filter taps (down-scaling > ~15x)")
+            if any(2 * math.ceil(2.0 * max(n_in / n_out, 1.0)) + 1 > self.max_taps for n_in, n_out in ((w, nw), (h, nh))):
+                # down-scaling beyond ~15x (a 12-megapixel photograph to 256): more filter taps than the kernels hold.  nrows = 0 makes the
+                # kernels skip the image; __call__ runs the chain for it with Pillow on the host (`_host_route`), the reference's own path
+                g = self._geo[key] = (nh, nw, top, left, 0, 0)
+                return g
             r0, _ = _row_bounds(h, nh, top)
             rl, cl = _row_bounds(h, nh, top + self.crop - 1)
             g = self._geo[key] = (nh, nw, top, left, r0, rl + cl - r0)
@@ -103,21 +106,45 @@ class GpuPreprocess:
         if B and ((bx[:, 0] < 0).any() or (bx[:, 1] < 0).any() or (bx[:, 2] < 1).any() or (bx[:, 3] < 1).any()
                   or (bx[:, 0] + bx[:, 2] > hw[:, 0]).any() or (bx[:, 1] + bx[:, 3] > hw[:, 1]).any()):
             raise ValueError("a crop box leaves its image")
-        for n_in in set(bx[:, 2].tolist()) | set(bx[:, 3].tolist()):
-            if 2 * math.ceil(2.0 * max(n_in / self.crop, 1.0)) + 1 > self.max_taps:
-                raise ValueError(f"a {n_in}-pixel box side needs more than {self.max_taps} filter taps (down-scaling > ~15x)")
+        too_big = np.asarray([2 * math.ceil(2.0 * max(max(int(b[2]), int(b[3])) / self.crop, 1.0)) + 1 > self.max_taps for b in bx], dtype=bool)
         desc = np.zeros(B, dtype=self._DESC_DTYPE)
         src = hw[:, 0] * hw[:, 1] * 3
-        tmp = bx[:, 2] * self.crop * 3                      # every source row of the box feeds the vertical pass
+        tmp = np.where(too_big, 0, bx[:, 2]) * self.crop * 3    # every source row of the box feeds the vertical pass
         desc["src_offset"] = np.cumsum(src) - src + (bx[:, 0] * hw[:, 1] + bx[:, 1]) * 3
         desc["tmp_offset"] = np.cumsum(tmp) - tmp
         desc["h"], desc["w"] = bx[:, 2], bx[:, 3]
         desc["nh"] = desc["nw"] = self.crop
-        desc["nrows"] = bx[:, 2]
+        desc["nrows"] = np.where(too_big, 0, bx[:, 2])      # 0: skipped by the kernels, done on the host (`_host_route`)
         desc["stride"] = hw[:, 1]
         if flips is not None:
             desc["flip"] = np.asarray(flips, dtype=np.int64).reshape(B) != 0
-        return desc, int(src.sum()), int(tmp.sum()), int(max(1, bx[:, 2].max())) if B else 1
+        return desc, int(src.sum()), int(tmp.sum()), int(max(1, desc["nrows"].max())) if B else 1
+
+    def _host_route(self, pixels, sizes, desc, boxes, flips, out, stream):
+        """Images the kernels skipped (nrows == 0: down-scaling beyond the tap limit) through Pillow on the host -- rare (a handful of very
+        large photographs in a dataset), exact (it IS the reference's chain), slow (one device -> host copy and one PIL resize per image)."""
+        from PIL import Image
+        mean = torch.tensor(list(self._mean)).view(3, 1, 1)
+        std = torch.tensor(list(self._std)).view(3, 1, 1)
+        offsets = np.cumsum([0] + [h * w * 3 for h, w in sizes])
+        s = stream if stream is not None else torch.cuda.current_stream(pixels.device)
+        for i in np.nonzero(desc["nrows"] == 0)[0]:
+            h, w = sizes[i]
+            s.synchronize()
+            img = Image.fromarray(pixels[int(offsets[i]):int(offsets[i + 1])].view(h, w, 3).cpu().numpy())
+            if boxes is None:
+                nh, nw, top, left = (int(desc[n][i]) for n in ("nh", "nw", "top", "left"))
+                img = img.resize((nw, nh), Image.BICUBIC).crop((left, top, left + self.crop, top + self.crop))
+            else:
+                top, left, bh, bw = (int(v) for v in np.asarray(boxes[i]).reshape(4))
+                img = img.crop((left, top, left + bw, top + bh)).resize((self.crop, self.crop), Image.BICUBIC)
+                if flips is not None and bool(flips[i]):
+                    img = img.transpose(Image.FLIP_LEFT_RIGHT)
+            x = torch.from_numpy(np.array(img, dtype=np.uint8)).permute(2, 0, 1).float().div_(255.0)
+            x = (x - mean) / std
+            with torch.cuda.stream(s):
+                out[i].copy_(x.to(out.dtype).to(out.device, non_blocking=False))
+        self.host_routed += int((desc["nrows"] == 0).sum())
 
     def _stage(self, desc: np.ndarray, device, stream=None) -> torch.Tensor:
         """descriptors -> device without synchronising: through a ring of pinned host buffers and a non-blocking copy (a copy from
@@ -160,4 +187,6 @@ class GpuPreprocess:
             _lib.check(self.lib.ch_preprocess(_lib.ptr(pixels), _lib.ptr(ddev), B, max_rows, self.crop, self._mean, self._std,
                                               _lib.ptr(out), 1 if self.out_dtype == torch.bfloat16 else 0, _lib.ptr(ws),
                                               _lib.stream_ptr(stream)), "ch_preprocess")
+            if (desc["nrows"] == 0).any():
+                self._host_route(pixels, sizes, desc, boxes, flips, out, stream)
         return out

@@ -201,7 +201,9 @@ double ch_model_flops_per_image(const ch_model *m);
  *   nw, nh      size after Resize(size): shorter side = size, the other int(size * long / short);
  *   left, top   CenterCrop origin int(round((n - crop) / 2.0)) (round-half-even);
  *   row0, nrows source rows the vertical pass needs for the crop's rows; tmp_offset: byte offset of this image's
- *               [nrows, crop, 3] intermediate in the workspace.
+ *               [nrows, crop, 3] intermediate in the workspace.  nrows = 0: the kernels leave this image's output slot
+ *               untouched (the host wrapper uses it for images whose down-scaling needs more than ch_preprocess_max_taps()
+ *               filter taps and fills the slot itself).
  * The training transforms of the same configs (configs/dataset/cub200.yaml:13-23: RandomResizedCrop(crop, bicubic) ->
  * RandomHorizontalFlip -> ToTensor -> normalize) use the same kernels: (h, w) is then the SIZE OF THE BOX the host drew
  * (torchvision get_params; PIL crops the box, then resizes it as an image of its own), src_offset points at the box's first

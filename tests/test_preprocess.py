@@ -222,8 +222,20 @@ def test_gpu_preprocess_equals_the_pil_chain_bit_for_bit():
     want = torch.stack([_pil_chain(im, 160, 128, 1) for im in imgs])
     got = GpuPreprocess(160, 128, *_NORMS[1], out_dtype=torch.float32, device=dev)(pixels, sizes).cpu()
     assert torch.equal(got, want)
-    with pytest.raises(ValueError):
-        GpuPreprocess(256, 224, device=dev)(torch.zeros(4200 * 4100 * 3, dtype=torch.uint8, device=dev), [(4200, 4100)])   # 16x down
+    # down-scaling beyond the kernels' tap limit (a 17-megapixel image to 256: 16x): that image goes through Pillow on the host, the
+    # others through the kernels, in the same call -- the batch still equals the PIL chain
+    big = _image(4200, 4100, 5)
+    mixed = [imgs[0], big, imgs[1]]
+    pre = GpuPreprocess(256, 224, *_NORMS[3], out_dtype=torch.float32, device=dev)
+    got = pre(torch.from_numpy(np.concatenate([im.reshape(-1) for im in mixed])).to(dev), [im.shape[:2] for im in mixed]).cpu()
+    assert torch.equal(got, torch.stack([_pil_chain(im, 256, 224, 3) for im in mixed])) and pre.host_routed == 1
+    # the same for a training crop box that large (RandomResizedCrop of nearly the whole image), flipped
+    from utils import transforms as T
+    box = (100, 50, 3900, 4000)                                         # top, left, height, width
+    ref = Image.fromarray(big).crop((box[1], box[0], box[1] + box[3], box[0] + box[2])).resize((224, 224), Image.BICUBIC).transpose(Image.FLIP_LEFT_RIGHT)
+    want = T.normalize_transform(3)(T.ToTensor()(ref))
+    got = pre(torch.from_numpy(big.reshape(-1)).to(dev), [big.shape[:2]], boxes=[box], flips=[True]).cpu()
+    assert torch.equal(got[0], want) and pre.host_routed == 2
     with pytest.raises(TypeError):
         GpuPreprocess(256, 224, device=dev)(pixels.float(), sizes)
 
