@@ -286,6 +286,7 @@ struct BitReader {
     uint64_t acc = 0;   // valid bits are the TOP `bits` bits
     int bits = 0;
     bool marker = false;   // a marker (FF xx, xx != 0) was reached: only zero bits are fed from here on
+    bool eof = false;      // ... or the FILE ended inside the entropy-coded data (a truncated file: libjpeg warns, Pillow raises)
 
     // callers need at most 31 valid bits at a time (a 16-bit code + a 15-bit magnitude): top up only when fewer than 32 are left
     inline void ensure32() {
@@ -322,6 +323,7 @@ struct BitReader {
                     ++p;
                 }
             } else {
+                if (!marker) eof = true;
                 marker = true;
             }
             acc |= (uint64_t)b << (56 - bits);
@@ -608,6 +610,7 @@ int decode_progressive(const uint8_t *d, int64_t n, const ch_jpeg_desc &desc, Pa
                             }
                     }
                 }
+            if (br.eof) return JS_TRUNCATED;
             // the next marker: the reader never steps over one, so it is at or after br.p
             const uint8_t *q = br.p;
             while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0 && q[1] != 0xFF && !(q[1] >= 0xD0 && q[1] <= 0xD7))) ++q;
@@ -672,7 +675,9 @@ int entropy_decode_one(const uint8_t *d, int64_t n, const ch_jpeg_desc &desc, in
             }
         }
     }
-    return JS_OK;
+    // the data ran out before a marker: a truncated file.  What was decoded is zero-padded garbage from there on; Pillow raises on
+    // such a file, so it is handed to the caller's decoder, which will say so
+    return br.eof ? JS_TRUNCATED : JS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -246,7 +246,7 @@ typedef struct ch_jpeg_desc {
     int32_t hs, vs;       /* luma sampling factors: 1x1 (4:4:4), 2x1 (4:2:2), 2x2 (4:2:0); chroma is 1x1 */
     int32_t mcu_w, mcu_h; /* MCUs per row / column */
     int32_t status;       /* 0 = decoded by this path (baseline, extended-sequential and progressive Huffman files); 1 not a JPEG,
-                             2 truncated, 3 lossless / arithmetic coding, or a progressive file whose scans leave DC or the first AC
+                             2 truncated (inside the headers, or -- set by ch_jpeg_entropy_decode -- inside the entropy-coded data), 3 lossless / arithmetic coding, or a progressive file whose scans leave DC or the first AC
                              coefficients above bit 0 (libjpeg smooths those; set by ch_jpeg_entropy_decode), 4 not 8 bit, 5 component
                              count, 6 sampling factors, 7 multi-scan sequential, 8 colour space, 9 tables, 10 smaller than 16x16,
                              11 corrupt entropy data (set by ch_jpeg_entropy_decode) */

@@ -114,7 +114,10 @@ def test_files_outside_the_subset_are_flagged_not_guessed():
     desc, _ = _host_decode([prog, cmyk.getvalue(), tiny, png.getvalue(), good, good[:100], trunc])
     assert list(desc["status"][:5]) == [0, 5, 10, 1, 0]           # (progressive files are decoded since round 4)
     assert desc["status"][5] != 0                                 # cut inside the headers
-    assert desc["status"][6] in (0, 11)                           # cut inside the entropy data: zero-filled tail or flagged corrupt
+    assert desc["status"][6] == 2                                 # cut inside the entropy-coded data: found by the decode, left to PIL (which raises)
+    prog_trunc = prog[: len(prog) * 2 // 3]
+    d2, _ = _host_decode([prog_trunc, good])
+    assert d2["status"][0] != 0 and d2["status"][1] == 0
     assert (desc["height"][0], desc["width"][0]) == (120, 160)    # the size of a file the caller decodes itself is still reported
 
 

@@ -59,7 +59,7 @@ def main():
         result = {"train_images": n, "epochs": a.epochs, "batch_size": a.batch_size, "backbone": a.backbone, "host_cpu_quota": cpu_budget(), "runs": {}}
         for mode in a.modes.split(","):
             logdir = os.path.join(work, "run_" + mode)
-            flags = ["dataset.gpu_decode=true"] if mode == "gpu_decode" else []
+            flags = ["dataset.gpu_decode=true"] if mode == "gpu_decode" else ["dataset.gpu_decode=false", "dataset.gpu_preprocess=false"]
             t0 = time.perf_counter()
             subprocess.run([sys.executable, os.path.join(ROOT, "main_v2.py"), "exp=hashing", "dataset=cub200", "data_dir=" + work, "optim=sgd",
                             "model.backbone.name=" + a.backbone, "model.nbit=64", f"epochs={a.epochs}", "eval_interval=0",

@@ -71,7 +71,8 @@ def main():
                   "host_cpu_quota": cpu_budget(), "generate_s": round(gen_s, 1), "runs": {}}
         hist = {}
         for mode in a.modes.split(","):
-            flags = {"gpu_decode": ["dataset.gpu_decode=true"], "gpu_preprocess": ["dataset.gpu_preprocess=true"], "cpu_loader": []}[mode]
+            flags = {"gpu_decode": ["dataset.gpu_decode=true"], "gpu_preprocess": ["dataset.gpu_decode=false", "dataset.gpu_preprocess=true"],
+                     "cpu_loader": ["dataset.gpu_decode=false", "dataset.gpu_preprocess=false"]}[mode]
             ev = os.path.join(work, "ev_" + mode)
             t0 = time.perf_counter()
             subprocess.run([sys.executable, os.path.join(ROOT, "main_v2.py"), "--config-name", "val.yaml", "logdir=" + logdir,

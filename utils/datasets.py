@@ -75,7 +75,8 @@ def gpu_augmentation(transform):
     if len(rrc) != 1 or len(flips) > 1 or other or items.index(rrc[0]) != 0 or rrc[0].interp != Image.BICUBIC \
             or rrc[0].size[0] != rrc[0].size[1]:
         raise ValueError("gpu_preprocess / gpu_decode: the training transform list must be RandomResizedCrop(square, bicubic) "
-                         "[-> RandomHorizontalFlip] -> ToTensor -> normalize")
+                         "[-> RandomHorizontalFlip] -> ToTensor -> normalize; set dataset.gpu_decode=false dataset.gpu_preprocess=false to run "
+                         "any other list on CPU workers, as the reference does")
     return rrc[0], (flips[0] if flips else None)
 
 
