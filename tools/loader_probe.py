@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Where the time of the `gpu_decode` loader path goes (bench.py `loader_inclusive`): per batch, the wait for the DataLoader, the host
-entropy decode + copies + reconstruct launch, the pre-process launch and the encode launch, with 0 / 2 / 4 worker processes.
-`python tools/loader_probe.py [nimg]` on a GPU box."""
+"""Where the time of the `gpu_decode` loader path goes (bench.py `loader_inclusive`): per batch, the wait for the pipeline, the host
+entropy decode + uploads, the reconstruct / pre-process launches and the encode launch; cgroup throttling counters and CPU seconds per
+thread class per pass.  `python tools/loader_probe.py [nimg] [--matrix] [--workers N] [--encode-constant]
+[--no-thread-limit] [--pretouch] [--affinity N]` on a GPU box."""
 import io, os, sys, tempfile, time, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -79,7 +80,8 @@ def main():
             dl = engine.dataloader(ds, 256, shuffle=False, drop_last=False, workers=nworkers)
             if "--no-thread-limit" in sys.argv:
                 torch.set_num_threads(128)
-            workers, pin, ctx = dl.num_workers, False, f"forkserver threads {threads}"
+            workers, pin = dl.num_workers, False
+            ctx = (f"forkserver, decode threads {threads}" if workers else f"none (in-process file reads), decode threads {threads}")
             tw = td = tp = te = 0.0
             t_first = None
             cs0 = _cpu_stat()
