@@ -77,6 +77,7 @@ def main():
         for rep in range(2):
             for k in ("plan_s", "ring_wait_s", "entropy_s", "enqueue_s", "touch_s"):
                 dec.stats[k] = 0.0
+            ds.file_workers = nworkers > 0 and ("--workers" in sys.argv or "--matrix" in sys.argv)   # DataLoader worker processes reading the files
             dl = engine.dataloader(ds, 256, shuffle=False, drop_last=False, workers=nworkers)
             if "--no-thread-limit" in sys.argv:
                 torch.set_num_threads(128)
