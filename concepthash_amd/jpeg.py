@@ -2,14 +2,16 @@
 
 Reference: the loader workers of `engine.dataloader` (engine.py:41-54) run `PIL.Image.open(path).convert("RGB")` per item -- a full
 libjpeg-turbo decode on a CPU core, ~1-2 ms per 500 x 375 image -- and then the transform chain of configs/dataset/cub200.yaml:31-47.
-A 20k images/s encoder outruns that on any host, so here the workers only READ the files; `GpuJpegDecoder` then
+A 20k images/s encoder outruns that on any host, so here the loader only READS the files (in-process, `engine.FileBatchLoader`);
+`GpuJpegDecoder` then
   1. parses the headers and Huffman-decodes the entropy-coded segments on a pool of host threads (`ch_jpeg_plan`,
      `ch_jpeg_entropy_decode`: plain C++ inside the library, the GIL is released for the whole call) straight into pinned memory,
   2. copies the int16 coefficient blocks to the device (non-blocking) and
   3. runs dequantisation + inverse DCT + chroma upsampling + YCbCr -> RGB on the GPU (`ch_jpeg_reconstruct`),
 leaving decoded RGB bytes in the layout `GpuPreprocess` / `ch_preprocess` consume.  The bytes are BIT-EQUAL to Pillow's
-(tests/test_jpeg.py).  Files outside the supported subset (progressive, CMYK, ...: `ch_jpeg_desc.status != 0`) are decoded with PIL on
-the host -- the reference's own path -- and copied into their slots; `stats` counts them.  There is no CPU fallback for the
+(tests/test_jpeg.py).  Baseline and progressive Huffman files are covered; files outside the supported subset (CMYK, arithmetic coding,
+exotic sampling, truncated data, ...: `ch_jpeg_desc.status != 0`) are decoded with PIL on the host -- the reference's own path -- and copied
+into their slots; `stats` counts them.  There is no CPU fallback for the
 supported files: without the HIP library or a GPU, construction raises."""
 from __future__ import annotations
 
