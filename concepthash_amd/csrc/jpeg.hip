@@ -121,8 +121,11 @@ struct Parsed {
 // status codes (also documented in include/concepthash_hip.h)
 enum {
     JS_OK = 0, JS_NOT_JPEG = 1, JS_TRUNCATED = 2, JS_PROGRESSIVE_OR_OTHER_SOF = 3, JS_PRECISION = 4, JS_COMPONENTS = 5,
-    JS_SAMPLING = 6, JS_MULTISCAN = 7, JS_COLORSPACE = 8, JS_TABLES = 9, JS_TINY = 10, JS_CORRUPT = 11
+    JS_SAMPLING = 6, JS_MULTISCAN = 7, JS_COLORSPACE = 8, JS_TABLES = 9, JS_TINY = 10, JS_CORRUPT = 11, JS_TOO_LARGE = 12
 };
+// Pillow refuses images of more than 2 x MAX_IMAGE_PIXELS (DecompressionBombError): such a file is left to it, so that the caller sees the
+// reference's error instead of a multi-gigabyte coefficient buffer
+constexpr int64_t kMaxPixels = 2 * (int64_t)89478485;
 
 inline int rd16(const uint8_t *p) { return (p[0] << 8) | p[1]; }
 
@@ -175,6 +178,7 @@ void parse(const uint8_t *d, int64_t n, Parsed &P, bool full) {
                 P.ncomp = s[5];
                 if (P.ncomp != 1 && P.ncomp != 3) { P.status = JS_COMPONENTS; return; }
                 if (sl < 6 + 3 * P.ncomp || P.height == 0 || P.width == 0) { P.status = JS_CORRUPT; return; }
+                if ((int64_t)P.width * P.height > kMaxPixels) { P.status = JS_TOO_LARGE; return; }
                 for (int c = 0; c < P.ncomp; ++c) {
                     comp_id[c] = P.comp_id[c] = s[6 + 3 * c];
                     comp_h[c] = s[7 + 3 * c] >> 4;
@@ -251,6 +255,13 @@ void parse(const uint8_t *d, int64_t n, Parsed &P, bool full) {
                 }
                 if (P.width < 16 || P.height < 16) { P.status = JS_TINY; return; }   // the fancy upsamplers' narrow-image special cases
                 P.scan_begin = pos + len;
+                {
+                    // every block costs at least one bit of entropy-coded data (its DC code): a header that announces more blocks than the
+                    // rest of the file has bits is a damaged header, not a reason to allocate them
+                    const int64_t mw = (P.width + 8 * P.hs - 1) / (8 * P.hs), mh = (P.height + 8 * P.vs - 1) / (8 * P.vs);
+                    const int64_t blocks = mw * mh * (P.ncomp == 3 ? P.hs * P.vs + 2 : 1);
+                    if (blocks > 8 * (n - P.scan_begin)) { P.status = JS_TRUNCATED; return; }
+                }
                 return;
             }
             default: break;

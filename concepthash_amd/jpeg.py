@@ -32,7 +32,8 @@ DESC_DTYPE = np.dtype([("coef_offset", "<i8"), ("pix_offset", "<i8"), ("plane_of
 assert DESC_DTYPE.itemsize == ctypes.sizeof(_lib.JpegDesc)
 
 STATUS = {0: "ok", 1: "not a JPEG", 2: "truncated", 3: "lossless / arithmetic / unfinished progressive", 4: "not 8 bit", 5: "component count",
-          6: "sampling factors", 7: "multi-scan", 8: "colour space", 9: "tables", 10: "smaller than 16x16", 11: "corrupt entropy data"}
+          6: "sampling factors", 7: "multi-scan", 8: "colour space", 9: "tables", 10: "smaller than 16x16", 11: "corrupt entropy data",
+          12: "beyond Pillow's decompression-bomb limit"}
 
 
 _libc = None

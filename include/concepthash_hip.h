@@ -249,7 +249,7 @@ typedef struct ch_jpeg_desc {
                              2 truncated (inside the headers, or -- set by ch_jpeg_entropy_decode -- inside the entropy-coded data), 3 lossless / arithmetic coding, or a progressive file whose scans leave DC or the first AC
                              coefficients above bit 0 (libjpeg smooths those; set by ch_jpeg_entropy_decode), 4 not 8 bit, 5 component
                              count, 6 sampling factors, 7 multi-scan sequential, 8 colour space, 9 tables, 10 smaller than 16x16,
-                             11 corrupt entropy data (set by ch_jpeg_entropy_decode) */
+                             11 corrupt entropy data (set by ch_jpeg_entropy_decode), 12 more pixels than Pillow accepts (2 x MAX_IMAGE_PIXELS) */
     int32_t nblocks;      /* 8x8 blocks of all components = coefficient elements / 64 */
     int32_t reserved;
     uint16_t quant[3][64]; /* quantisation tables per component, natural (row-major) order */

@@ -115,10 +115,61 @@ def test_files_outside_the_subset_are_flagged_not_guessed():
     assert list(desc["status"][:5]) == [0, 5, 10, 1, 0]           # (progressive files are decoded since round 4)
     assert desc["status"][5] != 0                                 # cut inside the headers
     assert desc["status"][6] == 2                                 # cut inside the entropy-coded data: found by the decode, left to PIL (which raises)
+    # a damaged frame header that announces a gigantic image: flagged from the header alone (more blocks than the file has bits / more
+    # pixels than Pillow accepts), never allocated
+    sof = good.index(b"\xff\xc0")
+    huge = bytearray(good)
+    huge[sof + 5:sof + 9] = bytes([0xFF, 0xF0, 0xFF, 0xF0])       # 65520 x 65520
+    d3, _ = _host_decode([bytes(huge), good])
+    assert d3["status"][0] in (2, 12) and d3["status"][1] == 0 and int(d3["nblocks"][0]) == 0
     prog_trunc = prog[: len(prog) * 2 // 3]
     d2, _ = _host_decode([prog_trunc, good])
     assert d2["status"][0] != 0 and d2["status"][1] == 0
     assert (desc["height"][0], desc["width"][0]) == (120, 160)    # the size of a file the caller decodes itself is still reported
+
+
+def test_damaged_files_never_crash_the_host_decoder_or_overrun_its_buffer():
+    """The host half parses bytes from disk: whatever is in a file -- flipped bytes, a cut, a stray marker, a damaged header -- the calls
+    return (with some status) and never write past the coefficient buffer the plan sized.  400 mutations of five valid files (baseline,
+    progressive, 4:4:4, 4:2:2 with restart intervals, progressive with restart rows)."""
+    from concepthash_amd import _lib
+    from concepthash_amd.jpeg import DESC_DTYPE
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    seeds = [_jpeg(_image(64, 80, 1), quality=80), _jpeg(_image(48, 64, 2), quality=60, progressive=True),
+             _jpeg(_image(40, 56, 3), quality=90, subsampling=0), _jpeg(_image(33, 47, 4), quality=70, subsampling=1, restart_marker_blocks=3),
+             _jpeg(_image(64, 64, 5), quality=50, progressive=True, restart_marker_rows=1)]
+    seen = set()
+    for it in range(80):
+        batch = []
+        for sd in seeds:
+            b = bytearray(sd)
+            mode = int(rng.integers(0, 4))
+            if mode == 0:
+                for _ in range(int(rng.integers(1, 6))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif mode == 1:
+                b = b[: int(rng.integers(2, len(b)))]
+            elif mode == 2:
+                i = int(rng.integers(2, len(b) - 4))
+                b[i:i + 2] = bytes([0xFF, int(rng.integers(0xC0, 0xFF))])
+            else:
+                b[int(rng.integers(0, min(len(b), 600)))] = int(rng.integers(0, 256))       # the header region
+            batch.append(bytes(b))
+        n = len(batch)
+        bufs = [np.frombuffer(f, dtype=np.uint8) for f in batch]
+        ptrs = (ctypes.c_void_p * n)(*[x.ctypes.data for x in bufs])
+        lens = (ctypes.c_int64 * n)(*[len(f) for f in batch])
+        desc = np.zeros(n, dtype=DESC_DTYPE)
+        tc, tp, tl = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        assert lib.ch_jpeg_plan(ptrs, lens, n, desc.ctypes.data, ctypes.byref(tc), ctypes.byref(tp), ctypes.byref(tl)) == 0
+        assert tc.value <= 64 * 8 * sum(len(f) for f in batch)            # a plan never asks for more blocks than the files have bits
+        coef = np.zeros(tc.value + 64, np.int16)
+        coef[tc.value:] = 777
+        assert lib.ch_jpeg_entropy_decode(ptrs, lens, n, desc.ctypes.data, coef.ctypes.data, 2) == 0
+        assert (coef[tc.value:] == 777).all()
+        seen.update(int(v) for v in desc["status"])
+    assert 0 in seen and len(seen) >= 4                                     # intact-enough files decode, the others are told apart
 
 
 @pytest.mark.gpu
