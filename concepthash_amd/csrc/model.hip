@@ -662,7 +662,7 @@ const OptionRef g_options[] = {
     {"wide_kernel", 0, CH_OPT_FIELD(wide_kernel), 0, 1},
     {"graph_max_batch", 0, CH_OPT_FIELD(graph_max_batch), 0, 1 << 16},
     {"train_chains", 0, CH_OPT_FIELD(train_chains), 1, 2},
-    {"train_chain_min_rows", 2, CH_OPT_FIELD(train_chain_min_rows), 1, (int64_t)1 << 40},
+    {"train_chain_min_rows", 2, CH_OPT_FIELD(train_chain_min_rows), 0, (int64_t)1 << 40},
     {"train_prune_last", 1, CH_OPT_FIELD(train_prune_last), 0, 1},
     {"train_batched_grads", 1, CH_OPT_FIELD(train_batched_grads), 0, 1},
 };

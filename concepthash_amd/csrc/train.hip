@@ -401,7 +401,7 @@ extern "C" int ch_trainer_create(ch_model *m, int32_t max_batch, float *params, 
     t->ad_numel = adapter_numel(c);
     // options of the model the trainer is created on (ch_model_set_option "train_chains" / "train_chain_min_rows" / "train_prune_last")
     t->nchains = std::max(1, std::min(m->train_chains, TR_CHAINS));
-    t->chain_min_rows = std::max<int64_t>(1, m->train_chain_min_rows);
+    t->chain_min_rows = std::max<int64_t>(0, m->train_chain_min_rows);
     t->prune_last = m->train_prune_last;
     t->batched_grads = m->train_batched_grads;
     const int D = c.dim, L = c.layers, M = c.ffn, bpad = m->bpad, Q = c.ncontext;
@@ -517,7 +517,16 @@ extern "C" int ch_train_forward(ch_trainer *t, const void *images, int32_t image
     t->forward_done = false;
     t->attn_all_layers = out_concept_attn != nullptr && concept_attn_all_layers != 0;
     CH_CHECK_HIP(hipMemcpyAsync(t->ctx, concept_tokens, sizeof(float) * c.ncontext * c.dim, hipMemcpyDeviceToDevice, s));
-    t->nc = (t->nchains > 1 && (int64_t)(B / 2) * t->m->ntok >= t->chain_min_rows) ? 2 : 1;
+    {
+        // Two micro-batch chains or one?  Option "train_chain_min_rows" > 0: two when each chain has at least that many token rows.  0 (default):
+        // two when ONE chain's narrowest 256x256-tile GEMM (N = D: out_proj, fc2 and the input-gradient products) would need more than one
+        // round of the chip's 256 CUs -- a second round that is nearly empty is what a single chain pays just above the boundary (batch 112
+        // of ViT-B/16: 264 tiles, 18.4 ms against 16.5 with two chains; batch 96: 228 tiles, 14.3 against 15.5; profiles/r04_train_ab_two_chains.txt)
+        const int64_t rows = (int64_t)B * t->m->ntok;
+        const bool two = t->chain_min_rows > 0 ? (int64_t)(B / 2) * t->m->ntok >= t->chain_min_rows
+                                               : ((rows + 255) / 256) * ((c.dim + 255) / 256) > 256;
+        t->nc = (t->nchains > 1 && B >= 2 && two) ? 2 : 1;
+    }
     if (t->nc == 1) {
         t->Bc[0] = B; t->Bc[1] = 0;
         if (int e = forward_chain(t, 0, images, image_dtype, 0, B, out_hash_features, out_cls, out_concept_attn, s)) return e;
