@@ -111,7 +111,7 @@ SIGNATURES = {
 
 # ch_model_set_option keys (include/concepthash_hip.h) and the DEBUG environment overrides the Python wrapper maps onto them when a
 # handle is created.  The library itself reads no environment variable; code that needs a setting passes `options=` / set_option().
-OPTION_KEYS = ("streams", "ln_fold", "prune_last", "pp_min_k", "small_kernel", "serpentine", "pp_sched", "fused_adapter", "resid_nt",
+OPTION_KEYS = ("streams", "chain_auto", "ln_fold", "prune_last", "pp_min_k", "small_kernel", "serpentine", "pp_sched", "fused_adapter", "resid_nt",
                "nt_out", "group_n", "splitk", "gemm_rows", "wide_kernel", "graph_max_batch", "train_chains", "train_chain_min_rows", "train_prune_last",
                "train_batched_grads")
 _ENV_OVERRIDES = {  # env name -> (option key, value map)
@@ -120,7 +120,7 @@ _ENV_OVERRIDES = {  # env name -> (option key, value map)
     "CH_GEMM_PP_SCHED": ("pp_sched", int), "CH_FUSED_ADAPTER": ("fused_adapter", int),
     "CH_RESID_NT": ("resid_nt", lambda v: 1 if int(v) else -1), "CH_NT_OUT": ("nt_out", lambda v: 1 if int(v) else -1),
     "CH_GEMM_GROUP_N": ("group_n", int), "CH_GEMM_SPLITK": ("splitk", int), "CH_GEMM_ROWS": ("gemm_rows", int), "CH_GEMM_WIDE": ("wide_kernel", int), "CH_GRAPH_MAX_BATCH": ("graph_max_batch", int),
-    "CH_TRAIN_STREAMS": ("train_chains", int), "CH_TRAIN_CHAIN_MIN_ROWS": ("train_chain_min_rows", int),
+    "CH_CHAIN_AUTO": ("chain_auto", int), "CH_TRAIN_STREAMS": ("train_chains", int), "CH_TRAIN_CHAIN_MIN_ROWS": ("train_chain_min_rows", int),
     "CH_TRAIN_PRUNE_LAST": ("train_prune_last", int),
 }
 

@@ -532,7 +532,17 @@ int run_chain(ch_model *mm, int pi, const void *images_all, int image_dtype, int
 // micro-batches whose chains run concurrently (fork/join by events on the caller's stream).
 int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nlayers, hipStream_t s,
                 float *concept_attn = nullptr, bool attn_all_layers = false, bool prune = false) {
-    const int ns = std::min(m->nstreams, B);
+    int ns = std::min(m->nstreams, B);
+    if (ns == 2 && m->chain_auto) {
+        // Two chains are the default because they win from batch 32 up (+2 % there, +8 % at batch 256, +22 % at batch 112, where one
+        // chain's N = D GEMMs are 264 tiles = one round and a sliver).  Below ~5,600 token rows every launch is one tile's latency whatever
+        // its size, and splitting only doubles the launches: batch 4 / 8 / 12 / 16 / 24 of ViT-B/16 measure 2-5 % faster as ONE chain
+        // (1.93 vs 2.03 ms at batch 8) -- profiles/r04_encode_streams_by_batch.txt.  (A second rule, one chain when its N = D GEMMs fill
+        // >= 85 % of exactly one round of tiles, measured +2.6 % on one box and -1.3 % on another at batch 96: not kept.)
+        const int64_t rows = (int64_t)B * m->ntok;
+        if (rows < 5600) ns = 1;
+    }
+    m->last_chains = ns;
     if (ns < 2) return run_chain(m, 0, images, image_dtype, 0, B, nlayers, s, concept_attn, attn_all_layers, prune, B);
     // micro-batch i = images [i*B/ns, (i+1)*B/ns); chain 0 on the caller's stream, the others fork from / join it
     CH_CHECK_HIP(hipEventRecord(m->ev_fork, s));
@@ -647,6 +657,7 @@ struct OptionRef {
 #define CH_OPT_FIELD(name) [](ch_model *m) -> void * { return &m->name; }
 const OptionRef g_options[] = {
     {"streams", 0, CH_OPT_FIELD(nstreams), 1, CH_MAX_STREAMS},
+    {"chain_auto", 1, CH_OPT_FIELD(chain_auto), 0, 1},
     {"ln_fold", 1, CH_OPT_FIELD(ln_fold), 0, 1},
     {"prune_last", 1, CH_OPT_FIELD(prune_last), 0, 1},
     {"pp_min_k", 0, CH_OPT_FIELD(pp_min_k), 0, 1 << 20},
@@ -717,6 +728,7 @@ extern "C" int ch_model_set_option(ch_model *m, const char *key, int64_t value) 
 extern "C" int ch_model_get_option(ch_model *m, const char *key, int64_t *value) {
     CH_REQUIRE(m != nullptr && value != nullptr, "get_option: null model / value");
     if (key && std::string(key) == "graph_replays") { *value = m->graph_replays; return 0; }      // read-only counters (tests, bench)
+    if (key && std::string(key) == "last_chains") { *value = m->last_chains; return 0; }          // chains of the latest ch_encode launch sequence
     if (key && std::string(key) == "graph_captures") { *value = m->graph_captures; return 0; }
     const OptionRef *o = find_option(key);
     if (!o) {

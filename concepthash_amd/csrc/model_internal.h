@@ -105,6 +105,8 @@ struct ch_model {
     int64_t graph_replays = 0, graph_captures = 0;
     // read by ch_trainer_create from the model it is created on
     int train_chains = 2;           // two micro-batch chains when each has >= train_chain_min_rows rows (round 4: -4.6 % at batch 256, -5.3 % at 128)
+    int last_chains = 0;                // (read-only option "last_chains")
+    bool chain_auto = true;             // ch_encode with streams = 2: fall back to one chain for the two measured exceptions (model.hip run_encoder)
     int64_t train_chain_min_rows = 0;   // 0 = by tile rounds (train.hip: ch_train_forward); > 0 = explicit rows-per-chain threshold
     bool train_prune_last = true;
     bool train_batched_grads = true;  // one reduction launch per adapter, one gradient-assembly launch pair per step (train.hip)

@@ -95,9 +95,11 @@ size_t ch_model_device_bytes(const ch_model *m);
  *                          captures).  0 (default) = off: ch_encode then only enqueues kernels and is itself capturable by the caller.
  *                          Bit-identical outputs; measured NEUTRAL on MI355X (batch 8: 2.07 vs 2.09 ms -- small batches are bound by the
  *                          latency of one GEMM tile per launch on the GPU, not by host launch time), hence opt-in.
- *                          (read-only keys of ch_model_get_option: "graph_replays", "graph_captures")
+ *                          (read-only keys of ch_model_get_option: "graph_replays", "graph_captures", "last_chains")
  *   "splitk"        0/1    split-K tail of the 256x256 GEMM (default 0; allocates 64 MiB per chain on first use)
  *   "serpentine"    0/1    alternate the row direction of consecutive launches (default 0)
+ *   "chain_auto"    0/1    with "streams" = 2: use ONE chain for batches of fewer than 5,600 token rows (batch <= 27 of ViT-B/16), where it
+ *                          measures 2-5 % faster.  Default 1; 0 = always split.  Outputs are bit-identical.
  *   "small_kernel", "pp_sched", "fused_adapter", "gemm_rows", "wide_kernel"  experiment kernels: non-zero values need the experiments build
  *   "train_chains" 1..2, "train_chain_min_rows", "train_prune_last" 0/1, "train_batched_grads" 0/1   read by ch_trainer_create from the model it is created on */
 int ch_model_set_option(ch_model *m, const char *key, int64_t value);

@@ -42,3 +42,11 @@ def fixture_images(z):
     if "in/images" in z.files:
         return torch.from_numpy(z["in/images"])
     return bf16_bits_to_f32(z["inbf/images"])
+
+
+@pytest.fixture(autouse=True)
+def _always_split_encode_chains(monkeypatch):
+    """ch_encode falls back to ONE launch chain for small batches (option "chain_auto", default on: fewer than 5,600 token rows).  The
+    fixtures of this suite are that small: without this every two-chain test would silently run one chain.  `test_chain_auto_rule`
+    removes the variable again."""
+    monkeypatch.setenv("CH_CHAIN_AUTO", "0")

@@ -401,3 +401,26 @@ def test_graph_replay_of_small_batches_is_bit_identical(dev):
     assert torch.equal(big["codes"], again["codes"]) and graph.get_option("graph_captures") == caps + 2
     eager.close()
     graph.close()
+
+
+def test_chain_auto_rule(dev, monkeypatch):
+    """Option "chain_auto" (default on): ch_encode launches ONE chain for the batches where that measures faster -- fewer than 5,600 token
+    rows (batch <= 27 of ViT-B/16: every launch is one tile's latency anyway) -- and two everywhere else.  Same bits either way."""
+    from oracle import encoder_oracle as eo
+    monkeypatch.delenv("CH_CHAIN_AUTO", raising=False)
+    cfg = dict(eo.CONFIGS["vit_b16"])
+    cfg["L"] = 2
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    auto = _encoder(sd, cfg["heads"], max_batch=112)
+    split = _encoder(sd, cfg["heads"], max_batch=112, options={"chain_auto": 0})
+    assert auto.get_option("chain_auto") == 1 and auto.get_option("streams") == 2
+    x = eo.synthetic_images(112, cfg["image"]).to(dev).to(torch.bfloat16)
+    for batch, chains in ((8, 1), (24, 1), (32, 2), (96, 2), (112, 2)):
+        a = auto.encode(x[:batch], want=("codes", "packed"))
+        assert auto.get_option("last_chains") == chains, (batch, auto.get_option("last_chains"))
+        b = split.encode(x[:batch], want=("codes", "packed"))
+        assert split.get_option("last_chains") == 2
+        torch.cuda.synchronize()
+        assert torch.equal(a["codes"], b["codes"]) and torch.equal(a["packed"], b["packed"])
+    auto.close()
+    split.close()
