@@ -267,8 +267,9 @@ def main():
         if rank == 0:
             result["hamming"] = hb
 
-    # ---- CPU baselines: oracle on the host cores, bounded samples (rank 0, N == 1 only).  Before the loader blocks: measured after them the
-    # same oracle ran at 0.55-0.65 of its rate (16.5 vs 25-29 images/s, no cgroup throttling; gpurun_out r04n) -- a clean process state, as in rounds 1-3 -------------------------------
+    # ---- CPU baselines: oracle on the host cores, bounded samples (rank 0, N == 1 only).  The value moves between 14 and 29 images/s from
+    # box to box and run to run (same code, 16 threads, no cgroup throttling in either case: where the shared host places the threads);
+    # the cgroup counters of the interval are in the object.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(cpu_baselines(torch, np, syn, sd, cfg, g_np))
 
