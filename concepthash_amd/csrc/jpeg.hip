@@ -442,16 +442,28 @@ inline bool take_restart(BitReader &br, int &next_rst) {
     return true;
 }
 
-// one AC refinement pass over a block (T.81 figure G.7): returns false on a bad code
-inline bool refine_block(BitReader &br, const Huff &ac, int16_t *blk, int Ss, int Se, int Al, int &eobrun) {
+// One AC refinement pass over a block (T.81 figure G.7): returns false on a bad code.  `nz` is the block's map of non-zero coefficients by
+// zig-zag position (kept by the AC passes): the pass has to (a) hand one correction bit to every non-zero coefficient it passes, in order,
+// and (b) count ZERO-history positions for the run lengths -- with the map both are bit operations on the positions that matter, instead
+// of a walk over all 63 positions of every block of every refinement scan.  (Measured: the four refinement scans of a typical file are
+// three quarters of its decode time with or without the map -- ~180 k correction / sign bits per 500 x 375 image at ~8 ns each; the map
+// is worth 9 %: 671 -> 731 images/s per thread against 2,100 for baseline files.  Reading the bits 16 at a time and applying them without
+// branches measured slower, 640.)
+inline bool refine_block(BitReader &br, const Huff &ac, int16_t *blk, uint64_t &nz, int Ss, int Se, int Al, int &eobrun) {
     const int p1 = 1 << Al, m1 = -(1 << Al);
-    int k = Ss;
-    // a coefficient that is already non-zero takes one correction bit as it is passed
-    auto correct = [&](int16_t &c) {
-        if (get_bits(br, 1) && !(c & p1)) c = (int16_t)(c >= 0 ? c + p1 : c + m1);
+    const uint64_t band = (Se == 63 ? ~0ull : ((1ull << (Se + 1)) - 1)) & ~((1ull << Ss) - 1);
+    // correction bits for the non-zero coefficients at the positions of `set`, ascending
+    auto correct = [&](uint64_t set) {
+        while (set) {
+            const int k = __builtin_ctzll(set);
+            set &= set - 1;
+            int16_t &c = blk[kZigzag[k]];
+            if (get_bits(br, 1) && !(c & p1)) c = (int16_t)(c >= 0 ? c + p1 : c + m1);
+        }
     };
+    int k = Ss;
     if (eobrun == 0) {
-        for (; k <= Se; ++k) {
+        while (k <= Se) {
             br.ensure32();
             const int rs = decode_sym(br, ac);
             if (rs < 0) return false;
@@ -466,23 +478,27 @@ inline bool refine_block(BitReader &br, const Huff &ac, int16_t *blk, int Ss, in
                 if (r) eobrun += get_bits(br, r);
                 break;                                   // the rest of the band belongs to the end-of-band run (below)
             }
-            // advance over r ZERO-history coefficients, correcting the non-zero ones met on the way
-            for (; k <= Se; ++k) {
-                int16_t &c = blk[kZigzag[k]];
-                if (c) correct(c);
-                else if (--r < 0) break;
+            // position of the (r + 1)-th zero-history coefficient at or after k; the non-zero ones in front of it take their bits
+            const uint64_t from = ~((1ull << k) - 1) & band;
+            uint64_t zeros = ~nz & from;
+            for (; r > 0 && zeros; --r) zeros &= zeros - 1;
+            if (!zeros) {                                // the band ends first: legal for a run of zeros (ZRL), not for a coefficient
+                correct(nz & from);
+                if (value) return false;
+                k = Se + 1;
+                break;
             }
+            const int pos = __builtin_ctzll(zeros);
+            correct(nz & from & ((1ull << pos) - 1));
             if (value) {
-                if (k > Se) return false;
-                blk[kZigzag[k]] = (int16_t)value;
+                blk[kZigzag[pos]] = (int16_t)value;
+                nz |= 1ull << pos;
             }
+            k = pos + 1;
         }
     }
     if (eobrun > 0) {
-        for (; k <= Se; ++k) {
-            int16_t &c = blk[kZigzag[k]];
-            if (c) correct(c);
-        }
+        if (k <= Se) correct(nz & band & ~((1ull << k) - 1));
         --eobrun;
     }
     return true;
@@ -498,6 +514,7 @@ int decode_progressive(const uint8_t *d, int64_t n, const ch_jpeg_desc &desc, Pa
         grid[2] = {grid[1].base + (int64_t)64 * desc.mcu_w * desc.mcu_h, desc.mcu_w, 1, 1, (cw + 7) / 8, (chh + 7) / 8};
     }
     std::memset(coef, 0, sizeof(int16_t) * 64 * (size_t)desc.nblocks);
+    std::vector<uint64_t> nzmap((size_t)desc.nblocks, 0);   // per block: non-zero AC coefficients by zig-zag position (refine_block)
     int8_t coef_al[3][10];   // successive-approximation bit of the last scan that carried zig-zag coefficient 0..9; -1 = never seen
     std::memset(coef_al, -1, sizeof(coef_al));
     int restart = P.restart;
@@ -606,6 +623,7 @@ int decode_progressive(const uint8_t *d, int64_t n, const ch_jpeg_desc &desc, Pa
                                             k += r;
                                             if (k > Se) return JS_CORRUPT;
                                             blk[kZigzag[k]] = (int16_t)(extend(get_bits(br, sz), sz) * (1 << Al));
+                                            nzmap[(size_t)(blk - coef) >> 6] |= 1ull << k;
                                         } else if (r == 15) {
                                             k += 15;
                                         } else {
@@ -615,7 +633,7 @@ int decode_progressive(const uint8_t *d, int64_t n, const ch_jpeg_desc &desc, Pa
                                             break;
                                         }
                                     }
-                                } else if (!refine_block(br, P.ac[ta[i]], blk, Ss, Se, Al, eobrun)) {
+                                } else if (!refine_block(br, P.ac[ta[i]], blk, nzmap[(size_t)(blk - coef) >> 6], Ss, Se, Al, eobrun)) {
                                     return JS_CORRUPT;
                                 }
                             }
