@@ -11,12 +11,14 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libconcepthash_hip.so")
 SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip",
-           "preprocess.hip", "train_kernels.hip", "attention_bwd.hip", "train.hip", "jpeg.hip"]
+           "preprocess.hip", "train_kernels.hip", "attention_bwd.hip", "train.hip", "jpeg.hip", "jpeg_host.cpp", "errors.cpp"]
+# plain C++ sources (no HIP): compiled by the same driver as host code; tests/test_jpeg.py also builds them with g++ -fsanitize=address,undefined
+HOST_SOURCES = ["jpeg_host.cpp", "errors.cpp"]
 # kernels that lost to the dispatched ones (DESIGN.md sections 3.8-3.9): kept in csrc/experiments/ with their parity tests, compiled
 # only into an experiments build (CH_BUILD_EXPERIMENTS=1), never into the product library
 EXPERIMENT_SOURCES = [os.path.join("experiments", f) for f in ("gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "gemm_r4.hip",
                                                                 "adapter_fused.hip", "gemm_rows.hip", "gemm_wide.hip")]
-HEADERS = ["ch_common.h", "kernels.h", "gemm_epilogue.h", "model_internal.h", os.path.join("..", "..", "include", "concepthash_hip.h"),
+HEADERS = ["ch_common.h", "ch_host.h", "kernels.h", "gemm_epilogue.h", "model_internal.h", os.path.join("..", "..", "include", "concepthash_hip.h"),
            os.path.join("..", "..", "include", "concepthash_hip_debug.h")]
 # attention post-processes every MFMA result on the VALU: keep accumulators in VGPRs (no v_accvgpr_read round trips)
 # preprocess reproduces Pillow's double-precision filter coefficients bit for bit: no fused multiply-adds there
@@ -54,10 +56,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in sources:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJDIR, os.path.basename(src).replace(".hip", ".o"))
+        op = os.path.join(OBJDIR, os.path.basename(src).replace(".hip", ".o").replace(".cpp", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + hdrs):
-            jobs.append([hipcc] + flags + ["-I", CSRC] + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op])
+            if src in HOST_SOURCES:       # plain C++: no offload pass
+                jobs.append([hipcc, "-x", "c++", "-O3", "-std=c++17", "-fPIC", "-Wall", "-I", CSRC, "-c", sp, "-o", op])
+            else:
+                jobs.append([hipcc] + flags + ["-I", CSRC] + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:

@@ -37,21 +37,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// ---- host-side error plumbing ----------------------------------------------------------------------------
-void ch_set_error(const std::string &msg);
+// ---- host-side error plumbing (ch_set_error, CH_REQUIRE: ch_host.h, shared with the plain C++ sources) -------
+#include "ch_host.h"
 #define CH_CHECK_HIP(expr)                                                                                   \
     do {                                                                                                     \
         hipError_t _e = (expr);                                                                              \
         if (_e != hipSuccess) {                                                                              \
             ch_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
             return 1;                                                                                        \
-        }                                                                                                    \
-    } while (0)
-#define CH_REQUIRE(cond, msg)                                                                                \
-    do {                                                                                                     \
-        if (!(cond)) {                                                                                       \
-            ch_set_error(std::string("invalid argument: ") + (msg));                                         \
-            return 2;                                                                                        \
         }                                                                                                    \
     } while (0)
 #define CH_LAUNCH_CHECK()                                                                                    \

@@ -12,10 +12,7 @@
 #include "ch_common.h"
 #include "kernels.h"
 
-static thread_local std::string g_last_error;
-thread_local ch_prof_pair g_ch_prof_pair;
-void ch_set_error(const std::string &msg) { g_last_error = msg; }
-extern "C" const char *ch_last_error(void) { return g_last_error.c_str(); }
+thread_local ch_prof_pair g_ch_prof_pair;   // (the last-error string lives in errors.cpp)
 extern "C" int ch_abi_version(void) { return CH_ABI_VERSION; }
 
 #include "model_internal.h"

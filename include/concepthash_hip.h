@@ -237,7 +237,7 @@ int32_t ch_preprocess_max_taps(void);
  * what is data-parallel (dequantise + 8x8 inverse DCT + chroma upsampling + YCbCr -> RGB), writing decoded RGB bytes in the layout
  * ch_preprocess reads.  Integer arithmetic restated from libjpeg-turbo (jidctint.c, jdsample.c, jdcolor.c): the bytes are bit-equal
  * to Pillow's.  Files outside the supported subset get status != 0 and are decoded by the caller's host decoder (PIL, the
- * reference's own path); see csrc/jpeg.hip for the subset.
+ * reference's own path); see csrc/jpeg_host.cpp for the subset (plain C++: the host half; csrc/jpeg.hip holds the kernels).
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct ch_jpeg_desc {
     int64_t coef_offset;  /* int16 elements from the batch coefficient buffer to this image's first block */

@@ -172,6 +172,79 @@ def test_damaged_files_never_crash_the_host_decoder_or_overrun_its_buffer():
     assert 0 in seen and len(seen) >= 4                                     # intact-enough files decode, the others are told apart
 
 
+_SAN_SCRIPT = r"""
+import ctypes, io, sys
+import numpy as np
+from PIL import Image
+lib = ctypes.CDLL(sys.argv[1])
+lib.ch_jpeg_plan.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+lib.ch_jpeg_entropy_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+rng = np.random.default_rng(11)
+def jpeg(h, w, **kw):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(127 + 100 * np.sin(xx / 9.0 + c) * np.cos(yy / 7.0)) for c in range(3)], -1) + rng.normal(0, 12, (h, w, 3))
+    bio = io.BytesIO()
+    Image.fromarray(np.clip(img, 0, 255).astype(np.uint8)).save(bio, "JPEG", **kw)
+    return bio.getvalue()
+seeds = [jpeg(64, 80, quality=80), jpeg(48, 64, quality=60, progressive=True), jpeg(40, 56, quality=90, subsampling=0),
+         jpeg(33, 47, quality=70, subsampling=1, restart_marker_blocks=3), jpeg(64, 64, quality=50, progressive=True, restart_marker_rows=1),
+         jpeg(200, 120, quality=95, progressive=True, optimize=True)]
+DESC = 448
+files = 0
+for it in range(int(sys.argv[2])):
+    batch = []
+    for sd in seeds:
+        b = bytearray(sd)
+        mode = int(rng.integers(0, 5))
+        if mode == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif mode == 1:
+            b = b[: int(rng.integers(2, len(b)))]
+        elif mode == 2:
+            i = int(rng.integers(2, len(b) - 4)); b[i:i + 2] = bytes([0xFF, int(rng.integers(0xC0, 0xFF))])
+        elif mode == 3:
+            b[int(rng.integers(0, min(len(b), 600)))] = int(rng.integers(0, 256))
+        batch.append(bytes(b))                       # mode 4: the intact file
+    n = len(batch)
+    bufs = [np.frombuffer(f, dtype=np.uint8).copy() for f in batch]      # exact-size heap copies: an over-read is an ASan report
+    ptrs = (ctypes.c_void_p * n)(*[x.ctypes.data for x in bufs])
+    lens = (ctypes.c_int64 * n)(*[len(f) for f in batch])
+    desc = np.zeros(n * DESC, dtype=np.uint8)
+    tc = ctypes.c_int64()
+    assert lib.ch_jpeg_plan(ptrs, lens, n, desc.ctypes.data, ctypes.byref(tc), None, None) == 0
+    coef = np.zeros(max(tc.value, 1), np.int16)      # exact size: an overrun is an ASan report
+    assert lib.ch_jpeg_entropy_decode(ptrs, lens, n, desc.ctypes.data, coef.ctypes.data, 2) == 0
+    files += n
+print("sanitizer run over", files, "files: clean")
+"""
+
+
+def test_host_decoder_under_address_and_ub_sanitizers(tmp_path):
+    """The host half of the decode split is plain C++ (csrc/jpeg_host.cpp + errors.cpp): built here with g++ -fsanitize=address,undefined
+    and driven with intact and damaged files -- flipped bytes, cuts, stray markers, damaged headers -- on exact-size heap buffers, in a
+    subprocess with the sanitizer runtime preloaded.  Any out-of-bounds read or write, use after free or undefined shift fails the test."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    gxx = shutil.which("g++")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip() if gxx else ""
+    if not gxx or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("g++ / libasan not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "concepthash_amd", "csrc")
+    so = str(tmp_path / "libjpeg_host_san.so")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-shared", "-fPIC", "-pthread", "-I", csrc, os.path.join(csrc, "jpeg_host.cpp"), os.path.join(csrc, "errors.cpp"), "-o", so],
+                   check=True)
+    script = tmp_path / "san_fuzz.py"
+    script.write_text(_SAN_SCRIPT)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, str(script), so, "60"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "clean" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 @pytest.mark.gpu
 def test_gpu_jpeg_decoder_equals_pillow_bit_for_bit():
     from concepthash_amd.jpeg import GpuJpegDecoder, decode_to_list

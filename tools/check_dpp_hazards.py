@@ -267,17 +267,17 @@ def product_objects():
     from concepthash_amd.build import EXPERIMENT_SOURCES, SOURCES
     stamp = os.path.join(build, "experiments.flag")
     experiments = os.path.exists(stamp) and open(stamp).read().strip() == "1"
-    return [os.path.join(build, os.path.basename(s).replace(".hip", ".o")) for s in SOURCES + (EXPERIMENT_SOURCES if experiments else [])]
+    return [os.path.join(build, os.path.splitext(os.path.basename(s))[0] + ".o") for s in SOURCES + (EXPERIMENT_SOURCES if experiments else [])]
 
 
 def expects_device_code(obj):
     """True when the object's source defines kernels (`__global__`): then a failed extraction is an error, not 'host-only object'."""
     sys.path.insert(0, ROOT)
     from concepthash_amd.build import CSRC, EXPERIMENT_SOURCES, SOURCES
-    base = os.path.basename(obj).replace(".o", ".hip")
+    stem = os.path.splitext(os.path.basename(obj))[0]
     for s in SOURCES + EXPERIMENT_SOURCES:
-        if os.path.basename(s) == base:
-            return "__global__" in open(os.path.join(CSRC, s)).read()
+        if os.path.splitext(os.path.basename(s))[0] == stem:
+            return s.endswith(".hip") and "__global__" in open(os.path.join(CSRC, s)).read()   # plain C++ sources have no device code
     return True
 
 
