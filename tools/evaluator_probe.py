@@ -18,7 +18,7 @@ def main():
     dev = torch.device("cuda", 0)
     cfg = syn.CONFIGS["vit_b16"]
     sd = syn.synthetic_state_dict(cfg, nbit=64, nclass=200, seed=42)
-    B = 256
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     from concepthash_amd import config as cfglib
     from concepthash_amd.preprocess import GpuPreprocess
     from models.arch.coop import LGHWithFixedPrompt

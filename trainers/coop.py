@@ -149,10 +149,21 @@ class COOPTrainer(BaseTrainer):
         with torch.no_grad():
             (image, labels, index), output = self.compute_features_one_batch(data)
             n = image.size(0)
-            target = labels if self.config.dataset.get("multiclass") else labels.argmax(1)
-            loss = self.criterion(output, target)
-            vals = {"loss": loss}
-            vals.update(self.criterion.losses)
-            vals.update(self._accuracies(output, labels))
-            self._record(meters, vals, n)
+            side = getattr(meters, "stream", None)
+            if side is not None:
+                # the bookkeeping of this batch goes to the meters' stream: it waits for the forward, reads the outputs there (recorded on
+                # it for the allocator) and leaves the main stream free for the next batch's pre-processing and encode
+                main = torch.cuda.current_stream(self.device)
+                side.wait_stream(main)
+                for t in list(output.values()) + [labels]:
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(side)
+            import contextlib
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                target = labels if self.config.dataset.get("multiclass") else labels.argmax(1)
+                loss = self.criterion(output, target)
+                vals = {"loss": loss}
+                vals.update(self.criterion.losses)
+                vals.update(self._accuracies(output, labels))
+                self._record(meters, vals, n)
         return {"codes": output["codes"], "labels": labels}

@@ -47,7 +47,9 @@ class DeviceMeters:
     update_many({name: 0-dim tensor or float}, n): sum[name] += value * n, no host synchronisation.
     finalize() -> OrderedDict name -> AverageMeter (ONE device -> host copy).
     snapshot() / latest(): asynchronous copy of the sums into pinned memory for progress lines -- `latest()` returns the averages of
-    the newest snapshot whose copy has completed (never waits)."""
+    the newest snapshot whose copy has completed (never waits).
+    `stream` (optional, a torch.cuda.Stream): every device operation of the meters runs on it -- the evaluation loop computes the loss
+    terms and accuracies of batch i there, beside the encode of batch i + 1 (trainers/coop.py: inference_one_batch)."""
 
     CAP = 64
 
@@ -60,6 +62,11 @@ class DeviceMeters:
         self._sums = torch.zeros(self.CAP, dtype=torch.float64, device=self.device)
         self._host = {}                  # float values given by the caller: plain host sums
         self._snaps = []                 # (event, pinned tensor, counts copy, names copy)
+        self.stream = None
+
+    def _on_stream(self):
+        import contextlib
+        return self._torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def __getitem__(self, name):
         return _Slot(self, name)
@@ -88,11 +95,12 @@ class DeviceMeters:
         if not dev_vals:
             return
         slots = [self._slot(nm) for nm in dev_names]
-        vals = torch.stack(dev_vals)                                       # one launch
-        if slots == list(range(slots[0], slots[0] + len(slots))):          # the usual case: same meters, same order, every batch
-            self._sums[slots[0]:slots[0] + len(slots)].add_(vals, alpha=float(n))   # one launch (fp32 -> fp64 promotion in place)
-        else:
-            self._sums.index_add_(0, torch.tensor(slots, device=self.device), vals.double() * float(n))
+        with self._on_stream():
+            vals = torch.stack(dev_vals)                                       # one launch
+            if slots == list(range(slots[0], slots[0] + len(slots))):          # the usual case: same meters, same order, every batch
+                self._sums[slots[0]:slots[0] + len(slots)].add_(vals, alpha=float(n))   # one launch (fp32 -> fp64 promotion in place)
+            else:
+                self._sums.index_add_(0, torch.tensor(slots, device=self.device), vals.double() * float(n))
         for s in slots:
             self._count[s] += n
 
@@ -113,7 +121,8 @@ class DeviceMeters:
         return out
 
     def finalize(self):
-        sums = self._sums[:max(1, len(self._idx))].cpu() if self._idx else []
+        with self._on_stream():
+            sums = self._sums[:max(1, len(self._idx))].cpu() if self._idx else []
         return self._to_meters(sums, self._count, self._idx, self._host)
 
     def snapshot(self):
@@ -122,9 +131,10 @@ class DeviceMeters:
             return
         k = len(self._idx)
         pinned = torch.empty(k, dtype=torch.float64, pin_memory=True)
-        pinned.copy_(self._sums[:k], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        with self._on_stream():
+            pinned.copy_(self._sums[:k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
         self._snaps.append((ev, pinned, list(self._count), OrderedDict(self._idx), dict(self._host)))
         self._snaps = self._snaps[-4:]
 
