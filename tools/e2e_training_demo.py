@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--backbone", default="openai/clip-vit-base-patch16")
     ap.add_argument("--modes", default="gpu_decode,cpu_loader")
     ap.add_argument("--out", default="")
+    ap.add_argument("--extra", default="", help="extra command-line overrides for every run, comma separated (e.g. meter_stream=false)")
     a = ap.parse_args()
     import numpy as np
     from PIL import Image
@@ -63,7 +64,8 @@ def main():
             t0 = time.perf_counter()
             subprocess.run([sys.executable, os.path.join(ROOT, "main_v2.py"), "exp=hashing", "dataset=cub200", "data_dir=" + work, "optim=sgd",
                             "model.backbone.name=" + a.backbone, "model.nbit=64", f"epochs={a.epochs}", "eval_interval=0",
-                            f"batch_size={a.batch_size}", "logdir=" + logdir] + flags, check=True, env=env, cwd=work)
+                            f"batch_size={a.batch_size}", "logdir=" + logdir] + flags + [x for x in a.extra.split(",") if x],
+                           check=True, env=env, cwd=work)
             sec = time.perf_counter() - t0
             hist = json.load(open(os.path.join(logdir, "train_history.json")))
             ep = [round(h.get("train_seconds", 0.0), 2) for h in hist]

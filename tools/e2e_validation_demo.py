@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=64)     # configs/val.yaml:10
     ap.add_argument("--modes", default="gpu_decode,gpu_preprocess,cpu_loader")
     ap.add_argument("--out", default="")
+    ap.add_argument("--extra", default="", help="extra command-line overrides for every run, comma separated (e.g. meter_stream=false)")
     a = ap.parse_args()
     import numpy as np
     from PIL import Image
@@ -76,7 +77,8 @@ def main():
             ev = os.path.join(work, "ev_" + mode)
             t0 = time.perf_counter()
             subprocess.run([sys.executable, os.path.join(ROOT, "main_v2.py"), "--config-name", "val.yaml", "logdir=" + logdir,
-                            f"batch_size={a.batch_size}", "eval_logdir=" + ev] + common + flags, check=True, env=env, cwd=work)
+                            f"batch_size={a.batch_size}", "eval_logdir=" + ev] + common + flags + [x for x in a.extra.split(",") if x],
+                           check=True, env=env, cwd=work)
             sec = time.perf_counter() - t0
             hist[mode] = json.load(open(os.path.join(ev, "history.json")))
             result["runs"][mode] = {"wall_s": round(sec, 2), "images_per_s_whole_command": round(n / sec, 1), "mAP": hist[mode]["mAP"],

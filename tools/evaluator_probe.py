@@ -95,6 +95,9 @@ def main():
     timeit("(b) GPU pre-process + model.eval() forward (all outputs)", b)
     timeit("(c) inference_one_batch: (b) + LGHLoss + accuracies + device meters", c)
     timeit("(d) inference_one_epoch(return_codes=True)", lambda: tr.inference_one_epoch("test", True))
+    for flag in (False, True, False, True):          # same-process A/B of the meters' side stream (config key `meter_stream`)
+        tr.config["meter_stream"] = flag
+        timeit(f"(d) inference_one_epoch, meter_stream={flag}", lambda: tr.inference_one_epoch("test", True))
     host_only()
 
 
