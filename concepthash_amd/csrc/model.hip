@@ -557,6 +557,8 @@ int run_encoder(ch_model *m, const void *images, int image_dtype, int B, int nla
 }
 
 void drop_graphs(ch_model *m) {
+    // a replay may still be executing: destroy an executable graph only when the device has drained (opt-in path, rare call)
+    if (!m->graphs.empty()) (void)hipDeviceSynchronize();
     for (auto &kv : m->graphs) {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
