@@ -28,7 +28,9 @@ extern "C" {
 
 /* 2 (round 4): ch_encode / ch_train_forward take the layout of the concept-attention tap as an argument (ch_model_set_concept_attn_layers
  * is gone), ch_model_profile_end takes the capacity of the caller's arrays, ch_model_set_option / ch_model_get_option replace every
- * environment variable the library used to read. */
+ * environment variable the library used to read.
+ * 3 (late round 4): ch_image_desc gained `stride` and `flip` (56 bytes: the training transforms through ch_preprocess); ch_tensor.data may be a
+ * device pointer; new entry points ch_jpeg_* (decode split), ch_io_file_sizes / ch_io_read_files (batch file reads). */
 #define CH_ABI_VERSION 3
 
 typedef struct ch_model ch_model; /* opaque: weights (bf16/fp32, device) + activation workspace */
