@@ -164,14 +164,18 @@ __device__ __forceinline__ void ycc_to_rgb(int Y, int cb, int cr, uint8_t *rgb) 
     rgb[2] = (uint8_t)clamp255(Y + ((116130 * cb + 32768) >> 16));
 }
 
-// One thread per FOUR horizontally adjacent pixels (x0 = 4 t): the luma bytes come as one 32-bit load, the twelve output bytes leave as
-// three 32-bit stores when the row start allows it (one thread per pixel issued three strided byte stores per lane: 281 us per 256
-// images of 500 x 375 for 190 MB -- six times the traffic floor).  The arithmetic per pixel is unchanged.
+// One thread per FOUR horizontally adjacent pixels (x0 = 4 t), a workgroup = 64 threads x 4 rows (256 pixels x 4 rows: a 500-pixel row
+// wastes 2 % of the lanes; one 1,024-pixel strip per workgroup wasted half of them): the luma bytes come as one 32-bit load, the twelve
+// output bytes leave as three 32-bit stores when the row start allows it (one thread per pixel issued three strided byte stores per
+// lane: 281 us per 256 images of 500 x 375 for 190 MB -- six times the traffic floor).  The four pixels share their chroma
+// neighbourhood: samples i - 1 .. i + 2 (i = x0 / 2) of one row (h2v1) or of the nearer and the farther row (h2v2), loaded once with
+// the index CLAMPED to the plane -- which is jdsample.c's edge rule exactly: (3 c + c + 8) >> 4 == (4 c + 8) >> 4 at the left edge,
+// (3 c + c + 7) >> 4 == (4 c + 7) >> 4 at the right one, (3 v + v + 1|2) >> 2 == v for h2v1.
 __global__ __launch_bounds__(256) void jpeg_color_kernel(const ch_jpeg_desc *__restrict__ descs, const uint8_t *__restrict__ planes,
                                                          uint8_t *__restrict__ pixels) {
     const ch_jpeg_desc &d = descs[blockIdx.z];
     if (d.status) return;
-    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
     if (x0 >= d.width || y >= d.height) return;
     const int npx = min(4, d.width - x0);
     const int ypitch = d.mcu_w * d.hs * 8, yrows = d.mcu_h * d.vs * 8;
@@ -186,13 +190,48 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const ch_jpeg_desc *__r
         const int cpitch = d.mcu_w * 8;
         const uint8_t *pcb = py + (int64_t)ypitch * yrows, *pcr = pcb + (int64_t)cpitch * d.mcu_h * 8;
         const int dw = (d.width + d.hs - 1) / d.hs, dh = (d.height + d.vs - 1) / d.vs;
+        int cbv[4], crv[4];
+        if (d.hs == 2 && d.vs <= 2) {
+            const int i = x0 >> 1;
+            int col[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = min(x0 + j, d.width - 1);     // (lanes past the right edge recompute the last pixel; not stored)
-            const int cb = chroma_at(pcb, cpitch, dw, dh, d.hs, d.vs, x, y) - 128;
-            const int cr = chroma_at(pcr, cpitch, dw, dh, d.hs, d.vs, x, y) - 128;
-            ycc_to_rgb((int)((yw >> (8 * j)) & 255), cb, cr, rgb + 3 * j);
+            for (int k = 0; k < 4; ++k) col[k] = min(max(i - 1 + k, 0), dw - 1);
+            int sb[4], sr[4], rnd_even, rnd_odd, shift;
+            if (d.vs == 1) {   // h2v1_fancy_upsample
+                const int64_t r0 = (int64_t)y * cpitch;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sb[k] = pcb[r0 + col[k]];
+                    sr[k] = pcr[r0 + col[k]];
+                }
+                rnd_even = 1, rnd_odd = 2, shift = 2;
+            } else {           // h2v2_fancy_upsample: column sums 3 * nearer row + farther row (chroma_at)
+                const int r = y >> 1;
+                int far = (y & 1) ? r + 1 : r - 1;
+                far = far < 0 ? 0 : far > dh - 1 ? dh - 1 : far;
+                const int64_t r0 = (int64_t)r * cpitch, r1 = (int64_t)far * cpitch;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    sb[k] = 3 * pcb[r0 + col[k]] + pcb[r1 + col[k]];
+                    sr[k] = 3 * pcr[r0 + col[k]] + pcr[r1 + col[k]];
+                }
+                rnd_even = 8, rnd_odd = 7, shift = 4;
+            }
+            // pixel x0 + j sits on sample i + (j >> 1) = s[1 + (j >> 1)]; an even pixel leans on the sample to its left, an odd one right
+            cbv[0] = (3 * sb[1] + sb[0] + rnd_even) >> shift; crv[0] = (3 * sr[1] + sr[0] + rnd_even) >> shift;
+            cbv[1] = (3 * sb[1] + sb[2] + rnd_odd) >> shift;  crv[1] = (3 * sr[1] + sr[2] + rnd_odd) >> shift;
+            cbv[2] = (3 * sb[2] + sb[1] + rnd_even) >> shift; crv[2] = (3 * sr[2] + sr[1] + rnd_even) >> shift;
+            cbv[3] = (3 * sb[2] + sb[3] + rnd_odd) >> shift;  crv[3] = (3 * sr[2] + sr[3] + rnd_odd) >> shift;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = min(x0 + j, d.width - 1);     // (lanes past the right edge recompute the last pixel; not stored)
+                cbv[j] = chroma_at(pcb, cpitch, dw, dh, d.hs, d.vs, x, y);
+                crv[j] = chroma_at(pcr, cpitch, dw, dh, d.hs, d.vs, x, y);
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ycc_to_rgb((int)((yw >> (8 * j)) & 255), cbv[j] - 128, crv[j] - 128, rgb + 3 * j);
     }
     uint8_t *out = pixels + d.pix_offset + ((int64_t)y * d.width + x0) * 3;
     if (npx == 4 && (((uintptr_t)out) & 3) == 0) {
@@ -227,8 +266,8 @@ extern "C" int ch_jpeg_reconstruct(const int16_t *coef_dev, const ch_jpeg_desc *
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((max_blocks + 127) / 128), n), dim3(128), 0, s, coef_dev, desc_dev, planes_ws);
     CH_LAUNCH_CHECK();
-    CH_REQUIRE(max_h <= 65535, "jpeg_reconstruct: image taller than 65535 rows");
-    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_w + 1023) / 1024, max_h, n), dim3(256), 0, s, desc_dev, planes_ws, pixels);
+    CH_REQUIRE(max_h <= 4 * 65535, "jpeg_reconstruct: image taller than 262140 rows");
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_w + 255) / 256, (max_h + 3) / 4, n), dim3(64, 4), 0, s, desc_dev, planes_ws, pixels);
     CH_LAUNCH_CHECK();
     return 0;
 }
