@@ -64,7 +64,7 @@ SIGNATURES = {
     "ch_encode": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "ch_encode_hidden": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
-    "ch_preprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p,
+    "ch_preprocess": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_float), POINTER(c_float), c_void_p,
                               c_int32, c_void_p, c_void_p]),
     "ch_preprocess_max_taps": (c_int32, []),
     "ch_jpeg_plan": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),

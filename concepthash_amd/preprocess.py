@@ -35,6 +35,12 @@ def _row_bounds(in_size: int, out_size: int, xx: int):
     return xmin, xmax
 
 
+def _taps(in_size: int, out_size: int) -> int:
+    """Pillow's ksize for a (0, in_size) -> out_size bicubic resize: an upper bound of the taps of any output index."""
+    scale = float(np.float32(in_size)) / out_size
+    return int(math.ceil(2.0 * max(scale, 1.0))) * 2 + 1
+
+
 class GpuPreprocess:
     """Resize(resize, bicubic) -> CenterCrop(crop) -> ToTensor -> Normalize(mean, std), on the GPU."""
 
@@ -64,7 +70,7 @@ class GpuPreprocess:
     _RING = 8          # pinned descriptor staging buffers in flight
 
     def _geometry(self, h: int, w: int):
-        """(nh, nw, top, left, row0, nrows) of one image size; cached -- dataset images repeat a handful of sizes."""
+        """(nh, nw, top, left, row0, nrows, horizontal taps) of one image size; cached -- dataset images repeat a handful of sizes."""
         key = (h, w)
         g = self._geo.get(key)
         if g is None:
@@ -73,18 +79,19 @@ class GpuPreprocess:
             if any(2 * math.ceil(2.0 * max(n_in / n_out, 1.0)) + 1 > self.max_taps for n_in, n_out in ((w, nw), (h, nh))):
                 # down-scaling beyond ~15x (a 12-megapixel photograph to 256): more filter taps than the kernels hold.  nrows = 0 makes the
                 # kernels skip the image; __call__ runs the chain for it with Pillow on the host (`_host_route`), the reference's own path
-                g = self._geo[key] = (nh, nw, top, left, 0, 0)
+                g = self._geo[key] = (nh, nw, top, left, 0, 0, 0)
                 return g
             r0, _ = _row_bounds(h, nh, top)
             rl, cl = _row_bounds(h, nh, top + self.crop - 1)
-            g = self._geo[key] = (nh, nw, top, left, r0, rl + cl - r0)
+            g = self._geo[key] = (nh, nw, top, left, r0, rl + cl - r0, _taps(w, nw))
         return g
 
     def plan(self, sizes: Sequence[tuple]):
-        """sizes: [(h, w)] -> (descriptor array (numpy, ch_image_desc layout), total source bytes, workspace bytes, max rows)."""
+        """sizes: [(h, w)] -> (descriptor array (numpy, ch_image_desc layout), total source bytes, workspace bytes, max rows,
+        max horizontal taps)."""
         B = len(sizes)
         hw = np.asarray(sizes, dtype=np.int64).reshape(B, 2)
-        geo = np.asarray([self._geometry(int(h), int(w)) for h, w in sizes], dtype=np.int64).reshape(B, 6)
+        geo = np.asarray([self._geometry(int(h), int(w)) for h, w in sizes], dtype=np.int64).reshape(B, 7)
         desc = np.zeros(B, dtype=self._DESC_DTYPE)
         src = hw[:, 0] * hw[:, 1] * 3
         tmp = geo[:, 5] * self.crop * 3
@@ -93,7 +100,7 @@ class GpuPreprocess:
         desc["h"], desc["w"] = hw[:, 0], hw[:, 1]
         for j, name in enumerate(("nh", "nw", "top", "left", "row0", "nrows")):
             desc[name] = geo[:, j]
-        return desc, int(src.sum()), int(tmp.sum()), int(max(1, geo[:, 5].max())) if B else 1
+        return desc, int(src.sum()), int(tmp.sum()), (int(max(1, geo[:, 5].max())) if B else 1), (int(geo[:, 6].max()) if B else 0)
 
     def plan_boxes(self, sizes: Sequence[tuple], boxes, flips=None):
         """The training chain (configs/dataset/cub200.yaml:13-23): RandomResizedCrop(crop, bicubic) -> RandomHorizontalFlip.  boxes:
@@ -118,7 +125,8 @@ class GpuPreprocess:
         desc["stride"] = hw[:, 1]
         if flips is not None:
             desc["flip"] = np.asarray(flips, dtype=np.int64).reshape(B) != 0
-        return desc, int(src.sum()), int(tmp.sum()), int(max(1, desc["nrows"].max())) if B else 1
+        taps = max([_taps(int(b[3]), self.crop) for b, big in zip(bx, too_big) if not big], default=0)
+        return desc, int(src.sum()), int(tmp.sum()), (int(max(1, desc["nrows"].max())) if B else 1), taps
 
     def _host_route(self, pixels, sizes, desc, boxes, flips, out, stream):
         """Images the kernels skipped (nrows == 0: down-scaling beyond the tap limit) through Pillow on the host -- rare (a handful of very
@@ -177,14 +185,14 @@ class GpuPreprocess:
         out = torch.empty(B, 3, self.crop, self.crop, dtype=self.out_dtype, device=pixels.device)
         if B == 0:
             return out
-        desc, nbytes, ws_bytes, max_rows = self.plan(sizes) if boxes is None else self.plan_boxes(sizes, boxes, flips)
+        desc, nbytes, ws_bytes, max_rows, max_taps = self.plan(sizes) if boxes is None else self.plan_boxes(sizes, boxes, flips)
         if pixels.numel() != nbytes:
             raise ValueError(f"pixels holds {pixels.numel()} bytes, the sizes add up to {nbytes}")
         pixels = pixels.contiguous()
         with torch.cuda.device(pixels.device):
             ddev = self._stage(desc, pixels.device, stream)
             ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=pixels.device)
-            _lib.check(self.lib.ch_preprocess(_lib.ptr(pixels), _lib.ptr(ddev), B, max_rows, self.crop, self._mean, self._std,
+            _lib.check(self.lib.ch_preprocess(_lib.ptr(pixels), _lib.ptr(ddev), B, max_rows, max_taps, self.crop, self._mean, self._std,
                                               _lib.ptr(out), 1 if self.out_dtype == torch.bfloat16 else 0, _lib.ptr(ws),
                                               _lib.stream_ptr(stream)), "ch_preprocess")
             if (desc["nrows"] == 0).any():

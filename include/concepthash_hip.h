@@ -29,8 +29,8 @@ extern "C" {
 /* 2 (round 4): ch_encode / ch_train_forward take the layout of the concept-attention tap as an argument (ch_model_set_concept_attn_layers
  * is gone), ch_model_profile_end takes the capacity of the caller's arrays, ch_model_set_option / ch_model_get_option replace every
  * environment variable the library used to read.
- * 3 (late round 4): ch_image_desc gained `stride` and `flip` (56 bytes: the training transforms through ch_preprocess); ch_tensor.data may be a
- * device pointer; new entry points ch_jpeg_* (decode split), ch_io_file_sizes / ch_io_read_files (batch file reads). */
+ * 3 (late round 4): ch_image_desc gained `stride` and `flip` (56 bytes: the training transforms through ch_preprocess), ch_preprocess takes
+ * `max_taps` (kernel selection); ch_tensor.data may be a device pointer; new entry points ch_jpeg_* (decode split), ch_io_file_sizes / ch_io_read_files (batch file reads). */
 #define CH_ABI_VERSION 3
 
 typedef struct ch_model ch_model; /* opaque: weights (bf16/fp32, device) + activation workspace */
@@ -222,12 +222,16 @@ typedef struct ch_image_desc {
 } ch_image_desc;
 
 /* pixels: device uint8; desc_device: device array of B descriptors; max_rows = max nrows over the batch;
+ * max_taps: an upper bound of the horizontal pass's filter taps per output column over the batch's images with nrows > 0 --
+ * Pillow's ksize = 2 * ceil(2 * max(w / nw, 1)) + 1 (w / nw in double precision) -- or 0 = not known.  It only selects kernels:
+ * up to 16 taps (down-scaling up to 3.5x) with crop % 4 == 0, a 4-byte-aligned workspace and a 16-byte-aligned `out` run the
+ * dword forms of the two passes (2.5x faster on MI355X), anything else the byte forms; the results are the same bits;
  * mean3_host / std3_host: HOST float[3]; out: device NCHW [B,3,crop,crop], out_dtype 0 = fp32, 1 = bf16;
  * workspace: device bytes, >= sum of nrows * crop * 3.  Resampling is Pillow's two-pass 8-bit bicubic (22-bit fixed-point
  * coefficients, uint8 intermediate): the uint8 pixels are bit-equal to PIL's, the output to the CPU chain's. */
-int ch_preprocess(const uint8_t *pixels, const ch_image_desc *desc_device, int32_t B, int32_t max_rows, int32_t crop,
-                  const float *mean3_host, const float *std3_host, void *out, int32_t out_dtype, uint8_t *workspace,
-                  void *stream);
+int ch_preprocess(const uint8_t *pixels, const ch_image_desc *desc_device, int32_t B, int32_t max_rows, int32_t max_taps,
+                  int32_t crop, const float *mean3_host, const float *std3_host, void *out, int32_t out_dtype,
+                  uint8_t *workspace, void *stream);
 /* largest number of filter taps per output pixel the kernels hold (down-scaling factor up to ~15.5) */
 int32_t ch_preprocess_max_taps(void);
 

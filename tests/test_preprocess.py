@@ -241,6 +241,57 @@ def test_gpu_preprocess_equals_the_pil_chain_bit_for_bit():
 
 
 @pytest.mark.gpu
+def test_gpu_preprocess_kernel_forms_agree_with_pillow():
+    """`ch_preprocess` picks its kernels by the batch: the dword forms (crop % 4 == 0; coefficients in registers for up to 8 or up to 16
+    horizontal taps) or the byte forms (any crop, up to 64 taps).  Every combination against the PIL chain, evaluation and training
+    geometry (crop boxes inside wider images, flipped or not), fp32 and bf16."""
+    from concepthash_amd.preprocess import GpuPreprocess, _taps
+    from utils import transforms as T
+    from utils.transforms import _NORMS
+    dev = torch.device("cuda:0")
+    batches = {8: [(375, 500), (500, 375), (333, 500), (64, 48), (257, 300), (256, 256), (100, 731)],     # <= 8 taps
+               16: [(600, 800), (820, 640), (375, 500), (880, 881)],                                     # 9 .. 16 taps
+               64: [(1200, 900), (375, 500), (2000, 1500)]}                                              # more: byte-form horizontal pass
+    for bound, sizes in batches.items():
+        imgs = [_image(h, w, 3 + i) for i, (h, w) in enumerate(sizes)]
+        pixels = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).to(dev)
+        for crop in (224, 222, 256):                                                  # 222: byte forms of both passes
+            resize = 256 if crop < 256 else 292
+            pre = GpuPreprocess(resize, crop, *_NORMS[3], out_dtype=torch.float32, device=dev)
+            taps = pre.plan(sizes)[4]
+            assert {8: 0, 16: 8, 64: 16}[bound] < taps <= bound, (bound, taps)
+            want = torch.stack([_pil_chain(im, resize, crop, 3) for im in imgs])
+            got = pre(pixels, sizes).cpu()
+            assert torch.equal(got, want), (bound, crop, float((got - want).abs().max()))
+            got16 = GpuPreprocess(resize, crop, *_NORMS[3], out_dtype=torch.bfloat16, device=dev)(pixels, sizes).cpu()
+            assert torch.equal(got16, want.to(torch.bfloat16)), (bound, crop)
+        # training geometry: a box per image, every second one flipped
+        rng = np.random.default_rng(bound)
+        boxes, flips, want = [], [], []
+        for i, (im, (h, w)) in enumerate(zip(imgs, sizes)):
+            bh, bw = int(rng.integers(h // 3, h + 1)), int(rng.integers(w // 3, w + 1))
+            top, left = int(rng.integers(0, h - bh + 1)), int(rng.integers(0, w - bw + 1))
+            boxes.append((top, left, bh, bw))
+            flips.append(i % 2 == 1)
+            ref = Image.fromarray(im).crop((left, top, left + bw, top + bh)).resize((224, 224), Image.BICUBIC)
+            if flips[-1]:
+                ref = ref.transpose(Image.FLIP_LEFT_RIGHT)
+            want.append(T.normalize_transform(3)(T.ToTensor()(ref)))
+        pre = GpuPreprocess(256, 224, *_NORMS[3], out_dtype=torch.float32, device=dev)
+        assert pre.plan_boxes(sizes, boxes, flips)[4] == max(_taps(b[3], 224) for b in boxes)
+        got = pre(pixels, sizes, boxes=boxes, flips=flips).cpu()
+        assert torch.equal(got, torch.stack(want)), bound
+    # an image whose rows start at every alignment (odd width, odd offset in the batch): the 16-byte staging of the horizontal pass
+    sizes = [(61, 77), (59, 81), (300, 403), (301, 405), (64, 67)]
+    imgs = [_image(h, w, 11 + i) for i, (h, w) in enumerate(sizes)]
+    pixels = torch.from_numpy(np.concatenate([im.reshape(-1) for im in imgs])).to(dev)
+    for crop in (32, 224, 8):
+        resize = max(crop, 40)
+        got = GpuPreprocess(resize, crop, *_NORMS[3], out_dtype=torch.float32, device=dev)(pixels, sizes).cpu()
+        assert torch.equal(got, torch.stack([_pil_chain(im, resize, crop, 3) for im in imgs])), crop
+
+
+@pytest.mark.gpu
 def test_gpu_preprocess_feeds_the_encoder():
     """decoded bytes -> GPU pre-processing -> ch_encode: same codes as the CPU chain's tensors given to the encoder."""
     from concepthash_amd.encoder import ConceptHashEncoder
