@@ -64,6 +64,22 @@ def _write_dataset(root, sizes, quality=90, progressive_every=0):
     open(os.path.join(root, "train.txt"), "w").write("".join(lines))
 
 
+def test_tap_bound_covers_every_output_index():
+    """`ch_preprocess(max_taps=...)` picks kernels that hold their coefficients in 8 or 16 registers: the bound the planner passes
+    (Pillow's ksize) must cover the taps of every output index of every image, for the evaluation geometry and for crop boxes."""
+    from concepthash_amd.preprocess import _resized_size, _row_bounds, _taps
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        h, w = int(rng.integers(8, 3000)), int(rng.integers(8, 3000))
+        nw, _ = _resized_size(w, h, 256)
+        bound = _taps(w, nw)
+        assert bound % 2 == 1 and bound >= 5
+        assert max(_row_bounds(w, nw, xx)[1] for xx in range(nw)) <= bound
+        bw = int(rng.integers(1, w + 1))                       # a crop box resized to 224 columns
+        assert max(_row_bounds(bw, 224, xx)[1] for xx in range(224)) <= _taps(bw, 224)
+    assert _taps(500, 341) == 7 and _taps(375, 256) == 7 and _taps(300, 600) == 5 and _taps(1024, 256) == 17
+
+
 def test_jpeg_size_reads_the_frame_header(tmp_path):
     import io
     from utils.datasets import jpeg_size
