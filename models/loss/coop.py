@@ -106,7 +106,9 @@ class LGHLoss(nn.Module):
             # avg_attn: torch.stack(attn_cache).mean(0) sliced to the concept rows == the layer mean of every layer's concept rows
             att = outputs[key].mean(dim=0) if self.avg_attn else outputs[key]
             a = F.normalize(att.mean(dim=1), dim=-1, p=2)
-            cos = a @ a.transpose(1, 2)
+            # the Q x Q Gram matrix of 4 concept tokens, element-wise: a batched matmul would initialise the BLAS library for it (0.18 s in an
+            # evaluation command, where nothing else on the torch side multiplies matrices)
+            cos = (a.unsqueeze(2) * a.unsqueeze(1)).sum(-1)
             if self.div_method == 0:
                 cos = (cos - self.div_min).relu()
             cos = cos.mean(dim=0)

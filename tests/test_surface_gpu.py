@@ -185,3 +185,45 @@ def test_main_v2_two_ranks_on_one_gpu_match_the_single_process_run(tmp_path):
     assert h3["mAP"] == h4["mAP"] and h3["precisions"] == h4["precisions"] and h3["recalls"] == h4["recalls"]
     assert h3["mAP"] != h1["mAP"]                                  # the options did change the codes that were scored
     assert not os.path.exists(os.path.join(ev4, "outputs.pth"))
+
+
+@pytest.mark.gpu
+def test_module_to_device_moves_a_module_in_one_copy_per_dtype():
+    """`utils.misc.module_to_device` (BaseTrainer.to_device): every parameter / buffer lands on the GPU with the values, dtypes, shapes
+    and flags `module.to` gives, as views of one buffer per dtype; `_apply` overrides still see the move."""
+    import copy
+    from utils.misc import module_to_device
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.BatchNorm1d(19), torch.nn.Linear(19, 3, bias=False))
+            self.frozen = torch.nn.Parameter(torch.randn(5, 7, 3), requires_grad=False)
+            self.register_buffer("ids", torch.arange(11))
+            self.register_buffer("strided", torch.randn(6, 4).t())       # not contiguous: moved by module.to itself
+            self.tied = self.body[0].weight                                # one Parameter under two names
+            self.applied = 0
+
+        def _apply(self, fn, *a, **k):
+            self.applied += 1
+            return super()._apply(fn, *a, **k)
+
+    torch.manual_seed(0)
+    net = Net()
+    ref = copy.deepcopy(net).to("cuda:0")
+    out = module_to_device(net, "cuda:0")
+    assert out is net and net.applied == 1
+    got, want = dict(net.state_dict()), dict(ref.state_dict())
+    assert got.keys() == want.keys()
+    for k in want:
+        assert got[k].device == want[k].device and got[k].dtype == want[k].dtype and got[k].shape == want[k].shape, k
+        assert torch.equal(got[k], want[k]), k
+    assert net.tied is net.body[0].weight and net.body[0].weight.requires_grad and not net.frozen.requires_grad
+    f32 = [p for p in net.parameters()] + [net.body[1].running_mean, net.body[1].running_var]
+    base = f32[0].untyped_storage().data_ptr()
+    assert all(t.untyped_storage().data_ptr() == base for t in f32)       # one device buffer for the fp32 tensors
+    assert all(t.data_ptr() % 256 == 0 for t in f32)
+    x = torch.randn(8, 37, device="cuda:0")
+    assert torch.equal(net.body(x), ref.body(x))
+    net.body(x).sum().backward()                                           # the views are ordinary leaf parameters
+    assert net.body[0].weight.grad is not None and net.frozen.grad is None

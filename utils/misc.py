@@ -143,3 +143,40 @@ class DeviceMeters:
             if ev.query():
                 return {k: round(m.avg, 4) for k, m in self._to_meters(pinned, counts, names, host).items()}
         return None
+
+
+def module_to_device(module, device):
+    """`module.to(device)` for a host module whose tensors are many: ONE host -> device copy per dtype instead of one per tensor.
+
+    On ROCm every copy from fresh pageable memory registers its pages with the driver first -- ~1.3 ms per call whatever the size: the
+    567 tensors of a ViT-B/16 ConceptHash model took 0.78 s to move, a single 344 MB tensor takes 17 ms.  The tensors are packed into
+    one host buffer per dtype (each at a 256-byte boundary), copied once, and every parameter / buffer becomes a view of the device
+    buffer (`param.data = view`, exactly what `nn.Module._apply` does with the tensor `.to` returns); `module.to(device)` then runs as
+    usual -- nothing left to copy -- so hooks in `_apply` overrides still fire.  Other moves (device -> device, dtype changes) are
+    `module.to` unchanged."""
+    import torch
+    device = torch.device(device)
+    if device.type != "cuda":
+        return module.to(device)
+    seen, groups = set(), {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t is None or id(t) in seen or t.device.type != "cpu" or t.numel() == 0 or not t.data.is_contiguous():
+            continue
+        seen.add(id(t))
+        groups.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for dtype, tensors in groups.items():
+            if len(tensors) < 2:
+                continue
+            align = max(1, 256 // tensors[0].element_size())
+            offsets, total = [], 0
+            for t in tensors:
+                offsets.append(total)
+                total += -(-t.numel() // align) * align
+            host = torch.empty(total, dtype=dtype)
+            for t, o in zip(tensors, offsets):
+                host[o:o + t.numel()].copy_(t.data.reshape(-1))
+            dev = host.to(device)
+            for t, o in zip(tensors, offsets):
+                t.data = dev[o:o + t.numel()].view(t.shape)
+    return module.to(device)
