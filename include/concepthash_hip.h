@@ -224,8 +224,8 @@ typedef struct ch_image_desc {
 /* pixels: device uint8; desc_device: device array of B descriptors; max_rows = max nrows over the batch;
  * max_taps: an upper bound of the horizontal pass's filter taps per output column over the batch's images with nrows > 0 --
  * Pillow's ksize = 2 * ceil(2 * max(w / nw, 1)) + 1 (w / nw in double precision) -- or 0 = not known.  It only selects kernels:
- * up to 16 taps (down-scaling up to 3.5x) with crop % 4 == 0, a 4-byte-aligned workspace and a 16-byte-aligned `out` run the
- * dword forms of the two passes (2.5x faster on MI355X), anything else the byte forms; the results are the same bits;
+ * up to 16 taps (down-scaling up to 3.5x) with crop % 4 == 0, 4-byte-aligned `pixels` and workspace and a 16-byte-aligned `out`
+ * run the dword forms of the two passes (3x faster on MI355X), anything else the byte forms; the results are the same bits;
  * mean3_host / std3_host: HOST float[3]; out: device NCHW [B,3,crop,crop], out_dtype 0 = fp32, 1 = bf16;
  * workspace: device bytes, >= sum of nrows * crop * 3.  Resampling is Pillow's two-pass 8-bit bicubic (22-bit fixed-point
  * coefficients, uint8 intermediate): the uint8 pixels are bit-equal to PIL's, the output to the CPU chain's. */
