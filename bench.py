@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the single-stream profiled pass")
     ap.add_argument("--no-evaluator", action="store_true", help="skip the evaluator-inclusive block (COOPTrainer.inference_one_epoch)")
     ap.add_argument("--no-loader", action="store_true", help="skip the loader-inclusive block (JPEG files -> DataLoader -> decode -> encode)")
-    ap.add_argument("--loader-images", type=int, default=4096, help="JPEG files the loader-inclusive block generates and reads")
+    ap.add_argument("--loader-images", type=int, default=8192, help="JPEG files the loader-inclusive block generates and reads")
     ap.add_argument("--encode-only", action="store_true",
                     help="nothing but the timed encode + retrieve steps (and the roofline pass unless --no-roofline-pass): no "
                          "pcie / decode / evaluator / training / Hamming-scan / CPU-baseline blocks -- what the rocprofv3 passes of "
