@@ -130,7 +130,7 @@ class RetrievalEvaluation:
                     for R, r, p in zip(Rs, recalls, precisions):
                         print(f"P@{R}: {p:.4f}; R@{R}: {r:.4f}")
                 print()
-            res["timing_s"] = dict(self.timing, since_start=round(time.time() - self.start_time, 3))
+            res["timing_s"] = dict(self.timing, since_start=round(time.time() - self.start_time, 3), written_unix=round(time.time(), 3))
             if self.rank == 0:
                 with open(os.path.join(self.eval_logdir, "history.json"), "w") as f:
                     json.dump(res, f)

@@ -27,6 +27,8 @@ from concepthash_amd import config as cfglib
 EVAL_KEYS = ("dataset", "data_dir", "work_dir", "eval_logdir", "R", "PRs", "use_last", "compute_mAP", "ternary_threshold",
              "dist_metric", "batch_size", "save_code", "sub_code_eval", "sub_code_eval_setting", "zero_mean_eval",
              "test_as_database")
+# knobs of this implementation's evaluation loop (configs/val.yaml), overlaid the same way
+LOOP_KEYS = ("eval_batch_min", "meter_stream")
 
 
 def run(config):
@@ -43,6 +45,9 @@ def run(config):
         load_config = cfglib.load(os.path.join(config.logdir, "config.yaml"))
         for k in EVAL_KEYS:                      # reference main_v2.py:23-40
             load_config[k] = config[k]
+        for k in LOOP_KEYS:
+            if k in config:
+                load_config[k] = config[k]
         load_config["logdir"] = config.logdir if os.path.isabs(str(config.logdir)) else f"{config.work_dir}/{config.logdir}"
         load_config["wandb"] = False
         load_config["exp"] = "validation"

@@ -316,13 +316,15 @@ def test_trainer_with_gpu_decode_gives_the_codes_of_the_cpu_loader(tmp_path):
 
     chain = [T.Resize(256, T.interpolation("bicubic")), T.CenterCrop(224), T.ToTensor(), T.normalize_transform(3)]
     codes = {}
-    for mode in (False, True):
-        conf = cfglib.DictConfig(device="cuda", batch_size=4, model=cfglib.DictConfig(),
-                                 dataset=cfglib.DictConfig(multiclass=False, resize=256, crop=224, norm=3, gpu_preprocess=mode, gpu_decode=mode))
+    for mode in (False, True, "coalesced"):
+        # `eval_batch_min` (default 256) reads a GPU-decode evaluation split in larger batches than configured: 0 keeps the two batches of 4 + 3
+        conf = cfglib.DictConfig(device="cuda", batch_size=4, model=cfglib.DictConfig(), eval_batch_min=0 if mode is True else 256,
+                                 dataset=cfglib.DictConfig(multiclass=False, resize=256, crop=224, norm=3, gpu_preprocess=bool(mode), gpu_decode=bool(mode)))
         tr = COOPTrainer(conf)
         tr.dataset = {"train": [], "db": [], "test": HashingDataset(str(root), "test.txt", transform=chain, target_transform=OneHot(3),
-                                                                     gpu_decode=mode)}
+                                                                     gpu_decode=bool(mode))}
         tr.load_dataloader()
+        assert len(tr.dataloader["test"]) == (1 if mode == "coalesced" else 2)
         tr.model, tr.criterion = Model(), Crit()
         meters, out = tr.inference_one_epoch("test", True)
         codes[mode] = out["codes"]
@@ -330,7 +332,7 @@ def test_trainer_with_gpu_decode_gives_the_codes_of_the_cpu_loader(tmp_path):
         if mode:
             assert tr._gpu_jpeg.stats["pil_fallback"] == 1 and tr._gpu_jpeg.stats["gpu"] == 6
     # the CPU loader hands fp32 tensors to the model, the GPU path bf16: compare through the same rounding
-    assert torch.equal(codes[True], codes[False])
+    assert torch.equal(codes[True], codes[False]) and torch.equal(codes["coalesced"], codes[False])
 
 
 def test_packed_batch_calls_equal_the_per_file_calls():
