@@ -10,13 +10,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libconcepthash_hip.so")
-SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip",
+SOURCES = ["model.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_r4.hip", "attention.hip", "rowops.hip", "head.hip", "small_f32.hip", "hamming.hip",
            "preprocess.hip", "train_kernels.hip", "attention_bwd.hip", "train.hip", "jpeg.hip", "jpeg_host.cpp", "errors.cpp"]
 # plain C++ sources (no HIP): compiled by the same driver as host code; tests/test_jpeg.py also builds them with g++ -fsanitize=address,undefined
 HOST_SOURCES = ["jpeg_host.cpp", "errors.cpp"]
 # kernels that lost to the dispatched ones (DESIGN.md sections 3.8-3.9): kept in csrc/experiments/ with their parity tests, compiled
 # only into an experiments build (CH_BUILD_EXPERIMENTS=1), never into the product library
-EXPERIMENT_SOURCES = [os.path.join("experiments", f) for f in ("gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip", "gemm_r4.hip",
+EXPERIMENT_SOURCES = [os.path.join("experiments", f) for f in ("gemm_pq.hip", "gemm_ppp.hip", "gemm_dp.hip",
                                                                 "adapter_fused.hip", "gemm_rows.hip", "gemm_wide.hip")]
 HEADERS = ["ch_common.h", "ch_host.h", "kernels.h", "gemm_epilogue.h", "model_internal.h", os.path.join("..", "..", "include", "concepthash_hip.h"),
            os.path.join("..", "..", "include", "concepthash_hip_debug.h")]

@@ -17,11 +17,14 @@
 //     buffer of stage kt-1 -> 8 fragment reads -> 16 MFMAs.
 // N must be a multiple of 128, K a multiple of 32, X padded to a multiple of 128 rows.
 //
-// RESULT (round 2, MI355X): bit-identical, and SLOWER than the kernel it was meant to replace -- down-projection 60.6 vs 54.8 us,
-// up-projection 107.1 vs 99.9 us per launch at 51,456 rows; encode 20,350-20,522 vs 20,460-20,505 images/s.  The premise was
-// wrong: a 128x128 tile of 64x64 wave tiles is LDS-bandwidth bound, not latency bound -- per 32-deep K-step a workgroup
-// reads 32 KB of fragments and receives 16 KB of LDS-DMA for 256 MFMA cycles per SIMD -- so keeping more K-steps in flight
-// buys nothing and the extra barriers cost.  Experiments build only.
+// RESULT (round 2, MI355X): bit-identical, and SLOWER than the kernel it was meant to replace at the benchmark's size -- down-projection
+// 60.6 vs 54.8 us, up-projection 107.1 vs 99.9 us per launch at 51,456 rows; encode 20,350-20,522 vs 20,460-20,505 images/s: a 128x128
+// tile of 64x64 wave tiles is LDS-bandwidth bound there, not latency bound -- per 32-deep K-step a workgroup reads 32 KB of fragments
+// and receives 16 KB of LDS-DMA for 256 MFMA cycles per SIMD -- so keeping more K-steps in flight buys nothing and the extra barriers
+// cost.  SMALL grids are the other regime (round 4, profiles/r04_small_batch_ring_ab.txt): at 1,608 rows (batch 8) a GEMM is 39-78
+// workgroups, one per CU with nothing beside it, and a step is 115 launches of 17 us each, every one a chain of L2 round trips; there
+// the ring wins -- 1.73 -> 1.63 ms at batch 1, 1.92 -> 1.78 ms at batch 8, 2.76 -> 2.69 ms at batch 32.  The dispatcher (gemm_bf16.hip)
+// sends the forward epilogues here up to CH_RING_MAX_ROWS rows; same bits either way.
 #include "ch_common.h"
 #include "kernels.h"
 #include "gemm_epilogue.h"
@@ -32,7 +35,7 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 16 KiB
 // NS (template): 4 = the ring above (64 KB, two workgroups per CU); 2 = one K-step in flight, 32 KB of LDS and <= 128 VGPRs so that FOUR
 // workgroups share a CU (bf16-output epilogues only: their staging is 8 KB per wave) -- the occupancy experiment of round 3
-// (CH_R4_STAGES=2; the bandwidth-bound adapter launches lose 24-34 % when a CU holds one workgroup instead of two).
+// (not instantiated any more; the bandwidth-bound adapter launches lose 24-34 % when a CU holds one workgroup instead of two).
 constexpr int NTHREADS = 256;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -164,25 +167,14 @@ int launch_r4(const GemmParams &p0, hipStream_t s) {
 
 }  // namespace
 
-bool ch_gemm_r4_supported(const GemmParams &p) {
-    return p.N % BN == 0 && p.K % BK == 0 && p.K >= 3 * BK && p.X_rows_alloc >= round_up64(p.M, BM);
+bool ch_gemm_r4_supported(const GemmParams &p, int epi) {   // the forward epilogues (the training-only ones stay with gemm_bf16.hip)
+    return epi >= EPI_BIAS && epi <= EPI_FOLD_GELU && p.N % BN == 0 && p.K % BK == 0 && p.K >= 3 * BK && p.X_rows_alloc >= round_up64(p.M, BM);
 }
 
 int ch_gemm_bf16_r4(const GemmParams &p, int epi, hipStream_t s) {
     CH_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem");
     CH_REQUIRE(epi == EPI_PATCH || p.bias != nullptr, "gemm: bias is required");
-    CH_REQUIRE(ch_gemm_r4_supported(p), "gemm_r4: needs N % 128 == 0, K % 32 == 0, K >= 96, X padded to 128 rows");
-    static const int two = getenv("CH_R4_STAGES") && atoi(getenv("CH_R4_STAGES")) == 2;
-    if (two && ch_epi::traits<EPI_BIAS>::bf16_only) {   // bf16-output epilogues: the four-workgroups-per-CU instance
-        switch (epi) {
-            case EPI_BIAS: return launch_r4<EPI_BIAS, 2>(p, s);
-            case EPI_BIAS_GELU: return launch_r4<EPI_BIAS_GELU, 2>(p, s);
-            case EPI_BIAS_STATS: return launch_r4<EPI_BIAS_STATS, 2>(p, s);
-            case EPI_FOLD_BIAS: return launch_r4<EPI_FOLD_BIAS, 2>(p, s);
-            case EPI_FOLD_GELU: return launch_r4<EPI_FOLD_GELU, 2>(p, s);
-            default: break;
-        }
-    }
+    CH_REQUIRE(ch_gemm_r4_supported(p, epi), "gemm_r4: needs a forward epilogue, N % 128 == 0, K % 32 == 0, K >= 96, X padded to 128 rows");
     switch (epi) {
         case EPI_BIAS: return launch_r4<EPI_BIAS>(p, s);
         case EPI_BIAS_QUICKGELU: return launch_r4<EPI_BIAS_QUICKGELU>(p, s);

@@ -66,7 +66,7 @@ struct GemmParams {
     int nt_resid;            // 1 = launch the instance with the non-temporal read-modify-write of the fp32 residual (set by the dispatcher)
     int nt_out;              // 1 = store out_bf16 non-temporally (an output larger than the Infinity Cache that is read once, much later)
     int tag;                 // profiling only: 1 = launch the 256x256 kernel under its second symbol name (gemm_pp.hip, TAG)
-    int small_kernel;        // dispatcher, GEMMs that do not go to the 256x256 kernel: 0 = default, 1 = 128x128x64 two-phase, 2 = 128x128x32 ring (experiments build)
+    int small_kernel;        // dispatcher, GEMMs that do not go to the 256x256 kernel: 0 = default, 1 = 128x128x64 two-phase, 2 = 128x128x32 ring at every size
     // per-model options handed down by the launch chain (ch_model_set_option); zero = the dispatcher's own choice
     int nt_resid_opt;        // 0 = by tensor size, 1 = non-temporal residual instance, -1 = default-policy instance
     int nt_out_opt;          // the same for the non-temporal bf16 output instance
@@ -82,6 +82,9 @@ int ch_gemm_bf16(const GemmParams &p, int epi, hipStream_t s);      // dispatche
 int ch_gemm_bf16_v1(const GemmParams &p, int epi, hipStream_t s);   // gemm_bf16.hip: 128x128x64, two-phase
 int ch_gemm_bf16_pp(const GemmParams &p, int epi, hipStream_t s);   // gemm_pp.hip: 256x256x64, ping-pong 8-phase
 bool ch_gemm_pp_supported(const GemmParams &p);
+int ch_gemm_bf16_r4(const GemmParams &p, int epi, hipStream_t s);   // gemm_r4.hip: 128x128x32, 4-stage ring, 2 workgroups/CU (small grids)
+bool ch_gemm_r4_supported(const GemmParams &p, int epi);
+constexpr int64_t CH_RING_MAX_ROWS = 8192;   // up to this many rows the GEMMs of the 128x128 path run the ring kernel (latency-bound grids)
 
 // Experiment kernels that did not beat the dispatched ones: built only with CH_BUILD_EXPERIMENTS=1
 // (-DCH_EXPERIMENTS); the product library does not contain them and their taps say so.
@@ -92,8 +95,6 @@ int ch_gemm_bf16_ppp(const GemmParams &p, int epi, hipStream_t s);  // gemm_ppp.
 bool ch_gemm_ppp_supported(const GemmParams &p, int epi);
 int ch_gemm_bf16_dp(const GemmParams &p, int epi, hipStream_t s);   // gemm_dp.hip: 256x128x32, 3-stage ring, 2 workgroups/CU
 bool ch_gemm_dp_supported(const GemmParams &p);
-int ch_gemm_bf16_r4(const GemmParams &p, int epi, hipStream_t s);   // gemm_r4.hip: 128x128x32, 4-stage ring, 2 workgroups/CU
-bool ch_gemm_r4_supported(const GemmParams &p);
 int ch_gemm_bf16_rows(const GemmParams &p, int epi, hipStream_t s); // gemm_rows.hip: 128 whole rows x N = 384 per workgroup (adapter down-projection)
 bool ch_gemm_rows_supported(const GemmParams &p, int epi);
 int ch_gemm_bf16_wide(const GemmParams &p, int epi, hipStream_t s); // gemm_wide.hip: 256x384x32, three-stage ring, two-phase ping-pong (N = 384: adapter bottleneck)
@@ -107,8 +108,6 @@ static inline int ch_experiments_not_built() {
 static inline int ch_gemm_bf16_pq(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
 static inline int ch_gemm_bf16_ppp(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
 static inline int ch_gemm_bf16_dp(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
-static inline int ch_gemm_bf16_r4(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
-static inline bool ch_gemm_r4_supported(const GemmParams &) { return false; }
 static inline int ch_gemm_bf16_rows(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }
 static inline bool ch_gemm_rows_supported(const GemmParams &, int) { return false; }
 static inline int ch_gemm_bf16_wide(const GemmParams &, int, hipStream_t) { return ch_experiments_not_built(); }

@@ -699,7 +699,7 @@ extern "C" int ch_model_set_option(ch_model *m, const char *key, int64_t value) 
     }
 #ifndef CH_EXPERIMENTS
     const std::string k = key;
-    if (value != 0 && (k == "fused_adapter" || k == "pp_sched" || k == "gemm_rows" || k == "wide_kernel" || (k == "small_kernel" && value == 2))) {
+    if (value != 0 && (k == "fused_adapter" || k == "pp_sched" || k == "gemm_rows" || k == "wide_kernel")) {
         ch_set_error("set_option: '" + k + "' selects an experiment kernel that is not part of this build (CH_BUILD_EXPERIMENTS=1)");
         return 2;
     }

@@ -78,7 +78,7 @@ struct ch_model {
     // ones that should still be in the 256 MB Infinity Cache.  Measured: no gain (12.44 vs 12.39 ms per step) -> off.
     bool serpentine = false;
     int pp_sched = 0;  // option "pp_sched": schedule of the 256x256 GEMM (gemm_pp.hip)
-    int small_kernel = 0;  // option "small_kernel": 2 = 128x128x32 four-stage ring, experiments build only (0 = dispatcher default)
+    int small_kernel = 0;  // option "small_kernel": 0 = dispatcher (ring up to CH_RING_MAX_ROWS rows), 1 = 128x128x64 two-phase always, 2 = ring always
     int pp_min_k = 0;  // option "pp_min_k" (tests: sends small-K GEMMs of a small fixture to the 256x256 kernel)
     // ---- per-handle tuning / test options (ch_model_set_option; the library reads no environment variable)
     int resid_nt = 0, nt_out = 0;   // cache policy of the fp32 residual read-modify-write / of large bf16 outputs: 0 = by tensor size, 1 = on, -1 = off

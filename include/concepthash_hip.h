@@ -102,7 +102,9 @@ size_t ch_model_device_bytes(const ch_model *m);
  *   "serpentine"    0/1    alternate the row direction of consecutive launches (default 0)
  *   "chain_auto"    0/1    with "streams" = 2: use ONE chain for batches of fewer than 5,600 token rows (batch <= 27 of ViT-B/16), where it
  *                          measures 2-5 % faster.  Default 1; 0 = always split.  Outputs are bit-identical.
- *   "small_kernel", "pp_sched", "fused_adapter", "gemm_rows", "wide_kernel"  experiment kernels: non-zero values need the experiments build
+ *   "small_kernel"  0..2   GEMMs of the 128x128 path: 0 = the four-stage ring kernel up to 8,192 rows (batch <= 40 of ViT-B/16: -7 % per
+ *                          step at batch 8), the two-phase kernel above; 1 = two-phase always; 2 = ring always.  Outputs are bit-identical.
+ *   "pp_sched", "fused_adapter", "gemm_rows", "wide_kernel"  experiment kernels: non-zero values need the experiments build
  *   "train_chains" 1..2, "train_chain_min_rows", "train_prune_last" 0/1, "train_batched_grads" 0/1   read by ch_trainer_create from the model it is created on */
 int ch_model_set_option(ch_model *m, const char *key, int64_t value);
 int ch_model_get_option(ch_model *m, const char *key, int64_t *value);

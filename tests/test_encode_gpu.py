@@ -424,3 +424,27 @@ def test_chain_auto_rule(dev, monkeypatch):
         assert torch.equal(a["codes"], b["codes"]) and torch.equal(a["packed"], b["packed"])
     auto.close()
     split.close()
+
+
+def test_small_grids_run_the_ring_kernel_with_the_same_bits(dev):
+    """Up to 8,192 token rows (batch <= 40 of ViT-B/16) the GEMMs of the 128x128 path run the four-stage ring kernel (gemm_r4.hip; option
+    "small_kernel" 0 = that rule, 1 = the two-phase kernel always, 2 = the ring always).  An image's codes do not depend on the kernel or on
+    the batch it came in: 8 images alone (ring), the same 8 inside a batch of 64 (two-phase / 256x256 kernels), and either kernel forced."""
+    from oracle import encoder_oracle as eo
+    cfg = dict(eo.CONFIGS["vit_b16"])
+    cfg["L"] = 3
+    sd = eo.synthetic_state_dict(cfg, nbit=64, nclass=10)
+    x = eo.synthetic_images(64, cfg["image"]).to(dev).to(torch.bfloat16)
+    want = ("codes", "packed", "logits_cont", "hash_features")
+    encs = {k: _encoder(sd, cfg["heads"], max_batch=64, options={"small_kernel": k}) for k in (0, 1, 2)}
+    big = encs[0].encode(x, want=want)
+    torch.cuda.synchronize()
+    big = {k: v.clone() for k, v in big.items()}
+    for n in (1, 8, 40):
+        outs = {k: {a: b.clone() for a, b in e.encode(x[:n], want=want).items()} for k, e in encs.items()}
+        torch.cuda.synchronize()
+        for key in want:
+            assert torch.equal(outs[0][key], outs[1][key]) and torch.equal(outs[0][key], outs[2][key]), (n, key)
+            assert torch.equal(outs[0][key], big[key][:n]), (n, key)
+    for e in encs.values():
+        e.close()
