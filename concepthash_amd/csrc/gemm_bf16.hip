@@ -278,7 +278,8 @@ int ch_gemm_bf16(const GemmParams &p0, int epi, hipStream_t s) {
     if (p.rows_opt && p.small_kernel == 0 && p.M >= 128 * 128 && ch_gemm_rows_supported(p, epi)) return ch_gemm_bf16_rows(p, epi, s);
     // Small grids (batch <= 40 of ViT-B/16): every launch is one workgroup per CU walking a chain of L2 round trips; the four-stage ring
     // (gemm_r4.hip, bit-identical) keeps three K-steps in flight: -7 % per step at batch 8, -2.5 % at batch 32; slower at 51,456 rows.
-    const bool ring = (p.small_kernel == 2 || g_gemm_variant == 7 || (p.small_kernel == 0 && g_gemm_variant == 0 && p.M <= CH_RING_MAX_ROWS)) &&
+    // (a non-temporal residual instance, chosen by size or forced by the option "resid_nt", exists in the two-phase kernel only and wins)
+    const bool ring = (p.small_kernel == 2 || g_gemm_variant == 7 || (p.small_kernel == 0 && g_gemm_variant == 0 && p.M <= CH_RING_MAX_ROWS && !p.nt_resid)) &&
                       ch_gemm_r4_supported(p, epi);
     return ring ? ch_gemm_bf16_r4(p, epi, s) : ch_gemm_bf16_v1(p, epi, s);
 }
